@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — Gbases/s assembled, k=31, 150 bp reads, on N MI355X (BASELINE.json metric).
+
+A "step" is one pass of the whole hot path over one batch of synthetic reads that are already
+2-bit packed and resident in HBM: shk_new -> shk_preprocess_packed_device (k-mer count ->
+histogram -> filter) -> shk_assemble (graph -> correct -> collapse -> contigs + FASTA/GFA on the
+host) -> shk_get_assembly.  Workload at N=1: BASELINE.json configs[1] — one 5 Mbp isolate,
+100x coverage of 150 bp reads (3 333 334 reads, 500 Mbases), k=31, min_count=5.
+
+Launch: python bench.py --gpus N --steps K --warmup W           (N=1)
+        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_reads_on_device(torch, dev, genome_len, coverage, read_len, seed):
+    """Synthetic isolate + error-free reads, generated and 2-bit packed on the GPU (SURVEY §8d cfg 2).
+    Returns (d_bases int32[words], d_seg_off int32[n_reads+1], n_reads, n_bases, genome codes)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    n_reads = (genome_len * coverage + read_len - 1) // read_len
+    genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.int32)
+    n_bases = n_reads * read_len
+    n_words = (n_bases + 15) // 16 + 1
+    words = torch.zeros(n_words, dtype=torch.int32, device=dev)
+    shifts = (2 * torch.arange(16, device=dev, dtype=torch.int32))
+    chunk = 1 << 18                                     # reads per chunk (chunk*read_len % 16 == 0)
+    ar = torch.arange(read_len, device=dev)
+    for r0 in range(0, n_reads, chunk):
+        r1 = min(n_reads, r0 + chunk)
+        starts = torch.randint(0, genome_len - read_len + 1, (r1 - r0,), generator=g, device=dev)
+        strand = torch.randint(0, 2, (r1 - r0,), generator=g, device=dev).bool()
+        codes = genome[starts[:, None] + ar[None, :]]
+        rc = (3 - codes).flip(1)
+        codes = torch.where(strand[:, None], rc, codes).reshape(-1)
+        pad = (-codes.numel()) % 16
+        if pad:
+            codes = torch.cat([codes, torch.zeros(pad, dtype=torch.int32, device=dev)])
+        w = (codes.reshape(-1, 16) << shifts[None, :]).sum(dim=1, dtype=torch.int32)
+        w0 = (r0 * read_len) // 16
+        assert (r0 * read_len) % 16 == 0
+        words[w0:w0 + w.numel()] = w
+    seg_off = (torch.arange(n_reads + 1, device=dev, dtype=torch.int64) * read_len).to(torch.int32)
+    torch.cuda.synchronize()
+    return words, seg_off, n_reads, n_bases, genome
+
+
+def cpu_baseline(k, min_count, read_len, coverage):
+    """The oracle (CPU restatement, single thread) timed on a bounded sample of the same
+    workload: a 10x smaller isolate at the same coverage / read length / k."""
+    from oracle import Oracle
+    from sparrowhawk_amd import synth
+    genome_len = 500_000
+    g = synth.random_genome(genome_len, 0xEC02)
+    codes, quals = synth.sample_reads(g, genome_len * coverage // read_len, read_len, 0xEC02 + 1)
+    fq = synth.to_fastq(codes, quals)
+    o = Oracle(k=k, min_count=min_count, min_qual=20)
+    o.add_fastq(fq)
+    t0 = time.perf_counter()
+    o.count(naive=False)
+    o.assemble()
+    dt = time.perf_counter() - t0
+    nb = codes.size
+    return {"value": nb / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
+            "sample": f"{genome_len} bp isolate, {coverage}x, {read_len} bp reads, k={k} "
+                      f"({nb / 1e6:.0f} Mbases; 1/10 of the GPU workload's genome), oracle count+assemble "
+                      f"{dt:.1f} s; build's CPU restatement, not upstream sparrowhawk-asm"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome", type=int, default=5_000_000)
+    ap.add_argument("--coverage", type=int, default=100)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--min-count", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch                                         # before libshk_hip.so: one HIP runtime
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sparrowhawk_amd import AssemblyHelper
+
+    # every rank owns one isolate of the batch (independent objects: no data-path collective)
+    d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
+        torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
+
+    def one_step():
+        h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+        h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
+        h.assemble()
+        out = h.get_assembly()
+        t = h.timings()
+        info = (h.n_solid, h.n_distinct)
+        h.free()
+        return out, t, info
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out, _, _ = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    kern_ms, all_t = [], []
+    for _ in range(args.steps):
+        out, t, info = one_step()
+        kern_ms.append(t.get("count_kernel", 0.0))
+        all_t.append(t)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # sanity on the result of the last step: one contig that is a substring of the genome
+    res = json.loads(out)
+    ncontigs = res["ncontigs"]
+
+    total_bases = n_bases * world
+    value = total_bases * args.steps / dt / 1e9
+    W = (2 * args.k + 63) // 64
+    n_solid, n_distinct = info
+    alg_bytes = n_bases * 0.25 + n_reads * 4 + n_distinct * (8 * W + 4)
+    k_ms = sum(kern_ms) / max(1, len(kern_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    line = {
+        "metric": "Gbases/s assembled, k=31 150bp reads",
+        "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"{args.genome} bp isolate per GPU, {args.coverage}x {args.read_len} bp reads "
+                               f"({n_reads} reads, {n_bases} bases per GPU), k={args.k}, min_count={args.min_count}, "
+                               f"error-free, packed 2-bit in HBM",
+                   "parallelism": "one isolate per rank, no data-path collective" if world > 1 else "single GPU",
+                   "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
+        "roofline": {"bound": "hbm", "kernel": "k_count_segments", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms},
+        "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, args.read_len, args.coverage)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * shk.h — C ABI of libshk_hip.so: the MI355X (gfx950) implementation of the sparrowhawk-asm
+ * assembly path (k-mer count -> filter -> de Bruijn graph -> correct -> collapse -> contigs).
+ *
+ * This is the drop-in boundary: exactly what a Rust `AssemblyHelper` (the wasm-bindgen struct
+ * the reference's worker drives, /root/reference/www/src/workers/Assembler.ts:15-39) binds over
+ * FFI.  See INTEGRATION.md for the Rust-side `extern "C"` block.  Plain pointers and sizes only;
+ * no C++ or torch types cross this boundary.
+ *
+ * Threading: a handle is not thread-safe; one handle drives one HIP device (the current device
+ * at shk_new time).  Every function returns SHK_OK (0) or a negative error code and never
+ * aborts; the message is available from shk_last_error().  Strings returned by the library are
+ * owned by the handle and stay valid until the next call on it or shk_free().
+ *
+ * There is no CPU fallback: without a usable HIP device shk_new() fails with SHK_E_DEVICE.
+ */
+#ifndef SHK_H
+#define SHK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SHK_OK 0
+#define SHK_E_PARAM  (-1)  /* even k, k out of range, bad argument                         */
+#define SHK_E_STATE  (-2)  /* call out of order (Assembler.ts:92-111,121-139 call sequence) */
+#define SHK_E_PARSE  (-3)  /* malformed FASTQ / gzip                                        */
+#define SHK_E_OOM    (-4)  /* host or device memory                                         */
+#define SHK_E_DEVICE (-5)  /* no HIP device / HIP runtime error                             */
+#define SHK_E_INTERNAL (-6)
+
+#define SHK_HISTO_BINS 500 /* KmerHistogram.vue:45 */
+#define SHK_K_MIN 15
+#define SHK_K_MAX 63       /* compiled key widths: 1 and 2 64-bit words (SPEC S3 allows 127) */
+
+typedef struct shk_handle shk_handle;
+
+/* Progress hook — replaces the crate's post_state(&str) -> postMessage({assemblyState})
+ * (/root/reference/AGENTS.md:236-250; strings: AssemblyPage.vue:458-609).  Fires on the
+ * calling thread. */
+typedef void (*shk_progress_cb)(const char *state, void *user);
+
+/* AssemblyHelper::new(k, verbose, min_count, min_qual, chunk_size, do_bloom, do_fit,
+ *                     no_bubble_collapse, no_dead_end_removal)        Assembler.ts:15-29,94-99
+ * Same nine parameters, same order.  Returns NULL on failure; shk_new_error() tells why. */
+shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qual,
+                    uint64_t chunk_size, int do_bloom, int do_fit,
+                    int no_bubble_collapse, int no_dead_end_removal);
+int shk_new_error(void);                 /* error code of the last failed shk_new on this thread */
+const char *shk_new_error_message(void);
+
+void shk_free(shk_handle *h);            /* Assembler.ts:141-143 (resetAll drops the handle) */
+const char *shk_last_error(shk_handle *h);
+void shk_set_progress_cb(shk_handle *h, shk_progress_cb cb, void *user);
+
+/* AssemblyHelper::preprocess(file1, file2|null)                        Assembler.ts:35,100
+ * fq1/fq2: whole FASTQ files in memory, plain or gzip (fastx_wasm.rs:9,53-70); fq2 may be NULL.
+ * The buffers are not retained. */
+int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2);
+
+/* Streaming form of preprocess for inputs that do not fit host memory at once (modelled on the
+ * reference's chunked bridge, rust/deacon-bridge/src/lib.rs:112,158).  Each chunk must hold
+ * whole FASTQ records (plain text); shk_finish_reads() completes preprocessing. */
+int shk_push_reads(shk_handle *h, const uint8_t *fastq_chunk, size_t n);
+int shk_finish_reads(shk_handle *h);
+
+/* Device-resident form of preprocess: reads already parsed, quality-masked, cut into valid
+ * segments (SPEC S2) and 2-bit packed in HBM (layout: DESIGN.md "Data layout").
+ *   d_bases   : uint32 words, base i of the stream in bits [2*(i%16), 2*(i%16)+1] of word i/16;
+ *               at least ceil(n_bases/16)+1 words allocated
+ *   d_seg_off : uint32[n_seg+1], base offset of each segment in the stream (ascending,
+ *               d_seg_off[n_seg] == n_bases); every segment is >= k bases
+ * Both are HIP device pointers on the handle's device; they are read, not retained.
+ * n_reads is only used for progress/statistics. */
+int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off,
+                                 uint64_t n_seg, uint64_t n_bases, uint64_t n_reads);
+
+/* AssemblyHelper::get_preprocessing_info() -> String                   Assembler.ts:36,110
+ * JSON {"nkmers":int,"histo":[500 ints],"used_min_count":int}          Assembler.ts:1-5 */
+const char *shk_get_preprocessing_info(shk_handle *h);
+
+/* AssemblyHelper::assemble()                                           Assembler.ts:37,124 */
+int shk_assemble(shk_handle *h);
+
+/* AssemblyHelper::get_assembly() -> String                             Assembler.ts:38,127
+ * JSON {"outfasta":str,"ncontigs":int,"outdot":str,"outgfa":str,"outgfav2":str}  :7-13 */
+const char *shk_get_assembly(shk_handle *h);
+
+/* ---- host-side packer (the parser the preprocess entry points use), exposed so a caller can
+ * stage packed reads in HBM itself (bench.py, the multi-GPU shard layer). */
+typedef struct shk_packed {
+    uint32_t *bases;       /* ceil(n_bases/16)+1 words */
+    uint32_t *seg_off;     /* n_seg+1 */
+    uint64_t n_seg, n_bases, n_reads, n_input_bases;
+} shk_packed;
+/* returns SHK_OK or SHK_E_PARSE / SHK_E_OOM; *err (optional) receives a static message */
+int shk_pack_fastq(const uint8_t *fq, size_t n, uint32_t k, uint32_t min_qual, shk_packed *out,
+                   const char **err);
+void shk_packed_free(shk_packed *p);
+
+/* ---- stage inspection (used by the parity tests; SURVEY.md §7 step 1 stages a-f).
+ * All copy device state to caller-provided host arrays.  Key layout: W = ceil(2k/64) uint64
+ * words per k-mer, w[0] least significant (SPEC S3).  Order of rows is unspecified. */
+uint32_t shk_key_words(shk_handle *h);
+uint64_t shk_total_instances(shk_handle *h);            /* valid k-mer windows counted (S4)   */
+uint64_t shk_n_distinct(shk_handle *h);
+int shk_get_distinct(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap);
+uint64_t shk_n_solid(shk_handle *h);
+int shk_get_solid(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap);
+int shk_get_histo(shk_handle *h, uint64_t *histo500);
+uint32_t shk_used_min_count(shk_handle *h);
+/* after shk_assemble: per solid node (same row order as shk_get_solid) */
+int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
+                      uint64_t cap);
+/* timing of the last preprocess/assemble, milliseconds, by stage name; returns a JSON object */
+const char *shk_get_timings(shk_handle *h);
+
+/* ---- host-only self tests of the device/host shared k-mer arithmetic (no GPU needed) */
+int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words /*W*/, int *orient);
+uint64_t shk_host_nthash(const char *seq, uint32_t k);   /* canonical ntHash of seq[0..k) */
+int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0 fit failed */
+
+const char *shk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHK_H */

@@ -1,0 +1,309 @@
+// api.cpp — the C ABI of libshk_hip.so (include/shk.h): the stateful AssemblyHelper the
+// reference's worker drives (www/src/workers/Assembler.ts:15-39,73-143), its call-order state
+// machine, the progress strings (AssemblyPage.vue:458-609) and the JSON getters.
+#include "../../include/shk.h"
+
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "fastq.h"
+#include "outputs.h"
+#include "pipeline.h"
+
+namespace shk {
+bool spectrum_fit(const uint64_t *histo500, uint32_t *out);
+}
+
+using namespace shk;
+
+namespace {
+
+thread_local int g_new_err = 0;
+thread_local std::string g_new_msg;
+
+enum class St { Fresh, Streaming, Preprocessed, Assembled };
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct shk_handle {
+    uint32_t k = 31, min_count = 5, min_qual = 20;
+    uint64_t chunk_size = 0;
+    bool verbose = false, do_bloom = false, do_fit = false, no_bubble = false, no_deadend = false;
+    St st = St::Fresh;
+    IPipeline *pipe = nullptr;
+    shk_progress_cb cb = nullptr;
+    void *cb_user = nullptr;
+    std::string err, pre_json, asm_json, timings_json;
+    uint64_t histo[SHK_HISTO_BINS] = {0};
+    uint32_t used_min_count = 0;
+    bool fit_ok = false;
+    PackedReads stream_reads;          // shk_push_reads accumulator
+    uint64_t n_reads = 0;
+    AssemblyText text;
+
+    const char *mode() const { return do_bloom ? "bloom" : (chunk_size > 0 ? "chunked" : "bulk"); }
+    void post(const std::string &s) { if (cb) cb(s.c_str(), cb_user); }
+    void post_mode(const char *suffix) { post(std::string("preprocess:") + mode() + ":" + suffix); }
+    uint64_t progress_every() const { return (!do_bloom && chunk_size > 0) ? chunk_size : 100000; }
+};
+
+static int fail(shk_handle *h, int code, const std::string &msg) { h->err = msg; return code; }
+
+extern "C" {
+
+const char *shk_version(void) { return "sparrowhawk_amd 0.1 (gfx950)"; }
+int shk_new_error(void) { return g_new_err; }
+const char *shk_new_error_message(void) { return g_new_msg.c_str(); }
+
+shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qual, uint64_t chunk_size,
+                    int do_bloom, int do_fit, int no_bubble_collapse, int no_dead_end_removal) {
+    g_new_err = 0; g_new_msg.clear();
+    if ((k & 1u) == 0 || k < SHK_K_MIN || k > SHK_K_MAX) {
+        g_new_err = SHK_E_PARAM; g_new_msg = "k must be odd and within [15, 63]"; return nullptr;
+    }
+    if (min_qual > 93) { g_new_err = SHK_E_PARAM; g_new_msg = "min_qual out of range"; return nullptr; }
+    if (min_count >= SHK_HISTO_BINS) { g_new_err = SHK_E_PARAM; g_new_msg = "min_count out of range"; return nullptr; }
+    if (do_bloom && min_count < 3) {     // AssemblyPage.vue:430-432,628-632
+        g_new_err = SHK_E_PARAM; g_new_msg = "Bloom mode requires min_count >= 3"; return nullptr;
+    }
+    shk_handle *h = new (std::nothrow) shk_handle();
+    if (!h) { g_new_err = SHK_E_OOM; g_new_msg = "out of host memory"; return nullptr; }
+    h->k = k; h->verbose = verbose != 0; h->min_count = min_count; h->min_qual = min_qual;
+    h->chunk_size = chunk_size; h->do_bloom = do_bloom != 0; h->do_fit = do_fit != 0;
+    h->no_bubble = no_bubble_collapse != 0; h->no_deadend = no_dead_end_removal != 0;
+    std::string err;
+    h->pipe = make_pipeline((int)k, err);
+    if (!h->pipe) { g_new_err = SHK_E_DEVICE; g_new_msg = err; delete h; return nullptr; }
+    return h;
+}
+
+void shk_free(shk_handle *h) {
+    if (!h) return;
+    delete h->pipe;
+    delete h;
+}
+
+const char *shk_last_error(shk_handle *h) { return h ? h->err.c_str() : "null handle"; }
+void shk_set_progress_cb(shk_handle *h, shk_progress_cb cb, void *user) { if (h) { h->cb = cb; h->cb_user = user; } }
+
+// common tail of every preprocess entry point: packed segments are in HBM
+static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                        uint64_t n_bases) {
+    std::string err;
+    const double t0 = now_ms();
+    int rc = h->pipe->count_batch(d_bases, d_seg_off, n_seg, n_bases, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    h->post_mode("loop:end");
+    if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
+    rc = h->pipe->histogram(h->histo, err);
+    if (rc) return fail(h, SHK_E_DEVICE, err);
+    h->used_min_count = h->min_count; h->fit_ok = false;
+    if (h->do_fit) {
+        h->post_mode("fitting");
+        uint32_t v = 0;
+        if (spectrum_fit(h->histo, &v)) { h->used_min_count = v; h->fit_ok = true; }
+    }
+    h->post_mode("filtering");
+    rc = h->pipe->filter(h->used_min_count, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+    h->post("preprocess:saving");
+    h->pre_json = preprocessing_json(h->pipe->n_solid(), h->histo, h->used_min_count);
+    h->pipe->times().add("preprocess_device_total_host_clock", now_ms() - t0);
+    h->st = St::Preprocessed;
+    h->post("preprocess:end");
+    return SHK_OK;
+}
+
+static int count_packed_host(shk_handle *h, PackedReads &pr) {
+    pr.finish();
+    std::string err;
+    void *d_bases = nullptr, *d_off = nullptr;
+    const double t0 = now_ms();
+    int rc = device_upload(pr.bases.data(), pr.bases.size() * 4, &d_bases, err);
+    if (!rc) rc = device_upload(pr.seg_off.data(), pr.seg_off.size() * 4, &d_off, err);
+    if (rc) { device_free(d_bases); device_free(d_off); return fail(h, SHK_E_OOM, err); }
+    h->pipe->times().add("h2d_upload_host_clock", now_ms() - t0);
+    rc = run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_off, pr.n_seg(), pr.n_bases);
+    device_free(d_bases); device_free(d_off);
+    return rc;
+}
+
+int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used (Assembler.ts:92: one preprocess per handle)");
+    if (!fq1) return fail(h, SHK_E_PARAM, "preprocess: file1 is required");
+    h->post("preprocess:start");
+    h->post_mode("start");
+    h->post_mode("loop:start");
+    PackedReads pr;
+    std::string err;
+    const double t0 = now_ms();
+    const size_t total = n1 + (fq2 ? n2 : 0);
+    size_t done_before = 0;
+    auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
+        const uint64_t pct = total ? (100 * (done_before + bytes)) / total : 100;
+        h->post_mode(("loop:" + std::to_string(reads) + ":" + std::to_string(pct)).c_str());
+    };
+    int rc = pack_fastq(fq1, n1, h->k, h->min_qual, pr, err, h->progress_every(), prog);
+    if (!rc && fq2) { done_before = n1; rc = pack_fastq(fq2, n2, h->k, h->min_qual, pr, err, h->progress_every(), prog); }
+    if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
+    h->n_reads = pr.n_reads;
+    h->pipe->times().add("fastq_parse_pack_host_clock", now_ms() - t0);
+    return count_packed_host(h, pr);
+}
+
+int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Fresh && h->st != St::Streaming) return fail(h, SHK_E_STATE, "push_reads: handle already preprocessed");
+    if (h->st == St::Fresh) {
+        h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+        h->st = St::Streaming;
+    }
+    std::string err;
+    auto prog = [&](uint64_t reads, uint64_t, uint64_t) { h->post_mode(("loop:" + std::to_string(reads)).c_str()); };
+    int rc = pack_fastq(chunk, n, h->k, h->min_qual, h->stream_reads, err, h->progress_every(), prog);
+    if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
+    return SHK_OK;
+}
+
+int shk_finish_reads(shk_handle *h) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Streaming) return fail(h, SHK_E_STATE, "finish_reads: no reads pushed");
+    h->n_reads = h->stream_reads.n_reads;
+    int rc = count_packed_host(h, h->stream_reads);
+    h->stream_reads.clear();
+    return rc;
+}
+
+int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                                 uint64_t n_bases, uint64_t n_reads) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used");
+    if (!d_bases || !d_seg_off) return fail(h, SHK_E_PARAM, "null device pointer");
+    h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+    h->n_reads = n_reads;
+    h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
+    return run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_seg_off, n_seg, n_bases);
+}
+
+const char *shk_get_preprocessing_info(shk_handle *h) {
+    if (!h) return nullptr;
+    if (h->st != St::Preprocessed && h->st != St::Assembled) { h->err = "get_preprocessing_info before preprocess"; return nullptr; }
+    return h->pre_json.c_str();
+}
+
+int shk_assemble(shk_handle *h) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Preprocessed) return fail(h, SHK_E_STATE, "assemble: preprocess first (and only once)");
+    std::string err;
+    const double t0 = now_ms();
+    h->post("assembly:start");
+    h->post("assembly:create_graph");
+    int rc = h->pipe->build_graph(err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+    h->post("assembly:correct_graph");
+    rc = h->pipe->correct(!h->no_deadend, !h->no_bubble, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+    h->post("assembly:collapse_graph");
+    std::vector<RawContig> contigs;
+    rc = h->pipe->collapse(contigs, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+    h->pipe->times().add("assemble_device_total_host_clock", now_ms() - t0);
+    h->post("assembly:saving");
+    const double t1 = now_ms();
+    build_assembly_text(contigs, h->k, h->text);
+    h->asm_json.swap(h->text.json);
+    h->pipe->times().add("outputs_host_clock", now_ms() - t1);
+    h->st = St::Assembled;
+    h->post("assembly:end");
+    return SHK_OK;
+}
+
+const char *shk_get_assembly(shk_handle *h) {
+    if (!h) return nullptr;
+    if (h->st != St::Assembled) { h->err = "get_assembly before assemble"; return nullptr; }
+    return h->asm_json.c_str();
+}
+
+// ---- packer ------------------------------------------------------------------------------
+int shk_pack_fastq(const uint8_t *fq, size_t n, uint32_t k, uint32_t min_qual, shk_packed *out, const char **errp) {
+    static thread_local std::string msg;
+    if (!out) return SHK_E_PARAM;
+    PackedReads pr;
+    int rc = pack_fastq(fq, n, k, min_qual, pr, msg);
+    if (rc) { if (errp) *errp = msg.c_str(); return rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM); }
+    pr.finish();
+    out->n_seg = pr.n_seg(); out->n_bases = pr.n_bases; out->n_reads = pr.n_reads; out->n_input_bases = pr.n_input_bases;
+    out->bases = (uint32_t *)malloc(pr.bases.size() * 4);
+    out->seg_off = (uint32_t *)malloc(pr.seg_off.size() * 4);
+    if (!out->bases || !out->seg_off) { free(out->bases); free(out->seg_off); return SHK_E_OOM; }
+    memcpy(out->bases, pr.bases.data(), pr.bases.size() * 4);
+    memcpy(out->seg_off, pr.seg_off.data(), pr.seg_off.size() * 4);
+    return SHK_OK;
+}
+void shk_packed_free(shk_packed *p) { if (p) { free(p->bases); free(p->seg_off); p->bases = nullptr; p->seg_off = nullptr; } }
+
+// ---- stage inspection -----------------------------------------------------------------------
+uint32_t shk_key_words(shk_handle *h) { return h ? (2 * h->k + 63) / 64 : 0; }
+uint64_t shk_total_instances(shk_handle *h) { return h && h->pipe ? h->pipe->total_instances() : 0; }
+uint64_t shk_n_distinct(shk_handle *h) { return h && h->pipe ? h->pipe->n_distinct() : 0; }
+uint64_t shk_n_solid(shk_handle *h) { return h && h->pipe ? h->pipe->n_solid() : 0; }
+uint32_t shk_used_min_count(shk_handle *h) { return h ? h->used_min_count : 0; }
+
+int shk_get_distinct(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Preprocessed) return fail(h, SHK_E_STATE, "get_distinct: only between preprocess and assemble");
+    std::string err; int rc = h->pipe->get_distinct(keys, counts, cap, err);
+    return rc ? fail(h, rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE, err) : SHK_OK;
+}
+int shk_get_solid(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Preprocessed && h->st != St::Assembled) return fail(h, SHK_E_STATE, "get_solid before preprocess");
+    std::string err; int rc = h->pipe->get_solid(keys, counts, cap, err);
+    return rc ? fail(h, rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE, err) : SHK_OK;
+}
+int shk_get_histo(shk_handle *h, uint64_t *histo500) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Preprocessed && h->st != St::Assembled) return fail(h, SHK_E_STATE, "get_histo before preprocess");
+    memcpy(histo500, h->histo, sizeof h->histo);
+    return SHK_OK;
+}
+int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive, uint64_t cap) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Assembled) return fail(h, SHK_E_STATE, "get_adjacency before assemble");
+    std::string err; int rc = h->pipe->get_adjacency(adj_initial, adj_final, alive, cap, err);
+    return rc ? fail(h, rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE, err) : SHK_OK;
+}
+const char *shk_get_timings(shk_handle *h) {
+    if (!h || !h->pipe) return "{}";
+    std::string j = "{";
+    bool first = true;
+    for (auto &kv : h->pipe->times().ms) {
+        if (!first) j += ",";
+        first = false;
+        char buf[64]; snprintf(buf, sizeof buf, "%.6f", kv.second);
+        j += "\"" + kv.first + "\":" + buf;
+    }
+    j += "}";
+    h->timings_json.swap(j);
+    return h->timings_json.c_str();
+}
+
+// ---- host-only self tests --------------------------------------------------------------------
+int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *orient) {
+    if (!seq || !out_words || (k & 1u) == 0 || k > 127) return SHK_E_PARAM;
+    return host_canonical(seq, k, out_words, orient) == 0 ? SHK_OK : SHK_E_PARAM;
+}
+uint64_t shk_host_nthash(const char *seq, uint32_t k) { return host_nthash(seq, k); }
+int shk_host_fit(const uint64_t *histo500, uint32_t *used) { return spectrum_fit(histo500, used) ? 1 : 0; }
+
+}  // extern "C"

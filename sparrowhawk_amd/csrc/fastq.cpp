@@ -1,0 +1,126 @@
+// fastq.cpp — see fastq.h
+#include "fastq.h"
+
+#include <string.h>
+#include <zlib.h>
+
+namespace shk {
+
+void PackedReads::clear() {
+    bases.clear(); seg_off.clear(); n_bases = n_reads = n_input_bases = 0; cur = 0;
+}
+
+void PackedReads::finish() {
+    if (seg_off.empty()) seg_off.push_back(0);
+    // materialise the partial word and one spare word so kernels may read one word past the end
+    std::vector<uint32_t> &b = bases;
+    const size_t full = (size_t)(n_bases >> 4);
+    b.resize(full);
+    b.push_back((n_bases & 15) ? cur : 0u);
+    b.push_back(0u);
+}
+
+static int inflate_all(const uint8_t *in, size_t n, std::vector<uint8_t> &out, std::string &err) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "zlib init failed"; return -3; }
+    out.resize(n * 4 + 4096);
+    size_t produced = 0, consumed = 0;
+    for (;;) {
+        if (produced == out.size()) out.resize(out.size() * 2);
+        size_t in_chunk = n - consumed; if (in_chunk > (1u << 30)) in_chunk = 1u << 30;
+        size_t out_chunk = out.size() - produced; if (out_chunk > (1u << 30)) out_chunk = 1u << 30;
+        zs.next_in = (Bytef *)(in + consumed); zs.avail_in = (uInt)in_chunk;
+        zs.next_out = out.data() + produced; zs.avail_out = (uInt)out_chunk;
+        int rc = inflate(&zs, Z_NO_FLUSH);
+        consumed += in_chunk - zs.avail_in;
+        produced += out_chunk - zs.avail_out;
+        if (rc == Z_STREAM_END) {
+            if (consumed >= n) break;
+            if (inflateReset(&zs) != Z_OK) { inflateEnd(&zs); err = "zlib reset failed"; return -3; }   // next member
+            continue;
+        }
+        if (rc != Z_OK && rc != Z_BUF_ERROR) { inflateEnd(&zs); err = "gzip stream corrupt"; return -3; }
+        if (consumed >= n && zs.avail_out != 0) { inflateEnd(&zs); err = "gzip stream truncated"; return -3; }
+    }
+    inflateEnd(&zs);
+    out.resize(produced);
+    return 0;
+}
+
+namespace {
+struct Lut {
+    uint8_t code[256];
+    Lut() {
+        memset(code, 4, sizeof code);
+        code[(int)'A'] = code[(int)'a'] = 0; code[(int)'C'] = code[(int)'c'] = 1;
+        code[(int)'G'] = code[(int)'g'] = 2; code[(int)'T'] = code[(int)'t'] = 3;
+    }
+};
+const Lut LUT;
+
+inline void append_run(PackedReads &o, const uint8_t *codes, size_t len) {
+    uint64_t nb = o.n_bases; uint32_t cur = o.cur;
+    for (size_t i = 0; i < len; i++) {
+        const uint32_t sh = 2u * (uint32_t)(nb & 15);
+        cur |= (uint32_t)codes[i] << sh;
+        nb++;
+        if ((nb & 15) == 0) { o.bases.push_back(cur); cur = 0; }
+    }
+    o.n_bases = nb; o.cur = cur;
+    o.seg_off.push_back((uint32_t)nb);
+}
+}  // namespace
+
+int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
+               std::string &err, uint64_t every, const ProgressFn &progress) {
+    std::vector<uint8_t> inflated;
+    if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
+        if (int rc = inflate_all(buf, n, inflated, err)) return rc;
+        buf = inflated.data(); n = inflated.size();
+    }
+    if (out.seg_off.empty()) out.seg_off.push_back(0);
+    std::vector<uint8_t> run;
+    size_t p = 0; uint64_t rec = 0;
+    const int minq = (int)min_qual;
+    while (p < n) {
+        if (buf[p] == '\n') { p++; continue; }
+        if (buf[p] == '\r' && p + 1 < n && buf[p + 1] == '\n') { p += 2; continue; }
+        const uint8_t *line[4]; size_t ll[4];
+        for (int i = 0; i < 4; i++) {
+            if (p >= n) { err = "truncated FASTQ record " + std::to_string(rec); return -3; }
+            const uint8_t *nl = (const uint8_t *)memchr(buf + p, '\n', n - p);
+            if (!nl && i < 3) { err = "truncated FASTQ record " + std::to_string(rec); return -3; }
+            size_t e = nl ? (size_t)(nl - buf) : n;
+            line[i] = buf + p; ll[i] = e - p;
+            if (ll[i] > 0 && line[i][ll[i] - 1] == '\r') ll[i]--;
+            p = e + 1;
+        }
+        if (ll[0] == 0 || line[0][0] != '@' || ll[2] == 0 || line[2][0] != '+' || ll[1] != ll[3]) {
+            err = "malformed FASTQ record " + std::to_string(rec); return -3;
+        }
+        // SPEC S2: maximal runs of valid bases; runs shorter than k are dropped
+        const uint8_t *s = line[1], *q = line[3];
+        const size_t L = ll[1];
+        run.clear();
+        for (size_t i = 0; i <= L; i++) {
+            uint8_t c = 4;
+            if (i < L) {
+                c = LUT.code[s[i]];
+                if (c < 4 && (int)q[i] - 33 < minq) c = 4;
+            }
+            if (c < 4) { run.push_back(c); continue; }
+            if (run.size() >= k) {
+                if (out.n_bases + run.size() >= 0xFFFFFFF0ull) { err = "input exceeds 2^32 bases per batch"; return -1; }
+                append_run(out, run.data(), run.size());
+            }
+            run.clear();
+        }
+        out.n_input_bases += L;
+        out.n_reads++; rec++;
+        if (every && progress && (out.n_reads % every) == 0) progress(out.n_reads, p > n ? n : p, n);
+    }
+    return 0;
+}
+
+}  // namespace shk

@@ -1,0 +1,32 @@
+// fastq.h — host FASTQ/gzip ingestion, quality masking, segmenting and 2-bit packing (SPEC S1-S2).
+// Replaces the reader the reference's crate builds over web_sys::File + gz sniff + seq_io
+// (/root/reference/AGENTS.md:180-183; sibling in tree: rust/orphos-bridge/src/fastx_wasm.rs:53-70).
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace shk {
+
+struct PackedReads {
+    std::vector<uint32_t> bases;     // 2-bit stream, base i in bits [2*(i%16)+1 : 2*(i%16)] of word i/16
+    std::vector<uint32_t> seg_off;   // n_seg+1 base offsets
+    uint64_t n_bases = 0;            // bases in the packed stream (valid segments >= k only)
+    uint64_t n_reads = 0;            // FASTQ records seen
+    uint64_t n_input_bases = 0;      // bases in the FASTQ records
+    uint32_t cur = 0;                // partial word being filled
+    void clear();
+    void finish();                   // flush the partial word, pad one spare word
+    uint64_t n_seg() const { return seg_off.empty() ? 0 : seg_off.size() - 1; }
+};
+
+// progress(reads_so_far, bytes_consumed, bytes_total) is called every `every` reads (0 = never)
+using ProgressFn = std::function<void(uint64_t, uint64_t, uint64_t)>;
+
+// Appends the reads of one FASTQ buffer (plain or gzip) to `out`.  0 or SHK_E_PARSE(-3)/-4.
+int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
+               std::string &err, uint64_t every = 0, const ProgressFn &progress = nullptr);
+
+}  // namespace shk

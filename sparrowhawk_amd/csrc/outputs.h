@@ -1,0 +1,22 @@
+// outputs.h — contig canonicalisation, ordering, links and the FASTA / GFA1 / GFA2 / DOT / JSON
+// writers (SPEC S10-S11).  Replaces the crate's `assembly:saving` phase and get_assembly()
+// (AssemblyPage.vue:604-605; www/src/workers/Assembler.ts:7-13,127-137;
+// www/src/components/DownloadButton.vue:46-57).
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "pipeline.h"
+
+namespace shk {
+
+struct AssemblyText {
+    uint64_t ncontigs = 0;
+    std::string fasta, dot, gfa1, gfa2, json;
+};
+
+void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out);
+std::string preprocessing_json(uint64_t nkmers, const uint64_t *histo500, uint32_t used_min_count);
+void json_escape_into(std::string &dst, const std::string &s);
+
+}  // namespace shk

@@ -1,0 +1,58 @@
+// pipeline.h — host-visible interface of the device pipeline (implemented in pipeline.hip).
+// One object per handle; templated on the key width W inside, type-erased here.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <map>
+
+namespace shk {
+
+struct RawContig {            // one unitig as spelled by the device, arbitrary strand
+    std::string seq;
+    uint64_t kc;              // sum of k-mer counts over its nodes
+};
+
+struct StageTimes {           // milliseconds (HIP events on the pipeline's stream / host clock)
+    std::map<std::string, double> ms;
+    void add(const std::string &k, double v) { ms[k] += v; }
+};
+
+class IPipeline {
+public:
+    virtual ~IPipeline() {}
+    // counting (SPEC S4): may be called once per batch of packed segments
+    virtual int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                            uint64_t n_bases, std::string &err) = 0;
+    // histogram over the count table (SPEC S5)
+    virtual int histogram(uint64_t histo[500], std::string &err) = 0;
+    // keep k-mers with count > threshold (SPEC S7); returns number kept via n_solid()
+    virtual int filter(uint32_t threshold, std::string &err) = 0;
+    virtual uint64_t total_instances() const = 0;
+    virtual uint64_t n_distinct() const = 0;
+    virtual uint64_t n_solid() const = 0;
+    virtual int get_distinct(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) = 0;
+    virtual int get_solid(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) = 0;
+    // assembly (SPEC S8-S10)
+    virtual int build_graph(std::string &err) = 0;
+    virtual int correct(bool tips, bool bubbles, std::string &err) = 0;
+    virtual int collapse(std::vector<RawContig> &out, std::string &err) = 0;
+    virtual int get_adjacency(uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
+                              uint64_t cap, std::string &err) = 0;
+    virtual StageTimes &times() = 0;
+    virtual void *stream() = 0;
+};
+
+// returns nullptr (and err) if no device / bad k
+IPipeline *make_pipeline(int k, std::string &err);
+int device_count();
+
+// host-side helpers implemented with the same kmer.h arithmetic as the kernels
+int host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *orient);
+uint64_t host_nthash(const char *seq, uint32_t k);
+
+// upload helper used by the host-buffer entry points
+int device_upload(const void *host, size_t bytes, void **dptr, std::string &err);
+void device_free(void *dptr);
+
+}  // namespace shk

@@ -1,0 +1,1247 @@
+// pipeline.hip — HIP kernels (gfx950, wave64) and the device pipeline of the assembly path.
+//
+// Reference rows replaced (the Rust lives in rust/sparrowhawk-asm, NOT IN TREE,
+// so citations are to the observable phases in www/src/components/pages/AssemblyPage.vue):
+//   a4/a5  preprocess:*:loop      -> k_count_segments   (extract + canonicalise + ntHash + insert)
+//   a6     histo                  -> k_histogram
+//   a8     preprocess:*:filtering -> k_compact          (ballot / prefix-sum stream compaction)
+//   a10    assembly:create_graph  -> k_gt_insert, k_adjacency
+//   a11    assembly:correct_graph -> k_tip_*, k_bubble_*, k_apply_removed
+//   a12    assembly:collapse_graph-> k_succ, k_mark_splitters, k_walk_segments, k_emit
+// Integer/hash work only: no MFMA anywhere on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "kmer.h"
+#include "pipeline.h"
+
+namespace shk {
+
+#define HIPCHK(call)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (call);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            err = std::string(#call) + ": " + hipGetErrorString(_e);                      \
+            return -5;                                                                    \
+        }                                                                                 \
+    } while (0)
+
+static constexpr uint32_t NIL = 0xFFFFFFFFu;
+static constexpr uint64_t EMPTY64 = ~0ull;
+static constexpr int MAX_PROBE = 4096;
+static constexpr int SPLIT_LOG = 6;            // one splitter every ~64 oriented nodes
+
+// ------------------------------------------------------------------------------------------
+// device-side views
+// ------------------------------------------------------------------------------------------
+template <int W> struct KeyArr {               // SoA key storage
+    uint64_t *w[W];
+    __device__ __forceinline__ Kmer<W> load(uint64_t i) const {
+        Kmer<W> x;
+#pragma unroll
+        for (int j = 0; j < W; j++) x.w[j] = w[j][i];
+        return x;
+    }
+    __device__ __forceinline__ void store(uint64_t i, const Kmer<W> &x) const {
+#pragma unroll
+        for (int j = 0; j < W; j++) w[j][i] = x.w[j];
+    }
+};
+
+template <int W> struct CountTable {           // open addressing, linear probing
+    KeyArr<W> keys;
+    uint32_t *cnt;
+    uint32_t *state;                           // W >= 2 only: 0 empty, 1 being written, 2 ready
+    uint64_t mask;
+};
+
+struct GraphTable {                            // entry = fingerprint<<32 | node index
+    uint64_t *e;
+    uint64_t mask;
+};
+
+// ------------------------------------------------------------------------------------------
+// count table insert (global memory; every concurrent access is an agent-scope atomic)
+// ------------------------------------------------------------------------------------------
+template <int W>
+__device__ __forceinline__ bool ct_insert(const CountTable<W> &t, const Kmer<W> &key, uint64_t h) {
+    uint64_t slot = h & t.mask;
+    if constexpr (W == 1) {
+        for (int p = 0; p < MAX_PROBE; p++) {
+            unsigned long long old = atomicCAS((unsigned long long *)&t.keys.w[0][slot],
+                                               (unsigned long long)EMPTY64,
+                                               (unsigned long long)key.w[0]);
+            if (old == EMPTY64 || old == key.w[0]) {
+                atomicAdd(&t.cnt[slot], 1u);
+                return true;
+            }
+            slot = (slot + 1) & t.mask;
+        }
+        return false;
+    } else {
+        int probes = 0;
+        for (;;) {
+            uint32_t st = __hip_atomic_load(&t.state[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool won = false;
+            if (st == 0) {
+                st = atomicCAS(&t.state[slot], 0u, 1u);
+                won = (st == 0);
+            }
+            if (won) {
+#pragma unroll
+                for (int j = 0; j < W; j++)
+                    __hip_atomic_store(&t.keys.w[j][slot], key.w[j], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(&t.state[slot], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&t.cnt[slot], 1u);
+                return true;
+            }
+            if (st == 1) continue;             // owner is mid-write: poll the same slot again
+            bool eq = true;
+#pragma unroll
+            for (int j = 0; j < W; j++) {
+                uint64_t v = __hip_atomic_load(&t.keys.w[j][slot], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                eq = eq && (v == key.w[j]);
+            }
+            if (eq) {
+                atomicAdd(&t.cnt[slot], 1u);
+                return true;
+            }
+            slot = (slot + 1) & t.mask;
+            if (++probes > MAX_PROBE) return false;
+        }
+    }
+}
+
+template <int W> __device__ __forceinline__ bool ct_occupied(const CountTable<W> &t, uint64_t slot) {
+    if constexpr (W == 1) return t.keys.w[0][slot] != EMPTY64;
+    else return t.state[slot] == 2u;
+}
+
+// ------------------------------------------------------------------------------------------
+// a4/a5: one lane per segment; both strands and the ntHash pair roll base by base
+// ------------------------------------------------------------------------------------------
+// 4-way select kept as compare/select on scalars (an indexable array would go to scratch)
+__device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3) {
+    uint64_t lo = (b & 1) ? t1 : t0;
+    uint64_t hi = (b & 1) ? t3 : t2;
+    return (b & 2) ? hi : lo;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_count_segments(const uint32_t *__restrict__ bases,
+                                                        const uint32_t *__restrict__ seg_off,
+                                                        uint32_t n_seg, int k, CountTable<W> tab,
+                                                        uint32_t *__restrict__ overflow,
+                                                        unsigned long long *__restrict__ n_inst) {
+    // pre-rotated ntHash seed tables (wave-uniform)
+    const uint64_t so0 = rol64(SHK_NT_A, (unsigned)k), so1 = rol64(SHK_NT_C, (unsigned)k),
+                   so2 = rol64(SHK_NT_G, (unsigned)k), so3 = rol64(SHK_NT_T, (unsigned)k);
+    const uint64_t ro0 = ror64(SHK_NT_T, 1), ro1 = ror64(SHK_NT_G, 1), ro2 = ror64(SHK_NT_C, 1),
+                   ro3 = ror64(SHK_NT_A, 1);
+    const uint64_t ri0 = rol64(SHK_NT_T, (unsigned)(k - 1)), ri1 = rol64(SHK_NT_G, (unsigned)(k - 1)),
+                   ri2 = rol64(SHK_NT_C, (unsigned)(k - 1)), ri3 = rol64(SHK_NT_A, (unsigned)(k - 1));
+    unsigned long long mine = 0;
+    for (uint32_t seg = blockIdx.x * blockDim.x + threadIdx.x; seg < n_seg;
+         seg += gridDim.x * blockDim.x) {
+        const uint32_t start = seg_off[seg], end = seg_off[seg + 1];
+        Kmer<W> f = km_zero<W>(), r = km_zero<W>();
+        NtState nt{0, 0};
+        uint32_t word = bases[start >> 4];
+        for (uint32_t pos = start; pos < end; pos++) {
+            if ((pos & 15u) == 0) word = bases[pos >> 4];
+            const uint32_t b = (word >> (2 * (pos & 15u))) & 3u;
+            const uint32_t i = pos - start;
+            if (i >= (uint32_t)k) {
+                const uint32_t out = km_first_base<W>(f, k);
+                nt.fh = rol64(nt.fh, 1) ^ sel4(out, so0, so1, so2, so3) ^ nt_seed(b);
+                nt.rh = ror64(nt.rh, 1) ^ sel4(out, ro0, ro1, ro2, ro3) ^ sel4(b, ri0, ri1, ri2, ri3);
+            } else {
+                nt_init_step(nt, b, i);
+            }
+            km_push_back<W>(f, b, k);
+            km_push_front<W>(r, 3 - b, k);
+            if (i + 1 >= (uint32_t)k) {
+                const bool use_r = km_less<W>(r, f);
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = use_r ? r.w[j] : f.w[j];
+                if (!ct_insert<W>(tab, c, nt_canonical(nt))) *overflow = 1;
+                mine++;
+            }
+        }
+    }
+    // one atomic per wave
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_inst, mine);
+}
+
+// ------------------------------------------------------------------------------------------
+// a6: spectrum histogram (SPEC S5): LDS bins, one global add per bin per block
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_histogram(CountTable<W> tab, uint64_t n_slots,
+                                                   unsigned long long *__restrict__ histo) {
+    __shared__ uint32_t h[500];
+    for (int i = threadIdx.x; i < 500; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_slots;
+         s += (uint64_t)gridDim.x * blockDim.x) {
+        if (ct_occupied<W>(tab, s)) {
+            uint32_t c = tab.cnt[s];
+            atomicAdd(&h[c >= 500 ? 499 : c - 1], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 500; i += blockDim.x)
+        if (h[i]) atomicAdd(&histo[i], (unsigned long long)h[i]);
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: filter + compaction: wave ballot, lane prefix by popcount, one cursor add per wave
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_compact(CountTable<W> tab, uint64_t n_slots,
+                                                 uint32_t threshold, KeyArr<W> out_keys,
+                                                 uint32_t *__restrict__ out_cnt,
+                                                 unsigned long long *__restrict__ cursor) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (n_slots + stride - 1) / stride * stride;
+    for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_round; s += stride) {
+        bool p = false;
+        uint32_t c = 0;
+        if (s < n_slots && ct_occupied<W>(tab, s)) {
+            c = tab.cnt[s];
+            p = c > threshold;
+        }
+        const unsigned long long m = __ballot(p);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0);
+        if (p) {
+            const uint64_t o = base + __popcll(m & ((1ull << lane) - 1ull));
+            out_keys.store(o, tab.keys.load(s));
+            out_cnt[o] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a10: graph table over the solid set (keys are distinct: claim the first empty slot)
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_gt_insert(KeyArr<W> keys, uint32_t n, GraphTable gt,
+                                                   uint32_t *__restrict__ overflow) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Kmer<W> x = keys.load(i);
+        const uint64_t h = km_hash<W>(x);
+        const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
+        uint64_t slot = h & gt.mask;
+        bool done = false;
+        for (int p = 0; p < MAX_PROBE; p++) {
+            unsigned long long old = atomicCAS((unsigned long long *)&gt.e[slot],
+                                               (unsigned long long)EMPTY64, (unsigned long long)entry);
+            if (old == EMPTY64) { done = true; break; }
+            slot = (slot + 1) & gt.mask;
+        }
+        if (!done) *overflow = 1;
+    }
+}
+
+template <int W>
+__device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr<W> &keys,
+                                              const Kmer<W> &q) {
+    const uint64_t h = km_hash<W>(q);
+    const uint32_t fp = (uint32_t)(h >> 32);
+    uint64_t slot = h & gt.mask;
+    for (int p = 0; p < MAX_PROBE; p++) {
+        const uint64_t e = gt.e[slot];
+        if (e == EMPTY64) return NIL;
+        if ((uint32_t)(e >> 32) == fp) {
+            const uint32_t idx = (uint32_t)e;
+            if (km_eq<W>(keys.load(idx), q)) return idx;
+        }
+        slot = (slot + 1) & gt.mask;
+    }
+    return NIL;
+}
+
+// adjacency byte (SPEC S8): bit b = successor by appended base b; bit 4+b = predecessor by
+// prepended base b, both relative to the canonical orientation.
+template <int W>
+__global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
+                                                   uint8_t *__restrict__ adj) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const Kmer<W> x = keys.load(i);
+        uint32_t a = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            Kmer<W> s = x; km_push_back<W>(s, b, k);
+            int o; Kmer<W> c = km_canonical<W>(s, k, o);
+            if (gt_lookup<W>(gt, keys, c) != NIL) a |= 1u << b;
+            Kmer<W> p = x; km_push_front<W>(p, b, k);
+            c = km_canonical<W>(p, k, o);
+            if (gt_lookup<W>(gt, keys, c) != NIL) a |= 1u << (4 + b);
+        }
+        adj[i] = (uint8_t)a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// oriented-node view of the graph.  v = idx*2 + o.  Adjacency bits are kept alive-aware, so a
+// set bit always leads to an alive node and following an edge is one table lookup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t rev4(uint32_t n) {
+    return ((n & 1) << 3) | ((n & 2) << 1) | ((n & 4) >> 1) | ((n & 8) >> 3);
+}
+__device__ __forceinline__ uint32_t outmask_of(uint32_t adjbyte, uint32_t o) {
+    return o ? rev4(adjbyte >> 4) : (adjbyte & 15u);
+}
+
+template <int W> struct Graph {
+    KeyArr<W> keys;
+    const uint32_t *cnt;
+    uint8_t *adj;
+    GraphTable gt;
+    int k;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t outmask(uint32_t v) const { return outmask_of(adj[v >> 1], v & 1); }
+    __device__ __forceinline__ uint32_t outdeg(uint32_t v) const { return __popc(outmask(v)); }
+    __device__ __forceinline__ uint32_t indeg(uint32_t v) const { return __popc(outmask(v ^ 1)); }
+    __device__ __forceinline__ Kmer<W> seq(uint32_t v) const {
+        Kmer<W> x = keys.load(v >> 1);
+        return (v & 1) ? km_revcomp<W>(x, k) : x;
+    }
+    // follow the out-edge of v labelled by appended base b (bit must be set)
+    __device__ __forceinline__ uint32_t follow(uint32_t v, uint32_t b) const {
+        Kmer<W> s = seq(v);
+        km_push_back<W>(s, b, k);
+        int o; Kmer<W> c = km_canonical<W>(s, k, o);
+        uint32_t idx = gt_lookup<W>(gt, keys, c);
+        return idx == NIL ? NIL : idx * 2 + (uint32_t)o;
+    }
+    __device__ __forceinline__ uint32_t only_out(uint32_t v) const {   // outdeg(v) must be 1
+        return follow(v, (uint32_t)__ffs((int)outmask(v)) - 1);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// a11: tips (SPEC S9)
+// ------------------------------------------------------------------------------------------
+struct TipRec { uint32_t start, junction, len, next; unsigned long long sum; };
+
+// candidates: oriented nodes with indeg 0 and outdeg 1
+template <int W>
+__global__ __launch_bounds__(256) void k_tip_candidates(Graph<W> g, const uint8_t *__restrict__ alive,
+                                                        uint32_t *__restrict__ cand,
+                                                        unsigned int *__restrict__ n_cand) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = g.n * 2;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (total + stride - 1) / stride * stride;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
+        bool p = false;
+        if (v < total && alive[v >> 1]) p = (g.indeg(v) == 0) && (g.outdeg(v) == 1);
+        const unsigned long long m = __ballot(p);
+        if (!m) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
+        base = __shfl(base, 0);
+        if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_tip_walk(Graph<W> g, const uint32_t *__restrict__ cand,
+                                                  uint32_t n_cand, TipRec *__restrict__ tips,
+                                                  unsigned int *__restrict__ n_tips,
+                                                  uint32_t *__restrict__ tip_head) {
+    const uint32_t T_TIP = 2u * (uint32_t)g.k;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
+        const uint32_t v = cand[c];
+        uint32_t cur = v, len = 1, J = NIL;
+        unsigned long long sum = g.cnt[v >> 1];
+        for (;;) {
+            if (g.outdeg(cur) != 1) break;
+            const uint32_t n = g.only_out(cur);
+            if (n == NIL) break;                           // cannot happen with consistent adjacency
+            if (g.indeg(n) >= 2) { J = n; break; }
+            len++; sum += g.cnt[n >> 1]; cur = n;
+            if (len > T_TIP) break;
+        }
+        if (J == NIL || len > T_TIP) continue;
+        const uint32_t t = atomicAdd(n_tips, 1u);
+        TipRec r; r.start = v; r.junction = J; r.len = len; r.sum = sum;
+        r.next = atomicExch(&tip_head[J], t);
+        tips[t] = r;
+    }
+}
+
+// decide on the snapshot: per junction, at most 4 tips hang off tip_head[J]
+template <int W>
+__global__ __launch_bounds__(256) void k_tip_decide(Graph<W> g, const TipRec *__restrict__ tips,
+                                                    uint32_t n_tips,
+                                                    const uint32_t *__restrict__ tip_head,
+                                                    uint8_t *__restrict__ kill) {
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x) {
+        const TipRec me = tips[a];
+        const uint32_t d = g.indeg(me.junction);
+        uint32_t t = 0; bool best = true;
+        const Kmer<W> myfirst = g.keys.load(me.start >> 1);
+        for (uint32_t b = tip_head[me.junction]; b != NIL; b = tips[b].next) {
+            t++;
+            if (b == a) continue;
+            const TipRec o = tips[b];
+            bool better;                                   // is o better than me?
+            if (o.len != me.len) better = o.len > me.len;
+            else if (o.sum != me.sum) better = o.sum > me.sum;
+            else better = km_less<W>(g.keys.load(o.start >> 1), myfirst);
+            if (better) best = false;
+        }
+        kill[a] = (t < d) ? 1 : (best ? 0 : 1);
+    }
+}
+
+// mark the nodes of killed tips dead and append them to the removed list
+template <int W>
+__global__ __launch_bounds__(256) void k_tip_remove(Graph<W> g, const TipRec *__restrict__ tips,
+                                                    uint32_t n_tips, const uint8_t *__restrict__ kill,
+                                                    uint32_t *__restrict__ tip_head,
+                                                    uint8_t *__restrict__ mark) {
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x) {
+        const TipRec me = tips[a];
+        if (kill[a]) {
+            uint32_t cur = me.start;
+            for (uint32_t i = 0; i < me.len; i++) {
+                mark[cur >> 1] = 1;
+                if (i + 1 < me.len) cur = g.only_out(cur);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tip_reset_heads(const TipRec *__restrict__ tips, uint32_t n_tips,
+                                                         uint32_t *__restrict__ tip_head) {
+    for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x)
+        tip_head[tips[a].junction] = NIL;
+}
+
+// ------------------------------------------------------------------------------------------
+// a11: bubbles (SPEC S9)
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_fork_candidates(Graph<W> g, const uint8_t *__restrict__ alive,
+                                                         uint32_t *__restrict__ cand,
+                                                         unsigned int *__restrict__ n_cand) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = g.n * 2;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (total + stride - 1) / stride * stride;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
+        bool p = false;
+        if (v < total && alive[v >> 1]) p = g.outdeg(v) >= 2;
+        const unsigned long long m = __ballot(p);
+        if (!m) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
+        base = __shfl(base, 0);
+        if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_bubble(Graph<W> g, const uint32_t *__restrict__ cand,
+                                                uint32_t n_cand, uint8_t *__restrict__ mark) {
+    const uint32_t T_BUB = 2u * (uint32_t)g.k;
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
+        const uint32_t S = cand[c];
+        const uint32_t om = g.outmask(S);
+        uint32_t first[4], end[4], len[4];
+        unsigned long long sum[4];
+        bool ok[4];
+#pragma unroll
+        for (uint32_t b = 0; b < 4; b++) {
+            ok[b] = false; first[b] = NIL; end[b] = NIL; len[b] = 0; sum[b] = 0;
+            if (!((om >> b) & 1u)) continue;
+            const uint32_t bn = g.follow(S, b);
+            if (bn == NIL || g.indeg(bn) != 1) continue;
+            first[b] = bn;
+            uint32_t cur = bn, l = 1;
+            unsigned long long s = g.cnt[bn >> 1];
+            for (;;) {
+                if (g.outdeg(cur) != 1) break;
+                const uint32_t n = g.only_out(cur);
+                if (n == NIL) break;
+                if (g.indeg(n) >= 2) { end[b] = n; ok[b] = true; break; }
+                if (l + 1 > T_BUB) break;
+                l++; s += g.cnt[n >> 1]; cur = n;
+            }
+            len[b] = l; sum[b] = s;
+        }
+#pragma unroll
+        for (uint32_t a = 0; a < 4; a++) {
+            if (!ok[a]) continue;
+            const uint32_t E = end[a];
+            // evaluate the bubble only from the side with key(S) <= key(rc(E))
+            {
+                const Kmer<W> ks = g.keys.load(S >> 1), ke = g.keys.load(E >> 1);
+                bool le;
+                if (km_less<W>(ks, ke)) le = true;
+                else if (km_less<W>(ke, ks)) le = false;
+                else le = (S & 1u) <= ((E ^ 1u) & 1u);
+                if (!le) continue;
+            }
+            uint32_t grp = 0; bool best = true;
+            const Kmer<W> fa = g.keys.load(first[a] >> 1);
+#pragma unroll
+            for (uint32_t b = 0; b < 4; b++) {
+                if (!ok[b] || end[b] != E) continue;
+                grp++;
+                if (b == a) continue;
+                const unsigned long long l = sum[b] * len[a], r = sum[a] * len[b];
+                bool better;                               // is branch b better than a?
+                if (l != r) better = l > r;
+                else if (len[b] != len[a]) better = len[b] < len[a];
+                else better = km_less<W>(g.keys.load(first[b] >> 1), fa);
+                if (better) best = false;
+            }
+            if (grp >= 2 && !best) {
+                uint32_t cur = first[a];
+                for (uint32_t i = 0; i < len[a]; i++) {
+                    mark[cur >> 1] = 1;
+                    if (i + 1 < len[a]) cur = g.only_out(cur);
+                }
+            }
+        }
+    }
+}
+
+// gather marked alive nodes into the removed list, clear alive
+__global__ __launch_bounds__(256) void k_collect_marked(uint32_t n, uint8_t *__restrict__ mark,
+                                                        uint8_t *__restrict__ alive,
+                                                        uint32_t *__restrict__ removed,
+                                                        unsigned int *__restrict__ n_removed) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + stride - 1) / stride * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        bool p = false;
+        if (i < n && mark[i]) { mark[i] = 0; if (alive[i]) { alive[i] = 0; p = true; } }
+        const unsigned long long m = __ballot(p);
+        if (!m) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(n_removed, (unsigned int)__popcll(m));
+        base = __shfl(base, 0);
+        if (p) removed[base + __popcll(m & ((1ull << lane) - 1ull))] = i;
+    }
+}
+
+__device__ __forceinline__ void adj_clear_bit(uint8_t *adj, uint32_t idx, uint32_t bit) {
+    uint32_t *wptr = (uint32_t *)adj + (idx >> 2);
+    atomicAnd(wptr, ~((1u << bit) << (8 * (idx & 3u))));
+}
+
+// for every removed node: clear the reciprocal edge bit in each neighbour, then its own byte
+template <int W>
+__global__ __launch_bounds__(256) void k_apply_removed(Graph<W> g, const uint32_t *__restrict__ removed,
+                                                       uint32_t n_removed) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_removed; t += gridDim.x * blockDim.x) {
+        const uint32_t r = removed[t];
+        const uint32_t a = g.adj[r];
+        const Kmer<W> x = g.keys.load(r);
+        const uint32_t fb = km_first_base<W>(x, g.k), lb = km_last_base<W>(x);
+        for (uint32_t b = 0; b < 4; b++) {
+            if ((a >> b) & 1u) {                            // edge (r,0) -> u
+                Kmer<W> s = x; km_push_back<W>(s, b, g.k);
+                int o; Kmer<W> c = km_canonical<W>(s, g.k, o);
+                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c);
+                if (u != NIL) adj_clear_bit(g.adj, u, o == 0 ? 4 + fb : 3 - fb);
+            }
+            if ((a >> (4 + b)) & 1u) {                      // edge p -> (r,0), p spelled b + x[..k-1)
+                Kmer<W> s = x; km_push_front<W>(s, b, g.k);
+                int o; Kmer<W> c = km_canonical<W>(s, g.k, o);
+                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c);
+                if (u != NIL) adj_clear_bit(g.adj, u, o == 0 ? lb : 4 + (3 - lb));
+            }
+        }
+        uint32_t *wptr = (uint32_t *)g.adj + (r >> 2);
+        atomicAnd(wptr, ~(0xFFu << (8 * (r & 3u))));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a12: collapse (SPEC S10).  succ[] over oriented nodes, splitters every ~64 nodes plus all
+// heads, one walker per splitter, splitter list ranked on the host (it is ~2N/64 long), then
+// every node scatters its base into the contig buffer.
+// ------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_succ(Graph<W> g, const uint8_t *__restrict__ alive,
+                                              uint32_t *__restrict__ succ) {
+    const uint32_t total = g.n * 2;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        uint32_t s = NIL;
+        if (alive[v >> 1] && g.outdeg(v) == 1) {
+            const uint32_t u = g.only_out(v);
+            if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
+        }
+        succ[v] = s;
+    }
+}
+
+// flags: bit0 splitter, bit1 head.  Compacts splitters, owner[v] = splitter index for them.
+template <int W>
+__global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_t *__restrict__ alive,
+                                                        const uint32_t *__restrict__ succ,
+                                                        uint8_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ spl,
+                                                        uint32_t *__restrict__ owner,
+                                                        unsigned int *__restrict__ n_spl) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = g.n * 2;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (total + stride - 1) / stride * stride;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
+        bool p = false; uint8_t f = 0;
+        if (v < total && alive[v >> 1]) {
+            const bool head = succ[v ^ 1u] == NIL;
+            const uint64_t h = km_hash<W>(g.keys.load(v >> 1)) + (uint64_t)(v & 1u) * 0x9E3779B97F4A7C15ull;
+            const bool samp = ((h >> 17) & ((1u << SPLIT_LOG) - 1u)) == 0;
+            p = head || samp;
+            f = (uint8_t)((p ? 1 : 0) | (head ? 2 : 0));
+        }
+        if (v < total) flags[v] = f;
+        const unsigned long long m = __ballot(p);
+        if (!m) continue;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(n_spl, (unsigned int)__popcll(m));
+        base = __shfl(base, 0);
+        if (p) {
+            const uint32_t i = base + __popcll(m & ((1ull << lane) - 1ull));
+            spl[i] = v; owner[v] = i;
+        }
+    }
+}
+
+struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, pad; };
+
+template <int W>
+__global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint32_t *__restrict__ succ,
+                                                       const uint8_t *__restrict__ flags,
+                                                       const uint32_t *__restrict__ spl, uint32_t n_spl,
+                                                       uint32_t *__restrict__ owner,
+                                                       uint32_t *__restrict__ local,
+                                                       SegRec *__restrict__ segs) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
+        const uint32_t s = spl[i];
+        uint32_t cur = s, len = 0, nxt;
+        unsigned long long sum = 0;
+        for (;;) {
+            if (cur != s) owner[cur] = i;
+            local[cur] = len;
+            sum += g.cnt[cur >> 1];
+            len++;
+            nxt = succ[cur];
+            if (nxt == NIL || (flags[nxt] & 1)) break;
+            cur = nxt;
+        }
+        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum;
+        r.next_spl = (nxt == NIL) ? NIL : owner[nxt];      // splitters wrote owner[] before this kernel
+        r.head = (flags[s] >> 1) & 1; r.pad = 0;
+        segs[i] = r;
+    }
+}
+
+// per splitter: chain slot (NIL = not emitted) and position of the segment start in the chain
+template <int W>
+__global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
+                                              const uint32_t *__restrict__ owner,
+                                              const uint32_t *__restrict__ local,
+                                              const uint32_t *__restrict__ spl_chain,
+                                              const uint32_t *__restrict__ spl_base,
+                                              const unsigned long long *__restrict__ chain_off,
+                                              char *__restrict__ out) {
+    const uint32_t total = g.n * 2;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        if (!alive[v >> 1]) continue;
+        const uint32_t s = owner[v];
+        if (s == NIL) continue;
+        const uint32_t ch = spl_chain[s];
+        if (ch == NIL) continue;
+        const uint32_t pos = spl_base[s] + local[v];
+        const Kmer<W> x = g.seq(v);
+        char *dst = out + chain_off[ch];
+        const uint32_t ACGT = 0x54474341u;                 // 'A','C','G','T' little-endian
+        dst[g.k - 1 + pos] = (char)((ACGT >> (8 * km_last_base<W>(x))) & 0xFF);
+        if (pos == 0) {
+            for (int i = 0; i + 1 < g.k; i++) {
+                dst[i] = (char)((ACGT >> (8 * km_bits2<W>(x, 2 * (g.k - 1 - i)))) & 0xFF);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+template <typename T> struct DevBuf {
+    T *p = nullptr; size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int alloc(size_t count, std::string &err) {
+        release();
+        if (count == 0) count = 1;
+        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; err = std::string("hipMalloc: ") + hipGetErrorString(e); return -4; }
+        n = count; return 0;
+    }
+};
+
+static inline int grid_for(uint64_t work, int block = 256, int max_blocks = 256 * 16) {
+    uint64_t b = (work + block - 1) / block;
+    if (b < 1) b = 1;
+    if (b > (uint64_t)max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+struct EvTimer {
+    hipEvent_t a, b; hipStream_t st; bool ok = false;
+    explicit EvTimer(hipStream_t s) : st(s) {
+        ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+        if (ok) (void)hipEventRecord(a, st);
+    }
+    double stop() {
+        if (!ok) return 0.0;
+        (void)hipEventRecord(b, st); (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
+    ~EvTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+};
+
+template <int W> class Pipeline : public IPipeline {
+public:
+    explicit Pipeline(int k) : k_(k) {}
+    ~Pipeline() override { if (stream_) (void)hipStreamDestroy(stream_); }
+    int init(std::string &err) {
+        HIPCHK(hipStreamCreate(&stream_));
+        HIPCHK(ctl_.alloc(16, err) ? hipErrorOutOfMemory : hipSuccess);
+        return 0;
+    }
+    StageTimes &times() override { return times_; }
+    void *stream() override { return (void *)stream_; }
+    uint64_t total_instances() const override { return total_instances_; }
+    uint64_t n_distinct() const override { return n_distinct_; }
+    uint64_t n_solid() const override { return n_solid_; }
+
+    // ---- counting --------------------------------------------------------------------------
+    int alloc_table(uint64_t slots, std::string &err) {
+        for (int j = 0; j < W; j++) if (int rc = tkeys_[j].alloc(slots, err)) return rc;
+        if (int rc = tcnt_.alloc(slots, err)) return rc;
+        if (W > 1) if (int rc = tstate_.alloc(slots, err)) return rc;
+        tslots_ = slots;
+        if (W == 1) HIPCHK(hipMemsetAsync(tkeys_[0].p, 0xFF, slots * 8, stream_));
+        else HIPCHK(hipMemsetAsync(tstate_.p, 0, slots * 4, stream_));
+        HIPCHK(hipMemsetAsync(tcnt_.p, 0, slots * 4, stream_));
+        return 0;
+    }
+    CountTable<W> table_view() {
+        CountTable<W> t;
+        for (int j = 0; j < W; j++) t.keys.w[j] = tkeys_[j].p;
+        t.cnt = tcnt_.p; t.state = tstate_.p; t.mask = tslots_ - 1;
+        return t;
+    }
+
+    int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                    uint64_t n_bases, std::string &err) override {
+        if (n_seg >= 0xFFFFFFFFull || n_bases >= 0xFFFFFFFFull) { err = "batch too large (>= 2^32 bases)"; return -1; }
+        if (n_seg == 0) return 0;
+        // single batch per table in this version; size from the instance upper bound
+        const uint64_t inst_ub = n_bases - n_seg * (uint64_t)(k_ - 1);
+        if (tslots_ == 0) {
+            uint64_t want = inst_ub / 4 + 1024;
+            uint64_t slots = 1ull << 16;
+            while (slots < want) slots <<= 1;
+            if (int rc = alloc_table(slots, err)) return rc;
+            pending_.clear();
+        }
+        pending_.push_back({d_bases, d_seg_off, n_seg});
+        for (;;) {
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            EvTimer t(stream_);
+            hipLaunchKernelGGL(k_count_segments<W>, dim3(grid_for(n_seg)), dim3(256), 0, stream_, d_bases,
+                               d_seg_off, (uint32_t)n_seg, k_, table_view(), (uint32_t *)(ctl_.p + 1),
+                               ctl_.p + 0);
+            HIPCHK(hipGetLastError());
+            double ms = t.stop();
+            unsigned long long h[2];
+            HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            if ((uint32_t)h[1] == 0) {
+                times_.add("count_kernel", ms);
+                total_instances_ += h[0];
+                return 0;
+            }
+            // table too small: grow 4x and recount every batch seen so far
+            if (pending_.size() > 1) { err = "count table overflow across batches"; return -6; }
+            times_.add("count_retry", ms);
+            if (int rc = alloc_table(tslots_ * 4, err)) return rc;
+        }
+    }
+
+    int histogram(uint64_t histo[500], std::string &err) override {
+        DevBuf<unsigned long long> dh;
+        if (int rc = dh.alloc(500, err)) return rc;
+        HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
+        if (tslots_) {
+            EvTimer t(stream_);
+            hipLaunchKernelGGL(k_histogram<W>, dim3(grid_for(tslots_)), dim3(256), 0, stream_, table_view(),
+                               tslots_, dh.p);
+            HIPCHK(hipGetLastError());
+            times_.add("histogram_kernel", t.stop());
+        }
+        HIPCHK(hipMemcpyAsync(histo, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        n_distinct_ = 0;
+        for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
+        return 0;
+    }
+
+    int compact_into(uint32_t threshold, uint64_t expect, DevBuf<uint64_t> (&keys)[W], DevBuf<uint32_t> &cnt,
+                     std::string &err) {
+        for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(expect, err)) return rc;
+        if (int rc = cnt.alloc(expect, err)) return rc;
+        if (!tslots_ || !expect) return 0;
+        HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
+        hipLaunchKernelGGL(k_compact<W>, dim3(grid_for(tslots_)), dim3(256), 0, stream_, table_view(), tslots_,
+                           threshold, ok, cnt.p, ctl_.p + 0);
+        HIPCHK(hipGetLastError());
+        unsigned long long got = 0;
+        HIPCHK(hipMemcpyAsync(&got, ctl_.p, 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        if (got != expect) { err = "compaction count mismatch"; return -6; }
+        return 0;
+    }
+
+    int filter(uint32_t threshold, std::string &err) override {
+        uint64_t expect = 0;
+        for (uint32_t c = 1; c <= 500; c++) if (c > threshold) expect += histo_[c - 1];
+        if (threshold >= 500) { err = "threshold out of range"; return -1; }
+        if (expect >= 0x7FFFFFFFull) { err = "too many solid k-mers for 32-bit node ids"; return -1; }
+        EvTimer t(stream_);
+        if (int rc = compact_into(threshold, expect, skeys_, scnt_, err)) return rc;
+        times_.add("filter_kernel", t.stop());
+        n_solid_ = expect;
+        graph_ready_ = false;
+        return 0;
+    }
+
+    int copy_out(DevBuf<uint64_t> (&keys)[W], DevBuf<uint32_t> &cnt, uint64_t n, uint64_t *hk, uint32_t *hc,
+                 std::string &err) {
+        std::vector<uint64_t> tmp(n ? n : 1);
+        for (int j = 0; j < W; j++) {
+            if (n) HIPCHK(hipMemcpy(tmp.data(), keys[j].p, n * 8, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n; i++) hk[i * W + j] = tmp[i];
+        }
+        if (n) HIPCHK(hipMemcpy(hc, cnt.p, n * 4, hipMemcpyDeviceToHost));
+        return 0;
+    }
+
+    int get_distinct(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) override {
+        if (cap < n_distinct_) { err = "buffer too small"; return -1; }
+        DevBuf<uint64_t> dk[W]; DevBuf<uint32_t> dc;
+        if (int rc = compact_into(0, n_distinct_, dk, dc, err)) return rc;
+        return copy_out(dk, dc, n_distinct_, keys, counts, err);
+    }
+    int get_solid(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) override {
+        if (cap < n_solid_) { err = "buffer too small"; return -1; }
+        return copy_out(skeys_, scnt_, n_solid_, keys, counts, err);
+    }
+
+    // ---- graph -----------------------------------------------------------------------------
+    Graph<W> graph_view() {
+        Graph<W> g;
+        for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
+        g.cnt = scnt_.p; g.adj = adj_.p; g.gt.e = gt_.p; g.gt.mask = gt_slots_ - 1; g.k = k_;
+        g.n = (uint32_t)n_solid_;
+        return g;
+    }
+
+    int build_graph(std::string &err) override {
+        const uint64_t n = n_solid_;
+        // count table is no longer needed once the solid set exists
+        for (int j = 0; j < W; j++) tkeys_[j].release();
+        tcnt_.release(); tstate_.release(); tslots_ = 0;
+        gt_slots_ = 1ull << 10;
+        while (gt_slots_ < 2 * n + 16) gt_slots_ <<= 1;
+        if (int rc = gt_.alloc(gt_slots_, err)) return rc;
+        if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
+        if (int rc = adj0_.alloc(n, err)) return rc;
+        if (int rc = alive_.alloc(n, err)) return rc;
+        HIPCHK(hipMemsetAsync(gt_.p, 0xFF, gt_slots_ * 8, stream_));
+        HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
+        HIPCHK(hipMemsetAsync(alive_.p, 1, n ? n : 1, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        if (n) {
+            Graph<W> g = graph_view();
+            EvTimer t(stream_);
+            hipLaunchKernelGGL(k_gt_insert<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, g.gt,
+                               (uint32_t *)(ctl_.p + 1));
+            HIPCHK(hipGetLastError());
+            times_.add("graph_table_kernel", t.stop());
+            EvTimer t2(stream_);
+            hipLaunchKernelGGL(k_adjacency<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_,
+                               g.gt, adj_.p);
+            HIPCHK(hipGetLastError());
+            times_.add("adjacency_kernel", t2.stop());
+            HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
+            unsigned long long h[2];
+            HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            if ((uint32_t)h[1]) { err = "graph table overflow"; return -6; }
+        }
+        graph_ready_ = true;
+        return 0;
+    }
+
+    int read_ctl(unsigned int &v, int slot, std::string &err) {
+        unsigned long long h = 0;
+        HIPCHK(hipMemcpyAsync(&h, ctl_.p + slot, 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        v = (unsigned int)h;
+        return 0;
+    }
+
+    int apply_marks(Graph<W> &g, DevBuf<uint8_t> &mark, DevBuf<uint32_t> &removed, unsigned int &n_removed,
+                    std::string &err) {
+        const uint32_t n = (uint32_t)n_solid_;
+        HIPCHK(hipMemsetAsync(ctl_.p + 2, 0, 8, stream_));
+        hipLaunchKernelGGL(k_collect_marked, dim3(grid_for(n)), dim3(256), 0, stream_, n, mark.p, alive_.p,
+                           removed.p, (unsigned int *)(ctl_.p + 2));
+        HIPCHK(hipGetLastError());
+        if (int rc = read_ctl(n_removed, 2, err)) return rc;
+        if (n_removed) {
+            hipLaunchKernelGGL(k_apply_removed<W>, dim3(grid_for(n_removed)), dim3(256), 0, stream_, g, removed.p,
+                               n_removed);
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
+
+    int correct(bool tips, bool bubbles, std::string &err) override {
+        if (!graph_ready_) { err = "graph not built"; return -2; }
+        const uint32_t n = (uint32_t)n_solid_;
+        tips_removed_ = bubbles_removed_ = 0; rounds_ = 0;
+        if (n == 0 || (!tips && !bubbles)) return 0;
+        Graph<W> g = graph_view();
+        DevBuf<uint32_t> cand, tip_head, removed;
+        DevBuf<uint8_t> mark, kill;
+        DevBuf<TipRec> tiprec;
+        if (int rc = cand.alloc(2ull * n, err)) return rc;
+        if (int rc = removed.alloc(n, err)) return rc;
+        if (int rc = mark.alloc(n, err)) return rc;
+        HIPCHK(hipMemsetAsync(mark.p, 0, n, stream_));
+        if (tips) {
+            if (int rc = tip_head.alloc(2ull * n, err)) return rc;
+            HIPCHK(hipMemsetAsync(tip_head.p, 0xFF, 2ull * n * 4, stream_));
+        }
+        EvTimer t(stream_);
+        for (int round = 0; round < 32; round++) {
+            unsigned int n1 = 0, n2 = 0;
+            if (tips) {
+                unsigned int nc = 0, nt = 0;
+                HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 16, stream_));
+                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, alive_.p,
+                                   cand.p, (unsigned int *)(ctl_.p + 3));
+                HIPCHK(hipGetLastError());
+                if (int rc = read_ctl(nc, 3, err)) return rc;
+                if (nc) {
+                    if (tiprec.n < nc) if (int rc = tiprec.alloc(nc, err)) return rc;
+                    if (kill.n < nc) if (int rc = kill.alloc(nc, err)) return rc;
+                    hipLaunchKernelGGL(k_tip_walk<W>, dim3(grid_for(nc)), dim3(256), 0, stream_, g, cand.p, nc,
+                                       tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
+                    HIPCHK(hipGetLastError());
+                    if (int rc = read_ctl(nt, 4, err)) return rc;
+                }
+                if (nt) {
+                    hipLaunchKernelGGL(k_tip_decide<W>, dim3(grid_for(nt)), dim3(256), 0, stream_, g, tiprec.p, nt,
+                                       tip_head.p, kill.p);
+                    hipLaunchKernelGGL(k_tip_remove<W>, dim3(grid_for(nt)), dim3(256), 0, stream_, g, tiprec.p, nt,
+                                       kill.p, tip_head.p, mark.p);
+                    hipLaunchKernelGGL(k_tip_reset_heads, dim3(grid_for(nt)), dim3(256), 0, stream_, tiprec.p, nt,
+                                       tip_head.p);
+                    HIPCHK(hipGetLastError());
+                    if (int rc = apply_marks(g, mark, removed, n1, err)) return rc;
+                }
+            }
+            if (bubbles) {
+                unsigned int nc = 0;
+                HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
+                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, alive_.p,
+                                   cand.p, (unsigned int *)(ctl_.p + 3));
+                HIPCHK(hipGetLastError());
+                if (int rc = read_ctl(nc, 3, err)) return rc;
+                if (nc) {
+                    hipLaunchKernelGGL(k_bubble<W>, dim3(grid_for(nc)), dim3(256), 0, stream_, g, cand.p, nc, mark.p);
+                    HIPCHK(hipGetLastError());
+                    if (int rc = apply_marks(g, mark, removed, n2, err)) return rc;
+                }
+            }
+            tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
+            if (n1 + n2 == 0) break;
+        }
+        times_.add("correct_total", t.stop());
+        return 0;
+    }
+
+    int get_adjacency(uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive, uint64_t cap,
+                      std::string &err) override {
+        if (!graph_ready_) { err = "graph not built"; return -2; }
+        if (cap < n_solid_) { err = "buffer too small"; return -1; }
+        if (!n_solid_) return 0;
+        if (adj_initial) HIPCHK(hipMemcpy(adj_initial, adj0_.p, n_solid_, hipMemcpyDeviceToHost));
+        if (adj_final) HIPCHK(hipMemcpy(adj_final, adj_.p, n_solid_, hipMemcpyDeviceToHost));
+        if (alive) HIPCHK(hipMemcpy(alive, alive_.p, n_solid_, hipMemcpyDeviceToHost));
+        return 0;
+    }
+
+    // ---- collapse ----------------------------------------------------------------------------
+    int collapse(std::vector<RawContig> &out, std::string &err) override {
+        out.clear();
+        if (!graph_ready_) { err = "graph not built"; return -2; }
+        const uint32_t n = (uint32_t)n_solid_;
+        if (n == 0) return 0;
+        const uint32_t total = 2 * n;
+        Graph<W> g = graph_view();
+        DevBuf<uint32_t> succ, spl, owner, local;
+        DevBuf<uint8_t> flags;
+        DevBuf<SegRec> segs;
+        if (int rc = succ.alloc(total, err)) return rc;
+        if (int rc = spl.alloc(total, err)) return rc;
+        if (int rc = owner.alloc(total, err)) return rc;
+        if (int rc = local.alloc(total, err)) return rc;
+        if (int rc = flags.alloc(total, err)) return rc;
+        HIPCHK(hipMemsetAsync(owner.p, 0xFF, (size_t)total * 4, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 8, stream_));
+        EvTimer t1(stream_);
+        hipLaunchKernelGGL(k_succ<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p);
+        hipLaunchKernelGGL(k_mark_splitters<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p,
+                           flags.p, spl.p, owner.p, (unsigned int *)(ctl_.p + 5));
+        HIPCHK(hipGetLastError());
+        unsigned int n_spl = 0;
+        if (int rc = read_ctl(n_spl, 5, err)) return rc;
+        times_.add("collapse_succ_split", t1.stop());
+        std::vector<SegRec> hseg(n_spl);
+        if (n_spl) {
+            if (int rc = segs.alloc(n_spl, err)) return rc;
+            EvTimer t2(stream_);
+            hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, g, succ.p,
+                               flags.p, spl.p, n_spl, owner.p, local.p, segs.p);
+            HIPCHK(hipGetLastError());
+            times_.add("collapse_walk", t2.stop());
+            HIPCHK(hipMemcpyAsync(hseg.data(), segs.p, (size_t)n_spl * sizeof(SegRec), hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+        }
+        // ---- rank the splitter list on the host (it is ~2N/64 long)
+        auto th0 = std::chrono::steady_clock::now();
+        struct Chain { uint32_t head_spl; uint64_t len; uint64_t kc; uint32_t head_node, tail_node; };
+        std::vector<Chain> chains;
+        std::vector<uint32_t> spl_chain(n_spl, NIL), spl_base(n_spl, 0);
+        std::vector<uint8_t> seen(n_spl, 0);
+        uint64_t covered = 0;
+        for (uint32_t i = 0; i < n_spl; i++) {
+            if (!hseg[i].head) continue;
+            Chain c; c.head_spl = i; c.len = 0; c.kc = 0; c.head_node = hseg[i].node; c.tail_node = hseg[i].node;
+            uint32_t cur = i;
+            while (cur != NIL) {
+                if (seen[cur]) { err = "collapse: splitter reached twice"; return -6; }
+                seen[cur] = 1;
+                spl_base[cur] = (uint32_t)c.len;
+                c.len += hseg[cur].len; c.kc += hseg[cur].sum; c.tail_node = hseg[cur].last;
+                cur = hseg[cur].next_spl;
+            }
+            covered += c.len;
+            // each unitig exists on both strands: keep the one whose head id <= rc(tail) id
+            const bool emit = c.head_node <= (c.tail_node ^ 1u);
+            if (emit) {
+                const uint32_t id = (uint32_t)chains.size();
+                chains.push_back(c);
+                for (cur = i; cur != NIL; cur = hseg[cur].next_spl) spl_chain[cur] = id;
+            }
+        }
+        std::vector<unsigned long long> chain_off(chains.size() + 1, 0);
+        for (size_t c = 0; c < chains.size(); c++) chain_off[c + 1] = chain_off[c] + chains[c].len + (uint64_t)(k_ - 1);
+        const uint64_t out_bytes = chain_off[chains.size()];
+        times_.add("collapse_host_rank", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
+
+        std::vector<char> hout(out_bytes);
+        if (!chains.empty()) {
+            DevBuf<uint32_t> d_chain, d_base; DevBuf<unsigned long long> d_off; DevBuf<char> d_out;
+            if (int rc = d_chain.alloc(n_spl, err)) return rc;
+            if (int rc = d_base.alloc(n_spl, err)) return rc;
+            if (int rc = d_off.alloc(chain_off.size(), err)) return rc;
+            if (int rc = d_out.alloc(out_bytes, err)) return rc;
+            HIPCHK(hipMemcpyAsync(d_chain.p, spl_chain.data(), (size_t)n_spl * 4, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(d_base.p, spl_base.data(), (size_t)n_spl * 4, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(d_off.p, chain_off.data(), chain_off.size() * 8, hipMemcpyHostToDevice, stream_));
+            EvTimer t3(stream_);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, owner.p, local.p,
+                               d_chain.p, d_base.p, d_off.p, d_out.p);
+            HIPCHK(hipGetLastError());
+            times_.add("collapse_emit", t3.stop());
+            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            for (size_t c = 0; c < chains.size(); c++) {
+                RawContig rc; rc.kc = chains[c].kc;
+                rc.seq.assign(hout.data() + chain_off[c], hout.data() + chain_off[c + 1]);
+                out.push_back(std::move(rc));
+            }
+        }
+        // ---- circular unitigs (no head): rare; resolved on the host from succ[] (SPEC S10)
+        std::vector<uint8_t> halive(n);
+        HIPCHK(hipMemcpy(halive.data(), alive_.p, n, hipMemcpyDeviceToHost));
+        uint64_t n_alive = 0;
+        for (uint32_t i = 0; i < n; i++) n_alive += halive[i];
+        if (covered != 2 * n_alive) {
+            auto tc0 = std::chrono::steady_clock::now();
+            std::vector<uint32_t> hsucc(total), howner(total), hcnt(n);
+            std::vector<uint64_t> hkeys((size_t)n * W);
+            HIPCHK(hipMemcpy(hsucc.data(), succ.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(hcnt.data(), scnt_.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+            {
+                std::vector<uint64_t> tmp(n);
+                for (int j = 0; j < W; j++) {
+                    HIPCHK(hipMemcpy(tmp.data(), skeys_[j].p, (size_t)n * 8, hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < n; i++) hkeys[(size_t)i * W + j] = tmp[i];
+                }
+            }
+            // nodes on headed chains: walk them again on the host to mark coverage
+            std::vector<uint8_t> on_chain(n, 0);
+            for (uint32_t i = 0; i < n_spl; i++) {
+                if (!seen[i]) continue;
+                uint32_t v = hseg[i].node;
+                for (uint32_t j = 0; j < hseg[i].len; j++) { on_chain[v >> 1] = 1; v = hsucc[v]; }
+            }
+            auto key_of = [&](uint32_t idx) { Kmer<W> x; for (int j = 0; j < W; j++) x.w[j] = hkeys[(size_t)idx * W + j]; return x; };
+            std::vector<uint8_t> done(n, 0);
+            for (uint32_t i = 0; i < n; i++) {
+                if (!halive[i] || on_chain[i] || done[i]) continue;
+                // find the smallest canonical k-mer on this cycle (either strand holds the same nodes)
+                uint32_t v = i * 2, best = i; uint64_t len = 0;
+                do {
+                    if (km_less<W>(key_of(v >> 1), key_of(best))) best = v >> 1;
+                    v = hsucc[v]; len++;
+                    if (v == NIL || len > (uint64_t)total) { err = "collapse: broken cycle"; return -6; }
+                } while (v != i * 2);
+                RawContig rc; rc.kc = 0;
+                const char B[4] = {'A', 'C', 'G', 'T'};
+                v = best * 2;
+                Kmer<W> x = key_of(best);
+                for (int q = 0; q < k_; q++) rc.seq.push_back(B[km_bits2<W>(x, 2 * (k_ - 1 - q))]);
+                for (uint64_t q = 0; q < len; q++) {
+                    done[v >> 1] = 1; rc.kc += hcnt[v >> 1];
+                    if (q > 0) {
+                        Kmer<W> y = key_of(v >> 1);
+                        if (v & 1) y = km_revcomp<W>(y, k_);
+                        rc.seq.push_back(B[km_last_base<W>(y)]);
+                    }
+                    v = hsucc[v];
+                }
+                out.push_back(std::move(rc));
+            }
+            times_.add("collapse_host_cycles", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
+        }
+        return 0;
+    }
+
+private:
+    int k_;
+    hipStream_t stream_ = nullptr;
+    StageTimes times_;
+    DevBuf<unsigned long long> ctl_;
+    // count table
+    DevBuf<uint64_t> tkeys_[W]; DevBuf<uint32_t> tcnt_, tstate_; uint64_t tslots_ = 0;
+    struct Batch { const uint32_t *bases, *seg_off; uint64_t n_seg; };
+    std::vector<Batch> pending_;
+    uint64_t total_instances_ = 0, n_distinct_ = 0, n_solid_ = 0;
+    uint64_t histo_[500] = {0};
+    // solid set / graph
+    DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
+    DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0;
+    DevBuf<uint8_t> adj_, adj0_, alive_;
+    bool graph_ready_ = false;
+    uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;
+};
+
+int device_count() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+IPipeline *make_pipeline(int k, std::string &err) {
+    if (device_count() <= 0) { err = "no HIP device available (libshk_hip has no CPU fallback)"; return nullptr; }
+    const int W = (2 * k + 63) / 64;
+    int rc = -1;
+    IPipeline *p = nullptr;
+    if (W == 1) { auto *q = new Pipeline<1>(k); rc = q->init(err); p = q; }
+    else if (W == 2) { auto *q = new Pipeline<2>(k); rc = q->init(err); p = q; }
+    else { err = "k too large for the compiled key widths"; return nullptr; }
+    if (rc != 0) { delete p; return nullptr; }
+    return p;
+}
+
+int device_upload(const void *host, size_t bytes, void **dptr, std::string &err) {
+    *dptr = nullptr;
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 4));
+    if (bytes) {
+        hipError_t e = hipMemcpy(*dptr, host, bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(*dptr); *dptr = nullptr; err = hipGetErrorString(e); return -5; }
+    }
+    return 0;
+}
+void device_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
+
+// ---- host-side self-test helpers (same arithmetic as the kernels) ---------------------------
+template <int W> static int host_canon_t(const char *seq, uint32_t k, uint64_t *out, int *orient) {
+    Kmer<W> f = km_zero<W>();
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t b;
+        switch (seq[i]) { case 'A': case 'a': b = 0; break; case 'C': case 'c': b = 1; break;
+                          case 'G': case 'g': b = 2; break; case 'T': case 't': b = 3; break; default: return -1; }
+        km_push_back<W>(f, b, (int)k);
+    }
+    int o; Kmer<W> c = km_canonical<W>(f, (int)k, o);
+    for (int j = 0; j < W; j++) out[j] = c.w[j];
+    if (orient) *orient = o;
+    return 0;
+}
+int host_canonical(const char *seq, uint32_t k, uint64_t *out, int *orient) {
+    const int W = (2 * k + 63) / 64;
+    if (W == 1) return host_canon_t<1>(seq, k, out, orient);
+    if (W == 2) return host_canon_t<2>(seq, k, out, orient);
+    if (W == 3) return host_canon_t<3>(seq, k, out, orient);
+    if (W == 4) return host_canon_t<4>(seq, k, out, orient);
+    return -1;
+}
+uint64_t host_nthash(const char *seq, uint32_t k) {
+    // roll across the first k bases exactly as the kernel does
+    NtState nt{0, 0};
+    for (uint32_t i = 0; i < k; i++) {
+        uint32_t b = seq[i] == 'A' ? 0 : seq[i] == 'C' ? 1 : seq[i] == 'G' ? 2 : 3;
+        nt_init_step(nt, b, i);
+    }
+    return nt_canonical(nt);
+}
+
+}  // namespace shk

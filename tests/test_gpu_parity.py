@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle, stage by stage,
+bit-exact (integer / byte / index work throughout).  Run on the MI355X box: pytest -m gpu."""
+import gzip
+import json
+
+import numpy as np
+import pytest
+
+import cases
+from sparrowhawk_amd import AssemblyHelper, ShkError, synth
+from util import (compare_all, int_to_words, make_dataset, parse_fastq, py_count, revcomp,
+                  run_oracle, sorted_table)
+
+pytestmark = pytest.mark.gpu
+
+
+def product(fq1, fq2=None, k=31, min_count=5, min_qual=20, csize=0, do_bloom=False, do_fit=False,
+            no_bubble=False, no_deadend=False, assemble=True):
+    h = AssemblyHelper.new(k, True, min_count, min_qual, csize, do_bloom, do_fit, no_bubble, no_deadend)
+    h.preprocess(fq1, fq2)
+    if assemble:
+        h.assemble()
+    return h
+
+
+def contig_set(h):
+    fa = json.loads(h.get_assembly())["outfasta"].split("\n")
+    return {l for l in fa if l and not l.startswith(">")}
+
+
+@pytest.mark.parametrize("k,err,cov", [(31, 0.0, 30), (31, 0.01, 40), (51, 0.01, 40), (21, 0.005, 25),
+                                        (63, 0.01, 40), (33, 0.0, 20)])
+def test_full_pipeline_parity(k, err, cov):
+    g, fq = make_dataset(30000, cov, err=err, seed=k + int(err * 1000))
+    h = product(fq, k=k, min_count=3)
+    o = run_oracle([fq], k=k, min_count=3)
+    out = compare_all(h, o)
+    assert out["ncontigs"] >= 1
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_distinct_table_parity(k):
+    """Stage (a): the complete (canonical k-mer, count) table before filtering."""
+    g, fq = make_dataset(20000, 20, err=0.01, seed=40 + k)
+    h = product(fq, k=k, min_count=0, min_qual=20, assemble=False)
+    hk, hc, _ = sorted_table(*h.distinct())
+    o = run_oracle([fq], k=k, min_count=0, min_qual=20)
+    ok_, oc_ = o.distinct()
+    assert np.array_equal(hk, ok_) and np.array_equal(hc, oc_)
+    assert h.total_instances == o.total_instances
+    # and against the independent pure-Python count
+    ref = py_count(parse_fastq(fq), k, min_qual=20)
+    W = (2 * k + 63) // 64
+    got = {tuple(int(x) for x in hk[i]): int(hc[i]) for i in range(0, len(hc), 37)}
+    for key, c in got.items():
+        v = sum(key[j] << (64 * j) for j in range(W))
+        assert ref[v] == c
+
+
+def test_error_reads_with_correction_flags():
+    g, fq = make_dataset(40000, 50, err=0.01, seed=77)
+    for nb, nd in ((False, False), (True, False), (False, True), (True, True)):
+        h = product(fq, k=31, min_count=2, no_bubble=nb, no_deadend=nd)
+        o = run_oracle([fq], k=31, min_count=2, no_bubble_collapse=nb, no_dead_end_removal=nd)
+        compare_all(h, o)
+
+
+def test_low_filter_many_tips_and_bubbles():
+    """min_count=0 keeps every error k-mer: thousands of tips and bubbles, several rounds."""
+    g, fq = make_dataset(15000, 30, err=0.01, seed=5)
+    h = product(fq, k=31, min_count=0, min_qual=0)
+    o = run_oracle([fq], k=31, min_count=0, min_qual=0)
+    compare_all(h, o)
+    assert o.tips_removed > 0 and o.bubbles_removed > 0
+
+
+def test_quality_masking_and_fit():
+    g, fq = make_dataset(30000, 60, err=0.01, seed=9)
+    for mq in (0, 20):
+        h = product(fq, k=31, min_count=5, min_qual=mq, do_fit=True)
+        o = run_oracle([fq], k=31, min_count=5, min_qual=mq, do_fit=True)
+        compare_all(h, o)
+        assert h.used_min_count == o.used_min_count
+
+
+def test_hand_cases():
+    c = cases.tip_case()
+    assert contig_set(product(c["fastq"], k=c["k"], min_count=0, min_qual=0)) == c["with_removal"]
+    assert contig_set(product(c["fastq"], k=c["k"], min_count=0, min_qual=0, no_deadend=True)) == c["without_removal"]
+    c = cases.bubble_case()
+    assert contig_set(product(c["fastq"], k=c["k"], min_count=0, min_qual=0)) == c["with_collapse"]
+    assert contig_set(product(c["fastq"], k=c["k"], min_count=0, min_qual=0, no_bubble=True)) == c["without_collapse"]
+    c = cases.cycle_case()
+    h = product(c["fastq"], k=c["k"], min_count=0, min_qual=0)
+    assert contig_set(h) == c["expect"]
+    compare_all(h, run_oracle([c["fastq"]], k=c["k"], min_count=0, min_qual=0))
+    c = cases.palindrome_case()
+    h = product(c["fastq"], k=c["k"], min_count=0, min_qual=0)
+    assert contig_set(h) == c["expect"]
+    compare_all(h, run_oracle([c["fastq"]], k=c["k"], min_count=0, min_qual=0))
+
+
+def test_circular_genome_with_and_without_splitters():
+    # long cycle (has sampled splitters) and short cycle (may have none)
+    for n, seed in ((5000, 21), (40, 22)):
+        g = synth.random_genome(n, seed)
+        codes, quals = synth.sample_reads(g, n * 40 // 100 + 50, 100, seed, circular=True)
+        fq = synth.to_fastq(codes, quals)
+        h = product(fq, k=31, min_count=1)
+        o = run_oracle([fq], k=31, min_count=1)
+        out = compare_all(h, o)
+        assert out["ncontigs"] == 1
+        assert "L\t1\t+\t1\t+\t30M" in out["outgfa"]
+
+
+def test_repeats_make_a_branching_graph():
+    rng = np.random.default_rng(3)
+    rep = synth.random_genome(400, 100)
+    parts = [synth.random_genome(3000, 101), rep, synth.random_genome(3000, 102), rep,
+             synth.random_genome(3000, 103), 3 - rep[::-1], synth.random_genome(2000, 104)]
+    g = np.concatenate(parts).astype(np.uint8)
+    codes, quals = synth.sample_reads(g, len(g) * 40 // 150, 150, 7)
+    fq = synth.to_fastq(codes, quals)
+    h = product(fq, k=31, min_count=2)
+    o = run_oracle([fq], k=31, min_count=2)
+    out = compare_all(h, o)
+    assert out["ncontigs"] > 3 and "L\t" in out["outgfa"]
+
+
+def test_paired_gzip_and_streaming_equal_single_file():
+    g, fq = make_dataset(20000, 30, err=0.005, seed=31)
+    recs = fq.decode().split("@r")[1:]
+    half = len(recs) // 2
+    f1 = ("@r" + "@r".join(recs[:half])).encode()
+    f2 = ("@r" + "@r".join(recs[half:])).encode()
+    a = product(fq, k=31, min_count=2)
+    b = product(gzip.compress(f1), gzip.compress(f2), k=31, min_count=2)
+    assert a.get_assembly() == b.get_assembly()
+    assert a.get_preprocessing_info() == b.get_preprocessing_info()
+    c = AssemblyHelper.new(31, True, 2, 20, 150000, False, False, False, False)
+    c.push_reads(f1); c.push_reads(f2); c.finish_reads(); c.assemble()
+    assert a.get_assembly() == c.get_assembly()
+    o = run_oracle([f1, f2], k=31, min_count=2)
+    compare_all(b, o)
+
+
+def test_metamorphic_read_order_and_strand():
+    g, fq = make_dataset(20000, 30, err=0.005, seed=32)
+    lines = fq.decode().strip().split("\n")
+    reads = [(lines[i + 1], lines[i + 3]) for i in range(0, len(lines), 4)]
+    rng = np.random.default_rng(1)
+    out = []
+    for j, i in enumerate(rng.permutation(len(reads))):
+        s, q = reads[i]
+        if j % 2:
+            s, q = revcomp(s), q[::-1]
+        out.append(f"@x{j}\n{s}\n+\n{q}\n")
+    a = product(fq, k=31, min_count=2)
+    b = product("".join(out).encode(), k=31, min_count=2)
+    assert a.get_assembly() == b.get_assembly()
+    # determinism: the same input twice gives identical bytes
+    c = product(fq, k=31, min_count=2)
+    assert a.get_assembly() == c.get_assembly()
+
+
+def test_progress_states_and_modes():
+    g, fq = make_dataset(5000, 20, seed=33)
+    for kw, mode in ((dict(csize=0), "bulk"), (dict(csize=150000), "chunked"),
+                     (dict(do_bloom=True), "bloom")):
+        h = product(fq, k=31, min_count=5, do_fit=True, **kw)
+        s = h.states
+        assert s[0] == "preprocess:start" and s[1] == f"preprocess:{mode}:start"
+        assert s[2] == f"preprocess:{mode}:loop:start"
+        assert f"preprocess:{mode}:loop:end" in s
+        assert (f"preprocess:bulk:sorting" in s) == (mode == "bulk")
+        assert f"preprocess:{mode}:fitting" in s and f"preprocess:{mode}:filtering" in s
+        i = s.index("preprocess:saving")
+        assert s[i:] == ["preprocess:saving", "preprocess:end", "assembly:start", "assembly:create_graph",
+                         "assembly:correct_graph", "assembly:collapse_graph", "assembly:saving", "assembly:end"]
+    # all modes count exactly the same here (SPEC S4)
+    outs = {product(fq, k=31, min_count=5, **kw).get_assembly()
+            for kw in (dict(csize=0), dict(csize=1000), dict(do_bloom=True))}
+    assert len(outs) == 1
+
+
+def test_state_machine_and_errors():
+    g, fq = make_dataset(3000, 10, seed=34)
+    h = AssemblyHelper.new(31, True, 2, 20, 0, False, False, False, False)
+    with pytest.raises(ShkError) as e:
+        h.assemble()
+    assert e.value.code == -2
+    with pytest.raises(ShkError):
+        h.get_preprocessing_info()
+    with pytest.raises(ShkError) as e:
+        h.preprocess(b"@r\nACGT\n+\nII\n")
+    assert e.value.code == -3
+    h = AssemblyHelper.new(31, True, 2, 20, 0, False, False, False, False)
+    h.preprocess(fq)
+    with pytest.raises(ShkError) as e:
+        h.preprocess(fq)                                  # one preprocess per handle (Assembler.ts:92)
+    assert e.value.code == -2
+    with pytest.raises(ShkError):
+        h.get_assembly()
+    h.assemble()
+    with pytest.raises(ShkError):
+        h.assemble()
+    json.loads(h.get_assembly())
+
+
+def test_empty_and_degenerate_inputs():
+    for fq in (b"", b"@r\nACGTACGT\n+\nIIIIIIII\n", b"@r\n" + b"N" * 100 + b"\n+\n" + b"I" * 100 + b"\n"):
+        h = product(fq, k=31, min_count=0)
+        out = json.loads(h.get_assembly())
+        assert out["ncontigs"] == 0 and out["outfasta"] == ""
+        info = json.loads(h.get_preprocessing_info())
+        assert info["nkmers"] == 0 and sum(info["histo"]) == 0
+        compare_all(h, run_oracle([fq], k=31, min_count=0), check_graph=False)
+    # a single k-mer
+    fq = b"@r\n" + b"ACGTTGCATGCCGATAGCTAGCTAGGATCCA" + b"\n+\n" + b"I" * 31 + b"\n"
+    h = product(fq, k=31, min_count=0)
+    compare_all(h, run_oracle([fq], k=31, min_count=0))
+    # homopolymer: one node with a self-loop
+    fq = b"@r\n" + b"A" * 60 + b"\n+\n" + b"I" * 60 + b"\n"
+    h = product(fq, k=31, min_count=0)
+    compare_all(h, run_oracle([fq], k=31, min_count=0))
+    # ragged read lengths
+    rng = np.random.default_rng(5)
+    g = synth.random_genome(5000, 55)
+    recs = []
+    for i in range(600):
+        L = int(rng.integers(20, 260)); s = int(rng.integers(0, 5000 - L))
+        seq = synth.codes_to_str(g[s:s + L])
+        recs.append(f"@q{i}\n{seq}\n+\n{'I' * L}\n")
+    fq = "".join(recs).encode()
+    compare_all(product(fq, k=31, min_count=1), run_oracle([fq], k=31, min_count=1))
+
+
+def test_count_saturating_histogram_bin():
+    """A k-mer seen more than 500 times lands in the last bin (SPEC S5)."""
+    s = synth.codes_to_str(synth.random_genome(60, 66))
+    fq = (f"@r\n{s}\n+\n{'I' * 60}\n" * 700).encode()
+    h = product(fq, k=31, min_count=5)
+    o = run_oracle([fq], k=31, min_count=5)
+    compare_all(h, o)
+    assert h.histo()[499] == 30
+
+
+def test_device_packed_entry_matches_host_entry():
+    import torch
+    from sparrowhawk_amd import pack_fastq
+    g, fq = make_dataset(20000, 30, err=0.005, seed=35)
+    a = product(fq, k=31, min_count=2)
+    bases, seg, nb, nr = pack_fastq(fq, 31, 20)
+    d_bases = torch.from_numpy(bases.view(np.int32)).cuda()
+    d_seg = torch.from_numpy(seg.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    h = AssemblyHelper.new(31, True, 2, 20, 0, False, False, False, False)
+    h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr)
+    h.assemble()
+    assert a.get_assembly() == h.get_assembly()
+    assert a.get_preprocessing_info() == h.get_preprocessing_info()

@@ -1,0 +1,135 @@
+"""CPU tests of the product's host side: the C ABI loads and exports every declared symbol,
+the packer, the shared k-mer arithmetic, ntHash, the spectrum fit — no compute calls that
+need a GPU."""
+import ctypes as C
+import gzip
+import os
+import re
+
+import numpy as np
+import pytest
+
+import sparrowhawk_amd
+from oracle import oracle_fit
+from sparrowhawk_amd import _lib, pack_fastq, ShkError
+from util import canonical_int, int_to_words, kmer_int, make_dataset, py_nthash, revcomp
+import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "shk.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(shk_[a-z_0-9]+)\s*\(", hdr)) - {"shk_progress_cb"}
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/shk.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "python binding and header disagree"
+
+
+def test_version(lib):
+    assert b"gfx950" in lib.shk_version()
+
+
+def test_new_rejects_bad_parameters(lib):
+    for k in (30, 13, 65, 255):
+        assert not lib.shk_new(k, 1, 5, 20, 0, 0, 0, 0, 0)
+        assert lib.shk_new_error() == -1
+    assert not lib.shk_new(31, 1, 1, 20, 0, 1, 0, 0, 0)       # Bloom needs min_count >= 3
+    assert lib.shk_new_error() == -1
+    assert not lib.shk_new(31, 1, 5, 200, 0, 0, 0, 0, 0)
+    assert lib.shk_new_error() == -1
+
+
+def unpack(bases, seg, i):
+    s, e = int(seg[i]), int(seg[i + 1])
+    return "".join("ACGT"[(int(bases[p >> 4]) >> (2 * (p & 15))) & 3] for p in range(s, e))
+
+
+def test_packer_segments_and_masking():
+    c = cases.qual_mask_case()
+    bases, seg, nb, nr = pack_fastq(c["fastq"], c["k"], 20)
+    M, cut = c["M"], c["cut"]
+    assert nr == 2 and len(seg) == 5
+    got = [unpack(bases, seg, i) for i in range(4)]
+    assert got == [M[:cut], M[cut + 1:], M[:cut], M[cut + 1:]]
+    assert nb == 2 * (len(M) - 1)
+    # min_qual 0: one segment per read
+    bases, seg, nb, nr = pack_fastq(c["fastq"], c["k"], 0)
+    assert len(seg) == 3 and unpack(bases, seg, 1) == M
+    # segments shorter than k vanish; N splits
+    fq = b"@a\nACGTNACGTACGTACGTACGTACGT\n+\n" + b"I" * 25 + b"\n"
+    bases, seg, nb, nr = pack_fastq(fq, 15, 0)
+    assert len(seg) == 2 and unpack(bases, seg, 0) == "ACGTACGTACGTACGTACGT"
+    # lower case accepted
+    bases, seg, nb, nr = pack_fastq(b"@a\nacgtacgtacgtacgtacgt\n+\n" + b"I" * 20 + b"\n", 15, 0)
+    assert unpack(bases, seg, 0) == "ACGTACGTACGTACGTACGT"
+
+
+def test_packer_gzip_crlf_and_errors():
+    g, fq = make_dataset(2000, 10, seed=2)
+    a = pack_fastq(fq, 31, 20)
+    b = pack_fastq(gzip.compress(fq[:len(fq) // 2]) + gzip.compress(fq[len(fq) // 2:]), 31, 20)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    c = pack_fastq(fq.replace(b"\n", b"\r\n") + b"\n\n", 31, 20)
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    for bad in (b"@r\nACGT\n+\nIII\n", b"r\nACGT\n+\nIIII\n", b"@r\nACGT\n+\n", b"\x1f\x8bgarbage"):
+        with pytest.raises(ShkError) as e:
+            pack_fastq(bad, 31, 20)
+        assert e.value.code == -3
+    assert pack_fastq(b"", 31, 20)[2] == 0
+
+
+@pytest.mark.parametrize("k", [15, 31, 33, 51, 63, 89, 127])
+def test_host_canonical_matches_python(lib, k):
+    rng = np.random.default_rng(k)
+    W = (2 * k + 63) // 64
+    for _ in range(50):
+        s = "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+        w = np.zeros(W, dtype=np.uint64)
+        o = C.c_int(-1)
+        assert lib.shk_host_canonical(s.encode(), k, w.ctypes.data, C.byref(o)) == 0
+        assert tuple(int(x) for x in w) == int_to_words(canonical_int(s), W)
+        assert o.value == (0 if kmer_int(s) <= kmer_int(revcomp(s)) else 1)
+
+
+@pytest.mark.parametrize("k", [15, 31, 51, 63])
+def test_host_nthash_matches_definition(lib, k):
+    rng = np.random.default_rng(100 + k)
+    for _ in range(50):
+        s = "".join("ACGT"[i] for i in rng.integers(0, 4, k))
+        assert lib.shk_host_nthash(s.encode(), k) == py_nthash(s)
+        assert lib.shk_host_nthash(revcomp(s).encode(), k) == py_nthash(s)     # strand-symmetric
+
+
+def test_host_fit_equals_oracle_fit(lib):
+    rng = np.random.default_rng(7)
+    from math import exp, lgamma, log
+    for trial in range(40):
+        lam = rng.uniform(3, 120)
+        a, b = rng.uniform(1e3, 1e6), rng.uniform(1e3, 1e6)
+        h = np.zeros(500, dtype=np.uint64)
+        for c in range(1, 501):
+            h[c - 1] = int(a * exp(-1.0 - lgamma(c + 1))) + int(b * exp(c * log(lam) - lam - lgamma(c + 1)))
+        h += rng.integers(0, 5, 500).astype(np.uint64)
+        out = C.c_uint32(0)
+        ok = lib.shk_host_fit(h.ctypes.data, C.byref(out))
+        ok_o, v_o = oracle_fit(h)
+        assert bool(ok) == ok_o
+        if ok:
+            assert out.value == v_o
+    z = np.zeros(500, dtype=np.uint64)
+    out = C.c_uint32(0)
+    assert lib.shk_host_fit(z.ctypes.data, C.byref(out)) == 0
+
+
+def test_product_does_not_touch_the_oracle():
+    """The product path must never import, load or link anything under oracle/."""
+    pkg = os.path.join(ROOT, "sparrowhawk_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "shk_oracle" not in txt and "shko_" not in txt and "import oracle" not in txt \
+                    and "from oracle" not in txt, f"{f} references the oracle"
