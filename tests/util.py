@@ -80,7 +80,7 @@ def py_nthash(s):
 def sorted_table(keys, cnt):
     """Sort rows of (keys[n,W], cnt[n]) by key, most significant word first."""
     if len(cnt) == 0:
-        return keys, cnt
+        return keys, cnt, np.zeros(0, dtype=np.int64)
     W = keys.shape[1]
     order = np.lexsort([keys[:, j] for j in range(W)])      # last key = most significant
     return keys[order], cnt[order], order
