@@ -104,7 +104,9 @@ static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
     h->post_mode("loop:end");
     if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
-    rc = h->pipe->histogram(h->histo, err);
+    // the fit never returns less than 1 and falls back to min_count (SPEC S6)
+    const uint32_t emit_thr = h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
+    rc = h->pipe->histogram(h->histo, emit_thr, err);
     if (rc) return fail(h, SHK_E_DEVICE, err);
     h->used_min_count = h->min_count; h->fit_ok = false;
     if (h->do_fit) {

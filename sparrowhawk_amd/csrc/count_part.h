@@ -1,0 +1,472 @@
+// count_part.h — minimiser-partitioned k-mer counting (the production counting path).
+//
+// Why: counting straight into one HBM hash table costs one scattered atomic per k-mer instance
+// (~400 M at 100x coverage of a 5 Mbp isolate) and runs at the chip's scattered-atomic rate
+// (measured 38 ms, profiles/r01_baseline_global_atomics).  Here identical k-mers are brought
+// together first, so that counting happens in the 160 KB LDS of one CU:
+//
+//   pass 1  k_partition         reads -> super-k-mer records, scattered by minimiser partition
+//   pass 2  k_count_partitions  one workgroup per partition: LDS hash table -> histogram +
+//                               (k-mer, count) rows with count > T
+//
+// Minimiser = the m-mer (m = k - WBLK + 1) of a k-mer with the smallest canonical ntHash
+// (SPEC S3); partition = low bits of that hash.  Both strands of a k-mer share it, so every
+// instance of a canonical k-mer lands in one partition.  A record is a run of consecutive
+// k-mers of one read segment with the same partition: (n + k - 1) bases, 2-bit, little-endian,
+// in RW = 2W 64-bit words, n-1 in the top 6 bits.  Results never depend on the partitioning.
+//
+// No global atomics in pass 1: workgroup g owns slice [p][g] of every partition buffer and keeps
+// its 4096 write cursors in LDS; the layout is a deterministic function of the input.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kmer.h"
+
+namespace shk {
+
+static constexpr int PART_THREADS = 512;
+static constexpr int PART_MAX_P = 4096;
+static constexpr int STAGE_WORDS = 8192;             // 131072 bases of a read tile in LDS
+static constexpr int DESC_CAP = 16384;
+static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
+
+struct PartParams {
+    uint32_t P, G, slice_cap;
+    int k, m;
+    uint32_t max_n;
+};
+
+template <int RW> struct Rec { uint64_t w[RW]; };
+
+// 4-way select kept as compare/select on scalars (an indexable array would go to scratch)
+__device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3) {
+    uint64_t lo = (b & 1) ? t1 : t0;
+    uint64_t hi = (b & 1) ? t3 : t2;
+    return (b & 2) ? hi : lo;
+}
+
+// ---- pass 1 -------------------------------------------------------------------------------
+struct PartShared {
+    uint32_t stage[STAGE_WORDS + 16];
+    uint32_t desc_a[DESC_CAP];        // tile-relative base offset (17 bits) | (n-1) << 17
+    uint16_t desc_p[DESC_CAP];
+    uint32_t cursor[PART_MAX_P];
+    uint32_t desc_count;
+    uint32_t max_len;
+};
+
+// build one record from the staged tile and store it
+template <int RW>
+__device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t off, uint32_t n, int k,
+                                                  uint64_t *__restrict__ dst) {
+    const uint32_t bit0 = 2u * off;
+    const uint32_t wi = bit0 >> 5, s = bit0 & 31u;
+    const uint32_t nbits = 2u * (n + (uint32_t)k - 1u);
+    uint64_t out[RW];
+#pragma unroll
+    for (int o = 0; o < RW; o++) {
+        const uint32_t a = sh.stage[wi + 2 * o], b = sh.stage[wi + 2 * o + 1], c = sh.stage[wi + 2 * o + 2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(b, a, s);
+        const uint32_t hi = __builtin_amdgcn_alignbit(c, b, s);
+        uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+        const int rem = (int)nbits - 64 * o;            // bits of this word that belong to the run
+        if (rem <= 0) v = 0;
+        else if (rem < 64) v &= (1ull << rem) - 1ull;
+        out[o] = v;
+    }
+    out[RW - 1] |= (uint64_t)(n - 1u) << 58;
+#pragma unroll
+    for (int o = 0; o < RW; o += 2) {
+        ulonglong2 v2; v2.x = out[o]; v2.y = out[o + 1];
+        *reinterpret_cast<ulonglong2 *>(dst + o) = v2;
+    }
+}
+
+template <int RW>
+__device__ __noinline__ void part_flush(PartShared &sh, const PartParams &pp, uint32_t g,
+                                        uint64_t *__restrict__ recs) {
+    __syncthreads();
+    const uint32_t n = sh.desc_count;
+    for (uint32_t d = threadIdx.x; d < n; d += PART_THREADS) {
+        const uint32_t a = sh.desc_a[d];
+        const uint32_t p = sh.desc_p[d];
+        const uint32_t idx = atomicAdd(&sh.cursor[p], 1u);          // LDS cursor of slice [p][g]
+        if (idx < pp.slice_cap) {
+            uint64_t *dst = recs + (((uint64_t)p * pp.G + g) * pp.slice_cap + idx) * RW;
+            part_write_record<RW>(sh, a & 0x1FFFFu, (a >> 17) + 1u, pp.k, dst);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) sh.desc_count = 0;
+    __syncthreads();
+}
+
+// W: key words (records have RW = 2W words); WBLK: k-mers per minimiser window block (= w)
+template <int W, int WBLK>
+__global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__restrict__ bases,
+                                                            const uint32_t *__restrict__ seg_off,
+                                                            uint32_t n_seg, PartParams pp,
+                                                            uint64_t *__restrict__ recs,
+                                                            uint32_t *__restrict__ fill,
+                                                            uint32_t *__restrict__ flags) {
+    constexpr int RW = 2 * W;
+    __shared__ PartShared sh;
+    const uint32_t g = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = pp.k, m = pp.m;
+    const uint32_t pmask = pp.P - 1u;
+    // cursors continue where an earlier batch left this workgroup's slices
+    for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) sh.cursor[p] = fill[(uint64_t)p * pp.G + g];
+    if (threadIdx.x == 0) sh.desc_count = 0;
+    // pre-rotated ntHash seeds for the m-mer window (SPEC S3)
+    const uint64_t so0 = rol64(SHK_NT_A, (unsigned)m), so1 = rol64(SHK_NT_C, (unsigned)m),
+                   so2 = rol64(SHK_NT_G, (unsigned)m), so3 = rol64(SHK_NT_T, (unsigned)m);
+    const uint64_t ro0 = ror64(SHK_NT_T, 1), ro1 = ror64(SHK_NT_G, 1), ro2 = ror64(SHK_NT_C, 1),
+                   ro3 = ror64(SHK_NT_A, 1);
+    const uint64_t ri0 = rol64(SHK_NT_T, (unsigned)(m - 1)), ri1 = rol64(SHK_NT_G, (unsigned)(m - 1)),
+                   ri2 = rol64(SHK_NT_C, (unsigned)(m - 1)), ri3 = rol64(SHK_NT_A, (unsigned)(m - 1));
+    __syncthreads();
+
+    for (uint32_t st = g * PART_THREADS; st < n_seg; st += gridDim.x * PART_THREADS) {
+        const uint32_t st_end = min(st + (uint32_t)PART_THREADS, n_seg);
+        uint32_t first = st;
+        while (first < st_end) {
+            // largest tile of segments [first, first+cnt) whose packed words fit the LDS stage
+            uint32_t cnt = st_end - first;
+            const uint32_t w0 = seg_off[first] >> 4;
+            while (cnt > 1 && ((seg_off[first + cnt] + 15u) >> 4) - w0 > (uint32_t)STAGE_WORDS) cnt >>= 1;
+            const uint32_t nwords = ((seg_off[first + cnt] + 15u) >> 4) - w0;
+            if (nwords > (uint32_t)STAGE_WORDS) {            // a single segment longer than the stage
+                if (threadIdx.x == 0) flags[1] = 1;
+                first += cnt;
+                continue;
+            }
+            // coalesced load of the tile's words into LDS (one dword per lane per pass)
+            for (uint32_t i = threadIdx.x; i < nwords + 8; i += PART_THREADS)
+                sh.stage[i] = (i < nwords + 1) ? bases[w0 + i] : 0u;     // +1: the spare word
+            if (threadIdx.x == 0) sh.max_len = 0;
+            __syncthreads();
+            uint32_t L = 0, rel = 0;
+            if (threadIdx.x < cnt) {
+                const uint32_t s0 = seg_off[first + threadIdx.x], s1 = seg_off[first + threadIdx.x + 1];
+                L = s1 - s0; rel = s0 - (w0 << 4);
+            }
+            atomicMax(&sh.max_len, L);
+            __syncthreads();
+            const uint32_t maxL = sh.max_len;
+
+            // ---- per-lane walk; every lane runs the same (block, t) schedule -------------------
+            NtState nt{0, 0};
+            uint32_t lead = 0, trail = 0;
+            // prologue: bases 0 .. m-2
+            for (int j = 0; j < m - 1; j++) {
+                if ((uint32_t)j < L) {
+                    const uint32_t pos = rel + (uint32_t)j;
+                    if (j == 0 || (pos & 15u) == 0) lead = sh.stage[pos >> 4];
+                    nt_init_step(nt, (lead >> (2 * (pos & 15u))) & 3u, (unsigned)j);
+                }
+            }
+            uint32_t hreg[WBLK], sreg[WBLK];
+#pragma unroll
+            for (int t = 0; t < WBLK; t++) { hreg[t] = 0xFFFFFFFFu; sreg[t] = 0xFFFFFFFFu; }
+            uint32_t run_start = 0, run_len = 0, run_p = 0;
+            const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
+            const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
+            for (uint32_t bq = 0; bq < n_blocks; bq++) {
+                // keep room for this block's descriptors (uniform decision)
+                // (the OR over all threads sees the count after every wave finished the previous block)
+                if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (WBLK + 1))))
+                    part_flush<RW>(sh, pp, g, recs);
+                uint32_t pm = 0xFFFFFFFFu;
+#pragma unroll
+                for (int t = 0; t < WBLK; t++) {
+                    const uint32_t j = bq * WBLK + (uint32_t)t + (uint32_t)m - 1u;     // base completing m-mer q
+                    uint32_t h = 0xFFFFFFFFu;
+                    const bool have = j < L;
+                    if (have) {
+                        const uint32_t pos = rel + j;
+                        if (j == 0 || (pos & 15u) == 0) lead = sh.stage[pos >> 4];
+                        const uint32_t b = (lead >> (2 * (pos & 15u))) & 3u;
+                        if (j >= (uint32_t)m) {
+                            const uint32_t tpos = pos - (uint32_t)m;
+                            if (j == (uint32_t)m || (tpos & 15u) == 0) trail = sh.stage[tpos >> 4];
+                            const uint32_t out = (trail >> (2 * (tpos & 15u))) & 3u;
+                            nt.fh = rol64(nt.fh, 1) ^ sel4(out, so0, so1, so2, so3) ^ nt_seed(b);
+                            nt.rh = ror64(nt.rh, 1) ^ sel4(out, ro0, ro1, ro2, ro3) ^ sel4(b, ri0, ri1, ri2, ri3);
+                        } else {
+                            nt_init_step(nt, b, (unsigned)j);
+                        }
+                        h = (uint32_t)(nt_canonical(nt) >> 32);
+                    }
+                    hreg[t] = h;
+                    pm = min(pm, h);
+                    // k-mer i = q - w + 1 completes here; its window is suffix(prev block, t+1) + prefix(this block, t)
+                    const uint32_t kmin = (t < WBLK - 1) ? min(sreg[(t + 1) % WBLK], pm) : pm;
+                    const bool valid = have && (bq > 0 || t == WBLK - 1);
+                    const uint32_t i = j - (uint32_t)k + 1u;
+                    const uint32_t p = kmin & pmask;
+                    const bool cut = valid && run_len > 0 && (p != run_p || run_len >= pp.max_n);
+                    const unsigned long long em = __ballot(cut);
+                    if (em) {
+                        uint32_t base = 0;
+                        const int leader = __ffsll((long long)em) - 1;
+                        if (lane == leader) base = atomicAdd(&sh.desc_count, (uint32_t)__popcll(em));
+                        base = __shfl(base, leader);
+                        if (cut) {
+                            const uint32_t d = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                            sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
+                            sh.desc_p[d] = (uint16_t)run_p;
+                            run_len = 0;
+                        }
+                    }
+                    if (valid) {
+                        if (run_len == 0) { run_start = i; run_p = p; }
+                        run_len++;
+                    }
+                }
+                // suffix minima of this block for the next one
+                sreg[WBLK - 1] = hreg[WBLK - 1];
+#pragma unroll
+                for (int t = WBLK - 2; t >= 0; t--) sreg[t] = min(hreg[t], sreg[t + 1]);
+            }
+            // close the last run of every segment
+            {
+                const bool cut = run_len > 0;
+                const unsigned long long em = __ballot(cut);
+                if (em) {
+                    uint32_t base = 0;
+                    const int leader = __ffsll((long long)em) - 1;
+                    if (lane == leader) base = atomicAdd(&sh.desc_count, (uint32_t)__popcll(em));
+                    base = __shfl(base, leader);
+                    if (cut) {
+                        const uint32_t d = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                        sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
+                        sh.desc_p[d] = (uint16_t)run_p;
+                    }
+                }
+            }
+            part_flush<RW>(sh, pp, g, recs);          // the stage is about to be replaced
+            first += cnt;
+        }
+    }
+    // publish this workgroup's slice fills (may exceed slice_cap: the host then retries bigger)
+    for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) fill[(uint64_t)p * pp.G + g] = sh.cursor[p];
+}
+
+// ---- pass 2 -------------------------------------------------------------------------------
+template <int W> struct CountShared;
+template <> struct CountShared<1> {
+    static constexpr uint32_t S = 12288;                // 12 B / slot -> 144 KB
+    uint64_t key0[S];
+    uint32_t cnt[S];
+};
+template <> struct CountShared<2> {
+    static constexpr uint32_t S = 6144;                 // 24 B / slot -> 144 KB
+    uint64_t key0[S];
+    uint64_t key1[S];
+    uint32_t cnt[S];
+    uint32_t state[S];                                  // 0 empty, 1 being written, 2 ready
+};
+
+struct CountCtl {
+    uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
+    uint32_t histo[500];
+    uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor;
+    uint32_t stack_res[32], stack_mod[32];
+    unsigned long long n_inst;
+};
+
+__device__ __forceinline__ uint32_t mix32(uint64_t x) {
+    uint32_t h = (uint32_t)x ^ ((uint32_t)(x >> 32) * 0x9E3779B1u);
+    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+    return h;
+}
+template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) {
+    uint32_t h = mix32(x.w[0]);
+#pragma unroll
+    for (int j = 1; j < W; j++) h = mix32(x.w[j] ^ ((uint64_t)h << 17));
+    return h;
+}
+
+// insert into the LDS table; returns false when the probe sequence is exhausted
+template <int W>
+__device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h) {
+    constexpr uint32_t S = CountShared<W>::S;
+    uint32_t slot = (uint32_t)(((uint64_t)h * S) >> 32);
+    if constexpr (W == 1) {
+        for (uint32_t probes = 0; probes < S; probes++) {
+            unsigned long long cur = tb.key0[slot];
+            if (cur == ~0ull) {
+                cur = atomicCAS((unsigned long long *)&tb.key0[slot], ~0ull, (unsigned long long)key.w[0]);
+                if (cur == ~0ull) { atomicAdd(&ctl.n_used, 1u); cur = key.w[0]; }
+            }
+            if (cur == key.w[0]) { atomicAdd(&tb.cnt[slot], 1u); return true; }
+            slot = slot + 1 == S ? 0 : slot + 1;
+        }
+        return false;
+    } else {
+        uint32_t probes = 0;
+        for (;;) {
+            uint32_t st = __hip_atomic_load(&tb.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bool won = false;
+            if (st == 0) { st = atomicCAS(&tb.state[slot], 0u, 1u); won = (st == 0); }
+            if (won) {
+                tb.key0[slot] = key.w[0]; tb.key1[slot] = key.w[1];
+                __hip_atomic_store(&tb.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                atomicAdd(&ctl.n_used, 1u);
+                atomicAdd(&tb.cnt[slot], 1u);
+                return true;
+            }
+            if (st == 1) continue;                          // owner is mid-write
+            if (tb.key0[slot] == key.w[0] && tb.key1[slot] == key.w[1]) { atomicAdd(&tb.cnt[slot], 1u); return true; }
+            slot = slot + 1 == S ? 0 : slot + 1;
+            if (++probes >= S) return false;
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
+    const uint64_t *__restrict__ recs, const uint32_t *__restrict__ fill, PartParams pp, uint32_t threshold,
+    unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
+    unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags) {
+    constexpr int RW = 2 * W;
+    constexpr uint32_t S = CountShared<W>::S;
+    __shared__ CountShared<W> tb;
+    __shared__ CountCtl ctl;
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = pp.k;
+    // exclusive prefix of the slice fills of this partition
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < pp.G; g0 += 64) {
+            const uint32_t g = g0 + threadIdx.x;
+            uint32_t f = g < pp.G ? min(fill[(uint64_t)p * pp.G + g], pp.slice_cap) : 0u;
+            uint32_t incl = f;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (g < pp.G) ctl.pre[g] = run + incl - f;
+            run += __shfl(incl, 63);
+        }
+        if (threadIdx.x == 0) {
+            ctl.pre[pp.G] = run; ctl.sp = 1; ctl.stack_res[0] = 0; ctl.stack_mod[0] = 1; ctl.n_inst = 0;
+        }
+    }
+    __syncthreads();
+    const uint32_t R = ctl.pre[pp.G];
+    const uint64_t *prec = recs + (uint64_t)p * pp.G * pp.slice_cap * RW;
+
+    while (true) {
+        __syncthreads();
+        if (ctl.sp == 0) break;
+        const uint32_t res = ctl.stack_res[ctl.sp - 1], mod = ctl.stack_mod[ctl.sp - 1];
+        __syncthreads();
+        if (threadIdx.x == 0) { ctl.sp--; ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; }
+        for (uint32_t s = threadIdx.x; s < S; s += PART_THREADS) {
+            tb.cnt[s] = 0;
+            if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
+        }
+        for (uint32_t b = threadIdx.x; b < 500; b += PART_THREADS) ctl.histo[b] = 0;
+        __syncthreads();
+
+        unsigned long long mine = 0;
+        for (uint32_t r0 = 0; r0 < R; r0 += PART_THREADS) {
+            const uint32_t r = r0 + threadIdx.x;
+            uint32_t n = 0;
+            Rec<RW> rec;
+            if (r < R) {
+                // slice g with pre[g] <= r < pre[g+1]
+                uint32_t lo = 0, hi = pp.G;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
+                const uint64_t *src = prec + ((uint64_t)lo * pp.slice_cap + (r - ctl.pre[lo])) * RW;
+#pragma unroll
+                for (int o = 0; o < RW; o += 2) {
+                    const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
+                    rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
+                }
+                n = (uint32_t)(rec.w[RW - 1] >> 58) + 1u;
+            }
+            const uint32_t steps = n ? n + (uint32_t)k - 1u : 0u;
+            Kmer<W> f = km_zero<W>(), rv = km_zero<W>();
+            for (uint32_t i = 0; i < steps; i++) {
+                const uint32_t b = (uint32_t)rec.w[0] & 3u;
+#pragma unroll
+                for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
+                rec.w[RW - 1] >>= 2;
+                km_push_back<W>(f, b, k);
+                km_push_front<W>(rv, 3u - b, k);
+                if (i + 1 >= (uint32_t)k) {
+                    const bool use_r = km_less<W>(rv, f);
+                    Kmer<W> c;
+#pragma unroll
+                    for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
+                    const uint32_t h = km_mix32<W>(c);
+                    if (mod == 1 || ((h >> 7) & (mod - 1u)) == res) {      // sub-round filter: bits 7.. of h
+                        if (!lds_insert<W>(tb, ctl, c, h * 0x9E3779B1u + (h >> 19))) ctl.overflow = 1;
+                        mine++;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
+        if (over) {
+            // split this residue class in two and redo it (results of other classes are unaffected)
+            if (mod >= 4096 || ctl.sp + 2 > 32) { if (threadIdx.x == 0) flags[0] = 1; break; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                ctl.stack_res[ctl.sp] = res; ctl.stack_mod[ctl.sp] = mod * 2;
+                ctl.stack_res[ctl.sp + 1] = res + mod; ctl.stack_mod[ctl.sp + 1] = mod * 2;
+                ctl.sp += 2;
+            }
+            continue;
+        }
+        // ---- scan 1: histogram + number of rows to emit
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+        if (lane == 0 && mine) atomicAdd(&ctl.n_inst, mine);
+        uint32_t my_emit = 0;
+        for (uint32_t s = threadIdx.x; s < S; s += PART_THREADS) {
+            const uint32_t c = tb.cnt[s];
+            if (c) {
+                atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
+                if (c > threshold) my_emit++;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) my_emit += __shfl_down(my_emit, o);
+        if (lane == 0 && my_emit) atomicAdd(&ctl.n_emit, my_emit);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long base = ctl.n_emit ? atomicAdd(out_cursor, (unsigned long long)ctl.n_emit) : 0ull;
+            ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
+        }
+        for (uint32_t b = threadIdx.x; b < 500; b += PART_THREADS)
+            if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
+        __syncthreads();
+        // ---- scan 2: write rows (wave-aggregated reservation inside the workgroup's range)
+        const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
+        const uint32_t s_round = (S + PART_THREADS - 1) / PART_THREADS * PART_THREADS;
+        for (uint32_t s = threadIdx.x; s < s_round; s += PART_THREADS) {
+            const uint32_t c = s < S ? tb.cnt[s] : 0u;
+            const bool e = c > threshold && c != 0;
+            const unsigned long long em = __ballot(e);
+            if (!em) continue;
+            uint32_t wb = 0;
+            if (lane == 0) wb = atomicAdd(&ctl.wave_cursor, (uint32_t)__popcll(em));
+            wb = __shfl(wb, 0);
+            if (e) {
+                const unsigned long long o = gbase + wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                if (o < out_cap) {
+                    Kmer<W> x; x.w[0] = tb.key0[s];
+                    if constexpr (W == 2) x.w[1] = tb.key1[s];
+                    out_keys.store(o, x);
+                    out_cnt[o] = c;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
+}
+
+}  // namespace shk

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <chrono>
@@ -65,6 +66,10 @@ struct GraphTable {                            // entry = fingerprint<<32 | node
     uint64_t *e;
     uint64_t mask;
 };
+
+}  // namespace shk
+#include "count_part.h"
+namespace shk {
 
 // ------------------------------------------------------------------------------------------
 // count table insert (global memory; every concurrent access is an agent-scope atomic)
@@ -129,13 +134,6 @@ template <int W> __device__ __forceinline__ bool ct_occupied(const CountTable<W>
 // ------------------------------------------------------------------------------------------
 // a4/a5: one lane per segment; both strands and the ntHash pair roll base by base
 // ------------------------------------------------------------------------------------------
-// 4-way select kept as compare/select on scalars (an indexable array would go to scratch)
-__device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, uint64_t t2, uint64_t t3) {
-    uint64_t lo = (b & 1) ? t1 : t0;
-    uint64_t hi = (b & 1) ? t3 : t2;
-    return (b & 2) ? hi : lo;
-}
-
 template <int W>
 __global__ __launch_bounds__(256) void k_count_segments(const uint32_t *__restrict__ bases,
                                                         const uint32_t *__restrict__ seg_off,
@@ -213,7 +211,11 @@ __global__ __launch_bounds__(256) void k_compact(CountTable<W> tab, uint64_t n_s
                                                  uint32_t threshold, KeyArr<W> out_keys,
                                                  uint32_t *__restrict__ out_cnt,
                                                  unsigned long long *__restrict__ cursor) {
-    const int lane = threadIdx.x & 63;
+    // one global atomic per block-step (a returning atomic on one address sustains only ~88 / us:
+    // one per wave made this kernel 23 ms, profiles/r01_baseline_global_atomics)
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long blk_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t n_round = (n_slots + stride - 1) / stride * stride;
     for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n_round; s += stride) {
@@ -224,15 +226,20 @@ __global__ __launch_bounds__(256) void k_compact(CountTable<W> tab, uint64_t n_s
             p = c > threshold;
         }
         const unsigned long long m = __ballot(p);
-        if (m == 0) continue;
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0);
+        if (lane == 0) wave_tot[wid] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
         if (p) {
-            const uint64_t o = base + __popcll(m & ((1ull << lane) - 1ull));
+            uint64_t o = blk_base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; w++) o += wave_tot[w];
             out_keys.store(o, tab.keys.load(s));
             out_cnt[o] = c;
         }
+        __syncthreads();
     }
 }
 
@@ -690,12 +697,57 @@ __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restr
     }
 }
 
+// compaction of (key, count) rows by count > threshold (used when the fitted threshold is above
+// the one the counting pass emitted with)
+template <int W>
+__global__ __launch_bounds__(256) void k_compact_rows(KeyArr<W> in_keys, const uint32_t *__restrict__ in_cnt,
+                                                      uint64_t n, uint32_t threshold, KeyArr<W> out_keys,
+                                                      uint32_t *__restrict__ out_cnt,
+                                                      unsigned long long *__restrict__ cursor) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ unsigned long long blk_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t n_round = (n + stride - 1) / stride * stride;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        uint32_t c = i < n ? in_cnt[i] : 0u;
+        const bool p = c > threshold;
+        const unsigned long long m = __ballot(p);
+        if (lane == 0) wave_tot[wid] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;    // one atomic per block-step
+        }
+        __syncthreads();
+        if (p) {
+            uint64_t o = blk_base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; w++) o += wave_tot[w];
+            out_keys.store(o, in_keys.load(i));
+            out_cnt[o] = c;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_max_u32(const uint32_t *__restrict__ a, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        m = max(m, a[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
     int alloc(size_t count, std::string &err) {
         release();
@@ -727,6 +779,11 @@ struct EvTimer {
     }
     ~EvTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
 };
+
+static inline uint64_t env_u64(const char *name, uint64_t dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
+}
 
 template <int W> class Pipeline : public IPipeline {
 public:
@@ -761,8 +818,8 @@ public:
         return t;
     }
 
-    int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
-                    uint64_t n_bases, std::string &err) override {
+    int count_batch_global(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                           uint64_t n_bases, std::string &err) {
         if (n_seg >= 0xFFFFFFFFull || n_bases >= 0xFFFFFFFFull) { err = "batch too large (>= 2^32 bases)"; return -1; }
         if (n_seg == 0) return 0;
         // single batch per table in this version; size from the instance upper bound
@@ -798,7 +855,109 @@ public:
         }
     }
 
-    int histogram(uint64_t histo[500], std::string &err) override {
+    // ---- partitioned counting (count_part.h) ---------------------------------------------------
+    template <int WBLK>
+    void launch_partition(const uint32_t *d_bases, const uint32_t *d_seg_off, uint32_t n_seg) {
+        hipLaunchKernelGGL((k_partition<W, WBLK>), dim3(pp_.G), dim3(PART_THREADS), 0, stream_, d_bases, d_seg_off,
+                           n_seg, pp_, recs_.p, fill_.p, (uint32_t *)(ctl_.p + 8));
+    }
+
+    int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+                    std::string &err) override {
+        if (global_mode_) return count_batch_global(d_bases, d_seg_off, n_seg, n_bases, err);
+        if (n_seg >= 0xFFFFFFFFull || n_bases >= 0xFFFFFFFFull) { err = "batch too large (>= 2^32 bases)"; return -1; }
+        if (n_seg == 0) return 0;
+        if (have_parts_) { err = "one batch per handle in this version"; return -1; }
+        constexpr int RW = 2 * W;
+        const int wblk = k_ >= 23 ? 16 : 8;
+        const uint64_t inst_ub = n_bases - n_seg * (uint64_t)(k_ - 1);
+        int cus = 256;
+        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+        const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
+        pp_.k = k_; pp_.m = k_ - wblk + 1;
+        pp_.max_n = std::min<uint32_t>(32u * RW - 3u - (uint32_t)(k_ - 1), 63u);
+        pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
+        uint32_t P = 64;
+        const uint64_t per_part = env_u64("SHK_PART_INST", 400000);
+        while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
+        if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
+        pp_.P = P;
+        uint64_t cap = inst_ub / (4ull * P * pp_.G) + 32;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            pp_.slice_cap = (uint32_t)cap;
+            const uint64_t n_slices = (uint64_t)P * pp_.G;
+            if (int rc = recs_.alloc(n_slices * cap * RW, err)) return rc;
+            if (int rc = fill_.alloc(n_slices, err)) return rc;
+            HIPCHK(hipMemsetAsync(fill_.p, 0, n_slices * 4, stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            EvTimer t(stream_);
+            if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
+            else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
+            HIPCHK(hipGetLastError());
+            const double ms = t.stop();
+            hipLaunchKernelGGL(k_max_u32, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, n_slices,
+                               (uint32_t *)(ctl_.p + 9));
+            HIPCHK(hipGetLastError());
+            unsigned long long h[2];
+            HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            const uint32_t *fl = (const uint32_t *)&h[0];
+            if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
+            const uint32_t max_fill = (uint32_t)h[1];
+            if (max_fill <= cap) { times_.add("partition_kernel", ms); have_parts_ = true; return 0; }
+            times_.add("partition_retry", ms);
+            cap = (uint64_t)max_fill + 8;               // exact from the counting run
+        }
+        err = "partition slices overflowed twice";
+        return -6;
+    }
+
+    // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying
+    int run_count_partitions(uint32_t threshold, DevBuf<uint64_t> (&keys)[W], DevBuf<uint32_t> &cnt,
+                             uint64_t &n_rows, uint64_t hist_out[500], uint64_t &inst_out, uint64_t cap_hint,
+                             double &ms_out, std::string &err) {
+        DevBuf<unsigned long long> dh;
+        if (int rc = dh.alloc(500, err)) return rc;
+        uint64_t cap = cap_hint;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
+            if (int rc = cnt.alloc(cap, err)) return rc;
+            HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
+            EvTimer t(stream_);
+            hipLaunchKernelGGL(k_count_partitions<W>, dim3(pp_.P), dim3(PART_THREADS), 0, stream_, recs_.p, fill_.p,
+                               pp_, threshold, dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
+                               (uint32_t *)(ctl_.p + 2));
+            HIPCHK(hipGetLastError());
+            ms_out = t.stop();
+            unsigned long long h[3];
+            HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way splitting"; return -6; }
+            n_rows = h[0]; inst_out = h[1];
+            if (n_rows <= cap) return 0;
+            cap = n_rows;                                 // exact; run again
+        }
+        err = "row buffer overflowed twice";
+        return -6;
+    }
+
+    int histogram(uint64_t histo[500], uint32_t emit_threshold, std::string &err) override {
+        if (!global_mode_) {
+            memset(histo, 0, 500 * 8);
+            n_distinct_ = 0; n_emitted_ = 0; emit_threshold_ = emit_threshold;
+            if (have_parts_) {
+                const uint64_t inst_ub_rows = total_rows_hint();
+                double ms = 0; uint64_t inst = 0;
+                if (int rc = run_count_partitions(emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst, inst_ub_rows, ms, err)) return rc;
+                times_.add("count_kernel", ms);
+                total_instances_ = inst;
+            }
+            for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
+            return 0;
+        }
         DevBuf<unsigned long long> dh;
         if (int rc = dh.alloc(500, err)) return rc;
         HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
@@ -814,6 +973,13 @@ public:
         n_distinct_ = 0;
         for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
         return 0;
+    }
+
+    uint64_t total_rows_hint() const {
+        // rows = distinct k-mers above the emit threshold; unknown before the pass, retried if short
+        uint64_t slots = 0;
+        for (uint64_t i = 0; i < 1; i++) slots = (uint64_t)pp_.P * pp_.G * pp_.slice_cap;   // records >= rows / max_n
+        return std::max<uint64_t>(1u << 16, slots / 8);
     }
 
     int compact_into(uint32_t threshold, uint64_t expect, DevBuf<uint64_t> (&keys)[W], DevBuf<uint32_t> &cnt,
@@ -835,11 +1001,35 @@ public:
 
     int filter(uint32_t threshold, std::string &err) override {
         uint64_t expect = 0;
-        for (uint32_t c = 1; c <= 500; c++) if (c > threshold) expect += histo_[c - 1];
         if (threshold >= 500) { err = "threshold out of range"; return -1; }
+        for (uint32_t c = 1; c <= 500; c++) if (c > threshold) expect += histo_[c - 1];
         if (expect >= 0x7FFFFFFFull) { err = "too many solid k-mers for 32-bit node ids"; return -1; }
         EvTimer t(stream_);
-        if (int rc = compact_into(threshold, expect, skeys_, scnt_, err)) return rc;
+        if (global_mode_) {
+            if (int rc = compact_into(threshold, expect, skeys_, scnt_, err)) return rc;
+        } else if (threshold == emit_threshold_ || n_emitted_ == 0) {
+            if (n_emitted_ != expect && threshold == emit_threshold_) { err = "emitted row count disagrees with the histogram"; return -6; }
+            for (int j = 0; j < W; j++) skeys_[j].swap(ekeys_[j]);
+            scnt_.swap(ecnt_);
+            for (int j = 0; j < W; j++) ekeys_[j].release();
+            ecnt_.release();
+        } else {
+            if (threshold < emit_threshold_) { err = "filter threshold below the emit threshold"; return -6; }
+            for (int j = 0; j < W; j++) if (int rc = skeys_[j].alloc(expect, err)) return rc;
+            if (int rc = scnt_.alloc(expect, err)) return rc;
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            KeyArr<W> ik, ok;
+            for (int j = 0; j < W; j++) { ik.w[j] = ekeys_[j].p; ok.w[j] = skeys_[j].p; }
+            hipLaunchKernelGGL(k_compact_rows<W>, dim3(grid_for(n_emitted_)), dim3(256), 0, stream_, ik, ecnt_.p,
+                               n_emitted_, threshold, ok, scnt_.p, ctl_.p + 0);
+            HIPCHK(hipGetLastError());
+            unsigned long long got = 0;
+            HIPCHK(hipMemcpyAsync(&got, ctl_.p, 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            if (got != expect) { err = "row compaction count mismatch"; return -6; }
+            for (int j = 0; j < W; j++) ekeys_[j].release();
+            ecnt_.release();
+        }
         times_.add("filter_kernel", t.stop());
         n_solid_ = expect;
         graph_ready_ = false;
@@ -860,7 +1050,15 @@ public:
     int get_distinct(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) override {
         if (cap < n_distinct_) { err = "buffer too small"; return -1; }
         DevBuf<uint64_t> dk[W]; DevBuf<uint32_t> dc;
-        if (int rc = compact_into(0, n_distinct_, dk, dc, err)) return rc;
+        if (global_mode_) {
+            if (int rc = compact_into(0, n_distinct_, dk, dc, err)) return rc;
+        } else if (n_distinct_) {
+            // stage inspection: run the counting pass again keeping every row
+            if (!have_parts_ || !recs_.p) { err = "partition buffers already released"; return -2; }
+            uint64_t rows = 0, hist[500], inst = 0; double ms = 0;
+            if (int rc = run_count_partitions(0, dk, dc, rows, hist, inst, n_distinct_, ms, err)) return rc;
+            if (rows != n_distinct_) { err = "distinct row count mismatch"; return -6; }
+        }
         return copy_out(dk, dc, n_distinct_, keys, counts, err);
     }
     int get_solid(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) override {
@@ -882,6 +1080,7 @@ public:
         // count table is no longer needed once the solid set exists
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
+        recs_.release(); fill_.release();
         gt_slots_ = 1ull << 10;
         while (gt_slots_ < 2 * n + 16) gt_slots_ <<= 1;
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
@@ -1175,6 +1374,13 @@ private:
     std::vector<Batch> pending_;
     uint64_t total_instances_ = 0, n_distinct_ = 0, n_solid_ = 0;
     uint64_t histo_[500] = {0};
+    // partitioned counting
+    bool global_mode_ = env_u64("SHK_COUNT_MODE_GLOBAL", 0) != 0;
+    bool have_parts_ = false;
+    PartParams pp_{};
+    DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
+    DevBuf<uint64_t> ekeys_[W]; DevBuf<uint32_t> ecnt_;
+    uint64_t n_emitted_ = 0; uint32_t emit_threshold_ = 0;
     // solid set / graph
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
     DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0;

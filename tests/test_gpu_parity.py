@@ -259,3 +259,58 @@ def test_device_packed_entry_matches_host_entry():
     h.assemble()
     assert a.get_assembly() == h.get_assembly()
     assert a.get_preprocessing_info() == h.get_preprocessing_info()
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_counting_modes_agree():
+    """The partitioned LDS counting path and the single-HBM-table path give identical tables."""
+    g, fq = make_dataset(30000, 40, err=0.01, seed=91)
+    for k in (31, 51):
+        a = product(fq, k=k, min_count=0, assemble=False)
+        b = _with_env({"SHK_COUNT_MODE_GLOBAL": 1}, lambda: product(fq, k=k, min_count=0, assemble=False))
+        ak, ac, _ = sorted_table(*a.distinct())
+        bk, bc, _ = sorted_table(*b.distinct())
+        assert np.array_equal(ak, bk) and np.array_equal(ac, bc)
+        assert np.array_equal(a.histo(), b.histo()) and a.total_instances == b.total_instances
+
+
+@pytest.mark.parametrize("k", [31, 51])
+def test_partition_subrounds_when_lds_table_overflows(k):
+    """Few partitions + many distinct k-mers: each partition exceeds the LDS table and is split
+    into residue classes (count_part.h); results must not change."""
+    g, fq = make_dataset(150000, 12, err=0.02, seed=92)
+    h = _with_env({"SHK_PART_P": 64}, lambda: product(fq, k=k, min_count=0, min_qual=0, assemble=False))
+    o = run_oracle([fq], k=k, min_count=0, min_qual=0)
+    hk, hc, _ = sorted_table(*h.distinct())
+    ok_, oc_ = o.distinct()
+    assert len(oc_) > 64 * 12288                       # really more than the tables hold
+    assert np.array_equal(hk, ok_) and np.array_equal(hc, oc_)
+    assert np.array_equal(h.histo(), o.histo()) and h.total_instances == o.total_instances
+
+
+def test_partition_slice_overflow_retry():
+    """Reads exactly k long give one record per k-mer: the first sizing guess overflows and the
+    pass is rerun with exact slice sizes."""
+    rng = np.random.default_rng(93)
+    g = synth.random_genome(4000, 93)
+    n = 300000
+    starts = rng.integers(0, 4000 - 31, n)
+    seqs = ["".join("ACGT"[c] for c in g[s:s + 31]) for s in starts[:2000]]
+    recs = [f"@r{i}\n{seqs[i % 2000]}\n+\n{'I' * 31}\n" for i in range(n)]
+    fq = "".join(recs).encode()
+    h = _with_env({"SHK_PART_P": 64}, lambda: product(fq, k=31, min_count=1))
+    assert "partition_retry" in h.timings()
+    compare_all(h, run_oracle([fq], k=31, min_count=1))
