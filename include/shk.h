@@ -123,6 +123,10 @@ int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words /*W*/, i
 uint64_t shk_host_nthash(const char *seq, uint32_t k);   /* canonical ntHash of seq[0..k) */
 int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0 fit failed */
 
+/* Device buffers of freed handles are cached process-wide for the next handle (a handle lives
+ * for one preprocess+assemble); this returns the cache to the driver.  SHK_NO_POOL=1 disables it. */
+void shk_release_cached_memory(void);
+
 const char *shk_version(void);
 
 #ifdef __cplusplus

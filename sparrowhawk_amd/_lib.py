@@ -49,6 +49,7 @@ SIGNATURES = {
     "shk_host_canonical": (_int, [_cp, _u32, _vp, C.POINTER(_int)]),
     "shk_host_nthash": (_u64, [_cp, _u32]),
     "shk_host_fit": (_int, [_vp, C.POINTER(_u32)]),
+    "shk_release_cached_memory": (None, []),
     "shk_version": (_cp, []),
 }
 

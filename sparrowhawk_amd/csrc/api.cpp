@@ -60,6 +60,8 @@ static int fail(shk_handle *h, int code, const std::string &msg) { h->err = msg;
 
 extern "C" {
 
+void shk_release_cached_memory(void) { device_pool_trim(); }
+
 const char *shk_version(void) { return "sparrowhawk_amd 0.1 (gfx950)"; }
 int shk_new_error(void) { return g_new_err; }
 const char *shk_new_error_message(void) { return g_new_msg.c_str(); }

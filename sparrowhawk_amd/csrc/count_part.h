@@ -25,6 +25,7 @@
 namespace shk {
 
 static constexpr int PART_THREADS = 512;
+static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
 static constexpr int PART_MAX_P = 4096;
 static constexpr int STAGE_WORDS = 8192;             // 131072 bases of a read tile in LDS
 static constexpr int DESC_CAP = 16384;
@@ -276,15 +277,19 @@ struct CountCtl {
     unsigned long long n_inst;
 };
 
-__device__ __forceinline__ uint32_t mix32(uint64_t x) {
-    uint32_t h = (uint32_t)x ^ ((uint32_t)(x >> 32) * 0x9E3779B1u);
-    h ^= h >> 15; h *= 0x85EBCA77u; h ^= h >> 13; h *= 0xC2B2AE3Du; h ^= h >> 16;
+// Table placement hash: add/shift/xor only (Jenkins one-at-a-time finaliser); integer multiplies
+// are quarter rate on CDNA and this runs once per k-mer instance.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h += h << 10; h ^= h >> 6; h += h << 3; h ^= h >> 11; h += h << 15;
     return h;
 }
 template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) {
-    uint32_t h = mix32(x.w[0]);
+    uint32_t h = 0x9E3779B9u;
 #pragma unroll
-    for (int j = 1; j < W; j++) h = mix32(x.w[j] ^ ((uint64_t)h << 17));
+    for (int j = 0; j < W; j++) {
+        const uint32_t lo = (uint32_t)x.w[j], hi = (uint32_t)(x.w[j] >> 32);
+        h = mix32(h ^ lo ^ __builtin_amdgcn_alignbit(hi, hi, 17));
+    }
     return h;
 }
 
@@ -326,7 +331,7 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
 }
 
 template <int W>
-__global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
+__global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     const uint64_t *__restrict__ recs, const uint32_t *__restrict__ fill, PartParams pp, uint32_t threshold,
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
@@ -363,15 +368,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
         const uint32_t res = ctl.stack_res[ctl.sp - 1], mod = ctl.stack_mod[ctl.sp - 1];
         __syncthreads();
         if (threadIdx.x == 0) { ctl.sp--; ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; }
-        for (uint32_t s = threadIdx.x; s < S; s += PART_THREADS) {
+        for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
             tb.cnt[s] = 0;
             if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
         }
-        for (uint32_t b = threadIdx.x; b < 500; b += PART_THREADS) ctl.histo[b] = 0;
+        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
         __syncthreads();
 
         unsigned long long mine = 0;
-        for (uint32_t r0 = 0; r0 < R; r0 += PART_THREADS) {
+        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
             const uint32_t r = r0 + threadIdx.x;
             uint32_t n = 0;
             Rec<RW> rec;
@@ -387,25 +392,30 @@ __global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
                 }
                 n = (uint32_t)(rec.w[RW - 1] >> 58) + 1u;
             }
-            const uint32_t steps = n ? n + (uint32_t)k - 1u : 0u;
-            Kmer<W> f = km_zero<W>(), rv = km_zero<W>();
-            for (uint32_t i = 0; i < steps; i++) {
-                const uint32_t b = (uint32_t)rec.w[0] & 3u;
+            // Window s of the record (little-endian 2-bit) read as an integer IS the reverse
+            // complement k-mer, complemented: rc = ~(rec >> 2s) & mask.  The forward k-mer is its
+            // revcomp once, then rolls.  No priming over the first k-1 bases.
+            Kmer<W> f = km_zero<W>();
+            for (uint32_t s = 0; s < n; s++) {
+                if (s) {
 #pragma unroll
-                for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
-                rec.w[RW - 1] >>= 2;
-                km_push_back<W>(f, b, k);
-                km_push_front<W>(rv, 3u - b, k);
-                if (i + 1 >= (uint32_t)k) {
-                    const bool use_r = km_less<W>(rv, f);
-                    Kmer<W> c;
+                    for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
+                    rec.w[RW - 1] >>= 2;
+                }
+                Kmer<W> rv;
 #pragma unroll
-                    for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
-                    const uint32_t h = km_mix32<W>(c);
-                    if (mod == 1 || ((h >> 7) & (mod - 1u)) == res) {      // sub-round filter: bits 7.. of h
-                        if (!lds_insert<W>(tb, ctl, c, h * 0x9E3779B1u + (h >> 19))) ctl.overflow = 1;
-                        mine++;
-                    }
+                for (int j = 0; j < W; j++) rv.w[j] = ~rec.w[j];
+                rv.w[W - 1] &= km_topmask<W>(k);
+                if (s) km_push_back<W>(f, (uint32_t)(rec.w[W - 1] >> ((2 * (k - 1)) & 63)) & 3u, k);
+                else f = km_revcomp<W>(rv, k);
+                const bool use_r = km_less<W>(rv, f);
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
+                const uint32_t h = km_mix32<W>(c);
+                if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {         // sub-round filter: bits 20.. of h
+                    if (!lds_insert<W>(tb, ctl, c, h ^ (h << 13))) ctl.overflow = 1;
+                    mine++;
                 }
             }
         }
@@ -426,7 +436,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
         if (lane == 0 && mine) atomicAdd(&ctl.n_inst, mine);
         uint32_t my_emit = 0;
-        for (uint32_t s = threadIdx.x; s < S; s += PART_THREADS) {
+        for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
             const uint32_t c = tb.cnt[s];
             if (c) {
                 atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
@@ -440,13 +450,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_count_partitions(
             unsigned long long base = ctl.n_emit ? atomicAdd(out_cursor, (unsigned long long)ctl.n_emit) : 0ull;
             ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
         }
-        for (uint32_t b = threadIdx.x; b < 500; b += PART_THREADS)
+        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
             if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
         __syncthreads();
         // ---- scan 2: write rows (wave-aggregated reservation inside the workgroup's range)
         const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
-        const uint32_t s_round = (S + PART_THREADS - 1) / PART_THREADS * PART_THREADS;
-        for (uint32_t s = threadIdx.x; s < s_round; s += PART_THREADS) {
+        const uint32_t s_round = (S + COUNT_THREADS - 1) / COUNT_THREADS * COUNT_THREADS;
+        for (uint32_t s = threadIdx.x; s < s_round; s += COUNT_THREADS) {
             const uint32_t c = s < S ? tb.cnt[s] : 0u;
             const bool e = c > threshold && c != 0;
             const unsigned long long em = __ballot(e);

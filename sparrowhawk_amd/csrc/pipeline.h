@@ -55,5 +55,6 @@ uint64_t host_nthash(const char *seq, uint32_t k);
 // upload helper used by the host-buffer entry points
 int device_upload(const void *host, size_t bytes, void **dptr, std::string &err);
 void device_free(void *dptr);
+void device_pool_trim();
 
 }  // namespace shk

@@ -16,6 +16,8 @@
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -606,6 +608,7 @@ __global__ __launch_bounds__(256) void k_succ(Graph<W> g, const uint8_t *__restr
 }
 
 // flags: bit0 splitter, bit1 head.  Compacts splitters, owner[v] = splitter index for them.
+// One global atomic per block-step (returning atomics on one address serialise at ~88 / us).
 template <int W>
 __global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_t *__restrict__ alive,
                                                         const uint32_t *__restrict__ succ,
@@ -613,7 +616,9 @@ __global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_
                                                         uint32_t *__restrict__ spl,
                                                         uint32_t *__restrict__ owner,
                                                         unsigned int *__restrict__ n_spl) {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t blk_base;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t total = g.n * 2;
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_round = (total + stride - 1) / stride * stride;
@@ -628,14 +633,19 @@ __global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_
         }
         if (v < total) flags[v] = f;
         const unsigned long long m = __ballot(p);
-        if (!m) continue;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(n_spl, (unsigned int)__popcll(m));
-        base = __shfl(base, 0);
+        if (lane == 0) wave_tot[wid] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+            blk_base = tot ? atomicAdd(n_spl, tot) : 0u;
+        }
+        __syncthreads();
         if (p) {
-            const uint32_t i = base + __popcll(m & ((1ull << lane) - 1ull));
+            uint32_t i = blk_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wid; w++) i += wave_tot[w];
             spl[i] = v; owner[v] = i;
         }
+        __syncthreads();
     }
 }
 
@@ -668,25 +678,78 @@ __global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint32_
     }
 }
 
-// per splitter: chain slot (NIL = not emitted) and position of the segment start in the chain
+// ---- splitter-list ranking on the device (pointer jumping over ~2N/64 elements) ------------------
+// P: predecessor pointer converging to the chain's head splitter (heads point to themselves);
+// A: nodes before this splitter in its chain; K: counts before it.
+__global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ segs, uint32_t n_spl,
+                                                   uint32_t *__restrict__ P, uint32_t *__restrict__ A,
+                                                   unsigned long long *__restrict__ K) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
+        const SegRec r = segs[s];
+        if (r.head) { P[s] = s; A[s] = 0; K[s] = 0; }
+        if (r.next_spl != NIL) { P[r.next_spl] = s; A[r.next_spl] = r.len; K[r.next_spl] = r.sum; }
+    }
+}
+__global__ __launch_bounds__(256) void k_rank_jump(uint32_t n_spl, const uint32_t *__restrict__ Pi,
+                                                   const uint32_t *__restrict__ Ai,
+                                                   const unsigned long long *__restrict__ Ki,
+                                                   uint32_t *__restrict__ Po, uint32_t *__restrict__ Ao,
+                                                   unsigned long long *__restrict__ Ko) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
+        const uint32_t p = Pi[s];
+        Po[s] = Pi[p]; Ao[s] = Ai[s] + Ai[p]; Ko[s] = Ki[s] + Ki[p];
+    }
+}
+struct HeadRec { uint32_t spl, head_node, tail_node, emit; unsigned long long len, kc; };
+// every chain's tail splitter reports the chain to its head's record slot.  A unitig exists on
+// both strands; the strand to emit is the lexicographically smaller spelling (SPEC S10), which
+// the first k characters decide: seq(head) against seq(rc(tail)).
+template <int W>
+__global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__restrict__ segs, uint32_t n_spl,
+                                                    const uint32_t *__restrict__ P, const uint32_t *__restrict__ A,
+                                                    const unsigned long long *__restrict__ K,
+                                                    HeadRec *__restrict__ heads, uint32_t *__restrict__ slot_of,
+                                                    unsigned int *__restrict__ n_heads) {
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
+        const SegRec r = segs[s];
+        if (r.next_spl != NIL) continue;
+        const uint32_t root = P[s];
+        if (root >= n_spl || !segs[root].head) continue;       // (cannot happen: a chain with a tail has a head)
+        const uint32_t slot = atomicAdd(n_heads, 1u);          // one per chain
+        HeadRec h; h.spl = root; h.head_node = segs[root].node; h.tail_node = r.last;
+        {
+            const Kmer<W> a = g.seq(h.head_node), b = g.seq(h.tail_node ^ 1u);
+            if (km_less<W>(a, b)) h.emit = 1;
+            else if (km_less<W>(b, a)) h.emit = 0;
+            else h.emit = h.head_node <= (h.tail_node ^ 1u);       // the chain is its own mirror, or a tie on ids
+        }
+        h.len = (unsigned long long)A[s] + r.len; h.kc = K[s] + r.sum;
+        heads[slot] = h; slot_of[root] = slot;
+    }
+}
+
+// per node: splitter -> chain head -> output offset (~0 = chain not emitted)
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
                                               const uint32_t *__restrict__ owner,
                                               const uint32_t *__restrict__ local,
-                                              const uint32_t *__restrict__ spl_chain,
-                                              const uint32_t *__restrict__ spl_base,
-                                              const unsigned long long *__restrict__ chain_off,
+                                              const uint32_t *__restrict__ P,
+                                              const uint32_t *__restrict__ A,
+                                              const uint32_t *__restrict__ slot_of,
+                                              const unsigned long long *__restrict__ head_off,
                                               char *__restrict__ out) {
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1]) continue;
         const uint32_t s = owner[v];
         if (s == NIL) continue;
-        const uint32_t ch = spl_chain[s];
-        if (ch == NIL) continue;
-        const uint32_t pos = spl_base[s] + local[v];
+        const uint32_t slot = slot_of[P[s]];
+        if (slot == NIL) continue;
+        const unsigned long long off = head_off[slot];
+        if (off == ~0ull) continue;
+        const uint32_t pos = A[s] + local[v];
         const Kmer<W> x = g.seq(v);
-        char *dst = out + chain_off[ch];
+        char *dst = out + off;
         const uint32_t ACGT = 0x54474341u;                 // 'A','C','G','T' little-endian
         dst[g.k - 1 + pos] = (char)((ACGT >> (8 * km_last_base<W>(x))) & 0xFF);
         if (pos == 0) {
@@ -741,20 +804,82 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *__restrict__ a,
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+// Process-wide cache of device allocations: a handle lives for one preprocess+assemble, and
+// hipMalloc/hipFree of its multi-GB buffers cost more than the kernels (measured ~10 ms/step).
+// Blocks are returned here on release and reused by the next handle; shk_release_cached_memory()
+// gives them back to the driver.
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    bool enabled = true;
+    DevPool() { const char *v = getenv("SHK_NO_POOL"); enabled = !(v && *v == '1'); }
+    void *get(size_t &bytes, hipError_t &e) {
+        bytes = (bytes + 4095) & ~(size_t)4095;
+        if (enabled) {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = free_blocks.lower_bound(bytes);
+            if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
+                void *p = it->second; bytes = it->first; free_blocks.erase(it); e = hipSuccess; return p;
+            }
+        }
+        void *p = nullptr;
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess && enabled) {              // out of memory: drop the cache and retry once
+            trim();
+            e = hipMalloc(&p, bytes);
+        }
+        return e == hipSuccess ? p : nullptr;
+    }
+    void put(void *p, size_t bytes) {
+        if (!p) return;
+        if (!enabled) { (void)hipFree(p); return; }
+        std::lock_guard<std::mutex> lk(mu);
+        free_blocks.emplace(bytes, p);
+    }
+    void trim() {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+    }
+};
+static DevPool &dev_pool() { static DevPool *p = new DevPool(); return *p; }   // never destroyed (HIP teardown order)
+void device_pool_trim() { dev_pool().trim(); }
+
 template <typename T> struct DevBuf {
-    T *p = nullptr; size_t n = 0;
+    T *p = nullptr; size_t n = 0; size_t bytes = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(bytes, o.bytes); }
+    void release() { if (p) { dev_pool().put(p, bytes); p = nullptr; n = 0; bytes = 0; } }
     int alloc(size_t count, std::string &err) {
         release();
         if (count == 0) count = 1;
-        hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
-        if (e != hipSuccess) { p = nullptr; err = std::string("hipMalloc: ") + hipGetErrorString(e); return -4; }
-        n = count; return 0;
+        size_t b = count * sizeof(T);
+        hipError_t e;
+        p = (T *)dev_pool().get(b, e);
+        if (!p) { err = std::string("hipMalloc: ") + hipGetErrorString(e); return -4; }
+        n = count; bytes = b; return 0;
+    }
+};
+
+// pinned host staging buffer (D2H of contigs at full PCIe rate), cached the same way
+struct PinnedBuf {
+    char *p = nullptr; size_t bytes = 0;
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::multimap<size_t, void *> &cache() { static auto *c = new std::multimap<size_t, void *>(); return *c; }
+    ~PinnedBuf() { if (p) { std::lock_guard<std::mutex> lk(mu()); cache().emplace(bytes, p); } }
+    int alloc(size_t b, std::string &err) {
+        b = (b + 4095) & ~(size_t)4095; if (!b) b = 4096;
+        {
+            std::lock_guard<std::mutex> lk(mu());
+            auto it = cache().lower_bound(b);
+            if (it != cache().end() && it->first <= 2 * b + (1u << 20)) { p = (char *)it->second; bytes = it->first; cache().erase(it); return 0; }
+        }
+        hipError_t e = hipHostMalloc((void **)&p, b, hipHostMallocDefault);
+        if (e != hipSuccess) { p = nullptr; err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return -4; }
+        bytes = b; return 0;
     }
 };
 
@@ -876,6 +1001,7 @@ public:
         const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
         pp_.k = k_; pp_.m = k_ - wblk + 1;
         pp_.max_n = std::min<uint32_t>(32u * RW - 3u - (uint32_t)(k_ - 1), 63u);
+        if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
         uint32_t P = 64;
         const uint64_t per_part = env_u64("SHK_PART_INST", 400000);
@@ -926,7 +1052,7 @@ public:
             HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             EvTimer t(stream_);
-            hipLaunchKernelGGL(k_count_partitions<W>, dim3(pp_.P), dim3(PART_THREADS), 0, stream_, recs_.p, fill_.p,
+            hipLaunchKernelGGL(k_count_partitions<W>, dim3(pp_.P), dim3(COUNT_THREADS), 0, stream_, recs_.p, fill_.p,
                                pp_, threshold, dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2));
             HIPCHK(hipGetLastError());
@@ -1240,7 +1366,7 @@ public:
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
         times_.add("collapse_succ_split", t1.stop());
-        std::vector<SegRec> hseg(n_spl);
+        times_.add("collapse_n_splitters_x1e-3", n_spl * 1e-3);
         if (n_spl) {
             if (int rc = segs.alloc(n_spl, err)) return rc;
             EvTimer t2(stream_);
@@ -1248,63 +1374,78 @@ public:
                                flags.p, spl.p, n_spl, owner.p, local.p, segs.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_walk", t2.stop());
-            HIPCHK(hipMemcpyAsync(hseg.data(), segs.p, (size_t)n_spl * sizeof(SegRec), hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipStreamSynchronize(stream_));
         }
-        // ---- rank the splitter list on the host (it is ~2N/64 long)
-        auto th0 = std::chrono::steady_clock::now();
-        struct Chain { uint32_t head_spl; uint64_t len; uint64_t kc; uint32_t head_node, tail_node; };
-        std::vector<Chain> chains;
-        std::vector<uint32_t> spl_chain(n_spl, NIL), spl_base(n_spl, 0);
-        std::vector<uint8_t> seen(n_spl, 0);
+        // ---- rank the splitter list on the device: prefix of segment lengths by pointer jumping
+        DevBuf<uint32_t> Pa, Pb, Aa, Ab, slot_of; DevBuf<unsigned long long> Ka, Kb, d_off; DevBuf<HeadRec> d_heads;
+        DevBuf<char> d_out;
+        uint32_t *Pf = nullptr, *Af = nullptr;
+        std::vector<HeadRec> heads;
         uint64_t covered = 0;
-        for (uint32_t i = 0; i < n_spl; i++) {
-            if (!hseg[i].head) continue;
-            Chain c; c.head_spl = i; c.len = 0; c.kc = 0; c.head_node = hseg[i].node; c.tail_node = hseg[i].node;
-            uint32_t cur = i;
-            while (cur != NIL) {
-                if (seen[cur]) { err = "collapse: splitter reached twice"; return -6; }
-                seen[cur] = 1;
-                spl_base[cur] = (uint32_t)c.len;
-                c.len += hseg[cur].len; c.kc += hseg[cur].sum; c.tail_node = hseg[cur].last;
-                cur = hseg[cur].next_spl;
+        if (n_spl) {
+            if (int rc = Pa.alloc(n_spl, err)) return rc;
+            if (int rc = Pb.alloc(n_spl, err)) return rc;
+            if (int rc = Aa.alloc(n_spl, err)) return rc;
+            if (int rc = Ab.alloc(n_spl, err)) return rc;
+            if (int rc = Ka.alloc(n_spl, err)) return rc;
+            if (int rc = Kb.alloc(n_spl, err)) return rc;
+            if (int rc = slot_of.alloc(n_spl, err)) return rc;
+            if (int rc = d_heads.alloc(n_spl, err)) return rc;
+            EvTimer tr(stream_);
+            // cycle members have no head: give every element a defined pointer first
+            HIPCHK(hipMemsetAsync(Pa.p, 0, (size_t)n_spl * 4, stream_));
+            HIPCHK(hipMemsetAsync(Aa.p, 0, (size_t)n_spl * 4, stream_));
+            HIPCHK(hipMemsetAsync(Ka.p, 0, (size_t)n_spl * 8, stream_));
+            HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)n_spl * 4, stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p + 6, 0, 8, stream_));
+            const int gr = grid_for(n_spl);
+            hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, n_spl, Pa.p, Aa.p, Ka.p);
+            uint32_t *Pi = Pa.p, *Po = Pb.p, *Ai = Aa.p, *Ao = Ab.p; unsigned long long *Ki = Ka.p, *Ko = Kb.p;
+            int rounds = 1; while ((1ull << rounds) < (uint64_t)n_spl) rounds++;
+            for (int r = 0; r < rounds; r++) {
+                hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, n_spl, Pi, Ai, Ki, Po, Ao, Ko);
+                std::swap(Pi, Po); std::swap(Ai, Ao); std::swap(Ki, Ko);
             }
-            covered += c.len;
-            // each unitig exists on both strands: keep the one whose head id <= rc(tail) id
-            const bool emit = c.head_node <= (c.tail_node ^ 1u);
-            if (emit) {
-                const uint32_t id = (uint32_t)chains.size();
-                chains.push_back(c);
-                for (cur = i; cur != NIL; cur = hseg[cur].next_spl) spl_chain[cur] = id;
+            Pf = Pi; Af = Ai;
+            hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, n_spl, Pi, Ai, Ki, d_heads.p,
+                               slot_of.p, (unsigned int *)(ctl_.p + 6));
+            HIPCHK(hipGetLastError());
+            unsigned int n_heads = 0;
+            if (int rc = read_ctl(n_heads, 6, err)) return rc;
+            times_.add("collapse_rank_device", tr.stop());
+            heads.resize(n_heads);
+            if (n_heads) HIPCHK(hipMemcpy(heads.data(), d_heads.p, (size_t)n_heads * sizeof(HeadRec), hipMemcpyDeviceToHost));
+        }
+        // each unitig exists on both strands: keep the canonical one (decided on the device)
+        std::vector<unsigned long long> head_off(heads.size(), ~0ull);
+        std::vector<uint32_t> emitted;
+        uint64_t out_bytes = 0;
+        for (size_t i = 0; i < heads.size(); i++) {
+            covered += heads[i].len;
+            if (heads[i].emit) {
+                head_off[i] = out_bytes; out_bytes += heads[i].len + (uint64_t)(k_ - 1); emitted.push_back((uint32_t)i);
             }
         }
-        std::vector<unsigned long long> chain_off(chains.size() + 1, 0);
-        for (size_t c = 0; c < chains.size(); c++) chain_off[c + 1] = chain_off[c] + chains[c].len + (uint64_t)(k_ - 1);
-        const uint64_t out_bytes = chain_off[chains.size()];
-        times_.add("collapse_host_rank", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - th0).count());
-
-        std::vector<char> hout(out_bytes);
-        if (!chains.empty()) {
-            DevBuf<uint32_t> d_chain, d_base; DevBuf<unsigned long long> d_off; DevBuf<char> d_out;
-            if (int rc = d_chain.alloc(n_spl, err)) return rc;
-            if (int rc = d_base.alloc(n_spl, err)) return rc;
-            if (int rc = d_off.alloc(chain_off.size(), err)) return rc;
+        if (!emitted.empty()) {
+            PinnedBuf hout;
+            if (int rc = hout.alloc(out_bytes, err)) return rc;
+            if (int rc = d_off.alloc(head_off.size(), err)) return rc;
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
-            HIPCHK(hipMemcpyAsync(d_chain.p, spl_chain.data(), (size_t)n_spl * 4, hipMemcpyHostToDevice, stream_));
-            HIPCHK(hipMemcpyAsync(d_base.p, spl_base.data(), (size_t)n_spl * 4, hipMemcpyHostToDevice, stream_));
-            HIPCHK(hipMemcpyAsync(d_off.p, chain_off.data(), chain_off.size() * 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * 8, hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, owner.p, local.p,
-                               d_chain.p, d_base.p, d_off.p, d_out.p);
+                               Pf, Af, slot_of.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
-            HIPCHK(hipMemcpyAsync(hout.data(), d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
+            auto tcp = std::chrono::steady_clock::now();
+            HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
-            for (size_t c = 0; c < chains.size(); c++) {
-                RawContig rc; rc.kc = chains[c].kc;
-                rc.seq.assign(hout.data() + chain_off[c], hout.data() + chain_off[c + 1]);
+            out.reserve(emitted.size());
+            for (uint32_t i : emitted) {
+                RawContig rc; rc.kc = heads[i].kc;
+                rc.seq.assign(hout.p + head_off[i], hout.p + head_off[i] + heads[i].len + (uint64_t)(k_ - 1));
                 out.push_back(std::move(rc));
             }
+            times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
         }
         // ---- circular unitigs (no head): rare; resolved on the host from succ[] (SPEC S10)
         std::vector<uint8_t> halive(n);
@@ -1325,9 +1466,16 @@ public:
                 }
             }
             // nodes on headed chains: walk them again on the host to mark coverage
+            std::vector<SegRec> hseg(n_spl);
+            std::vector<uint32_t> hP(n_spl);
+            if (n_spl) {
+                HIPCHK(hipMemcpy(hseg.data(), segs.p, (size_t)n_spl * sizeof(SegRec), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(hP.data(), Pf, (size_t)n_spl * 4, hipMemcpyDeviceToHost));
+            }
             std::vector<uint8_t> on_chain(n, 0);
             for (uint32_t i = 0; i < n_spl; i++) {
-                if (!seen[i]) continue;
+                const uint32_t root = hP[i];
+                if (!(root < n_spl && hP[root] == root && hseg[root].head)) continue;   // splitter on a cycle
                 uint32_t v = hseg[i].node;
                 for (uint32_t j = 0; j < hseg[i].len; j++) { on_chain[v >> 1] = 1; v = hsucc[v]; }
             }
