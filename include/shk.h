@@ -89,6 +89,35 @@ int shk_assemble(shk_handle *h);
  * JSON {"outfasta":str,"ncontigs":int,"outdot":str,"outgfa":str,"outgfav2":str}  :7-13 */
 const char *shk_get_assembly(shk_handle *h);
 
+/* ---- shard layer: one process per GPU (DESIGN.md "Multi-GPU").  It replaces the crate's rayon
+ * read-parallel driver (north_star; not in the reference tree).  The
+ * k-mer space is split by minimiser-hash partition: partition p belongs to rank p % world.
+ * Sequence on every rank (collectives done by the caller, e.g. sparrowhawk_amd/dist.py):
+ *   shk_shard_partition  reads -> super-k-mer records per partition; part_records[p] = records held
+ *   shk_shard_pack       records copied densely to d_send at base_records[p] (caller's order)
+ *        -- ONE all-to-all of d_send blocks (RCCL) --
+ *   shk_shard_count      counts the owned partitions from d_recv; run tables [n_owned][n_sources]
+ *                        give record offset/count of each source's run; local histogram out
+ *        -- all-reduce of the 500-bin histogram and the instance count --
+ *   shk_shard_rows       fit + filter on the global histogram; local solid rows (device pointers,
+ *                        W key arrays + one count array, valid until shk_shard_set_solid)
+ *        -- all-gather of the solid rows --
+ *   shk_shard_set_solid  installs the whole solid set; the handle is then "preprocessed" and
+ *                        shk_assemble() runs as usual (identically on every rank)
+ * n_partitions: a power of two <= 4096, identical on all ranks. */
+int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                        uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions,
+                        uint64_t *part_records /* [n_partitions] out */);
+uint32_t shk_shard_record_bytes(shk_handle *h);
+int shk_shard_pack(shk_handle *h, void *d_send, const uint64_t *base_records, uint32_t n_partitions);
+int shk_shard_count(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
+                    uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local,
+                    uint64_t *n_instances_local);
+int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **d_keys /* [W] out */,
+                   const void **d_cnt, uint64_t *n_rows, uint32_t *used_min_count);
+int shk_shard_set_solid(shk_handle *h, const void *const *d_keys /* [W] */, const void *d_cnt,
+                        uint64_t n_rows, uint64_t n_instances_global);
+
 /* ---- host-side packer (the parser the preprocess entry points use), exposed so a caller can
  * stage packed reads in HBM itself (bench.py, the multi-GPU shard layer). */
 typedef struct shk_packed {

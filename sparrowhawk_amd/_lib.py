@@ -34,6 +34,12 @@ SIGNATURES = {
     "shk_get_preprocessing_info": (_cp, [_vp]),
     "shk_assemble": (_int, [_vp]),
     "shk_get_assembly": (_cp, [_vp]),
+    "shk_shard_partition": (_int, [_vp, _vp, _vp, _u64, _u64, _u64, _u32, _vp]),
+    "shk_shard_record_bytes": (_u32, [_vp]),
+    "shk_shard_pack": (_int, [_vp, _vp, _vp, _u32]),
+    "shk_shard_count": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp]),
+    "shk_shard_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "shk_shard_set_solid": (_int, [_vp, _vp, _vp, _u64, _u64]),
     "shk_pack_fastq": (_int, [_cp, _sz, _u32, _u32, C.POINTER(ShkPacked), C.POINTER(_cp)]),
     "shk_packed_free": (None, [C.POINTER(ShkPacked)]),
     "shk_key_words": (_u32, [_vp]),

@@ -26,7 +26,7 @@ namespace {
 thread_local int g_new_err = 0;
 thread_local std::string g_new_msg;
 
-enum class St { Fresh, Streaming, Preprocessed, Assembled };
+enum class St { Fresh, Streaming, Sharding, Preprocessed, Assembled };
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -197,6 +197,83 @@ int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void 
     h->n_reads = n_reads;
     h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
     return run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_seg_off, n_seg, n_bases);
+}
+
+// ---- shard layer: the single-GPU preprocess cut at its two exchange points ----------------------
+static uint32_t emit_threshold_of(const shk_handle *h) {
+    return h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
+}
+
+int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+                        uint64_t n_reads, uint32_t n_partitions, uint64_t *part_records) {
+    if (!h || !part_records) return SHK_E_PARAM;
+    if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "shard_partition: handle already used");
+    h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+    h->n_reads = n_reads;
+    std::vector<uint64_t> pr;
+    std::string err;
+    int rc = h->pipe->shard_partition((const uint32_t *)d_bases, (const uint32_t *)d_seg_off, n_seg, n_bases, n_partitions, pr, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    memcpy(part_records, pr.data(), (size_t)n_partitions * 8);
+    h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
+    h->post_mode("loop:end");
+    h->st = St::Sharding;
+    return SHK_OK;
+}
+
+uint32_t shk_shard_record_bytes(shk_handle *h) { return h && h->pipe ? h->pipe->rec_words() * 8u : 0u; }
+
+int shk_shard_pack(shk_handle *h, void *d_send, const uint64_t *base_records, uint32_t n_partitions) {
+    if (!h || !base_records) return SHK_E_PARAM;
+    if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_pack: call shard_partition first");
+    std::string err;
+    int rc = h->pipe->shard_pack(d_send, base_records, n_partitions, err);
+    return rc ? fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err) : SHK_OK;
+}
+
+int shk_shard_count(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
+                    uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local, uint64_t *n_instances_local) {
+    if (!h || !histo500_local) return SHK_E_PARAM;
+    if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_count: call shard_partition first");
+    std::string err;
+    if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
+    int rc = h->pipe->shard_count(d_recv, run_off, run_cnt, n_owned, n_sources, emit_threshold_of(h), histo500_local, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    if (n_instances_local) *n_instances_local = h->pipe->total_instances();
+    return SHK_OK;
+}
+
+int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **d_keys, const void **d_cnt,
+                   uint64_t *n_rows, uint32_t *used_min_count) {
+    if (!h || !histo500_global || !d_keys || !d_cnt || !n_rows) return SHK_E_PARAM;
+    if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_rows: call shard_count first");
+    memcpy(h->histo, histo500_global, sizeof h->histo);
+    h->used_min_count = h->min_count; h->fit_ok = false;
+    if (h->do_fit) {
+        h->post_mode("fitting");
+        uint32_t v = 0;
+        if (spectrum_fit(h->histo, &v)) { h->used_min_count = v; h->fit_ok = true; }
+    }
+    h->post_mode("filtering");
+    std::string err;
+    int rc = h->pipe->shard_rows(h->used_min_count, d_keys, d_cnt, n_rows, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+    if (used_min_count) *used_min_count = h->used_min_count;
+    return SHK_OK;
+}
+
+int shk_shard_set_solid(shk_handle *h, const void *const *d_keys, const void *d_cnt, uint64_t n_rows,
+                        uint64_t n_instances_global) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_set_solid: call shard_rows first");
+    std::string err;
+    int rc = h->pipe->shard_set_solid(d_keys, d_cnt, n_rows, h->histo, n_instances_global, err);
+    if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    h->post("preprocess:saving");
+    h->pre_json = preprocessing_json(h->pipe->n_solid(), h->histo, h->used_min_count);
+    h->st = St::Preprocessed;
+    h->post("preprocess:end");
+    return SHK_OK;
 }
 
 const char *shk_get_preprocessing_info(shk_handle *h) {

@@ -330,9 +330,78 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
     }
 }
 
+// A partition's records arrive as S runs (local: one per producer workgroup; sharded: one per
+// source rank): run j of partition p holds run_cnt[p*S+j] records starting at record run_off[p*S+j].
+struct RunView {
+    const uint64_t *recs;
+    const unsigned long long *run_off;
+    const uint32_t *run_cnt;
+    uint32_t S;            // runs per partition (<= 256)
+    int k;
+};
+
+// run table of the local layout recs[p][g][slice_cap]
+__global__ __launch_bounds__(256) void k_make_runs(const uint32_t *__restrict__ fill, PartParams pp,
+                                                   unsigned long long *__restrict__ run_off,
+                                                   uint32_t *__restrict__ run_cnt) {
+    const uint64_t n = (uint64_t)pp.P * pp.G;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        run_off[i] = i * pp.slice_cap;
+        run_cnt[i] = min(fill[i], pp.slice_cap);
+    }
+}
+
+// records held per partition (sum over the producer slices)
+__global__ __launch_bounds__(256) void k_part_totals(const uint32_t *__restrict__ fill, PartParams pp,
+                                                     unsigned long long *__restrict__ totals) {
+    const uint32_t p = blockIdx.x;
+    unsigned long long t = 0;
+    for (uint32_t g = threadIdx.x; g < pp.G; g += blockDim.x) t += min(fill[(uint64_t)p * pp.G + g], pp.slice_cap);
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) totals[p] = part[0] + part[1] + part[2] + part[3];
+}
+
+// dense copy of partition p's records to dst + base[p] records (send buffer of the shard layer)
+template <int RW>
+__global__ __launch_bounds__(256) void k_pack_partition(const uint64_t *__restrict__ recs,
+                                                        const uint32_t *__restrict__ fill, PartParams pp,
+                                                        const unsigned long long *__restrict__ base,
+                                                        uint64_t *__restrict__ dst) {
+    __shared__ uint32_t pre[257];
+    const uint32_t p = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < pp.G; g0 += 64) {
+            const uint32_t g = g0 + threadIdx.x;
+            const uint32_t f = g < pp.G ? min(fill[(uint64_t)p * pp.G + g], pp.slice_cap) : 0u;
+            uint32_t incl = f;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (g < pp.G) pre[g] = run + incl - f;
+            run += __shfl(incl, 63);
+        }
+        if (threadIdx.x == 0) pre[pp.G] = run;
+    }
+    __syncthreads();
+    const uint32_t R = pre[pp.G];
+    const uint64_t *src_p = recs + (uint64_t)p * pp.G * pp.slice_cap * RW;
+    uint64_t *dst_p = dst + base[p] * RW;
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+        uint32_t lo = 0, hi = pp.G;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
+        const uint64_t *src = src_p + ((uint64_t)lo * pp.slice_cap + (r - pre[lo])) * RW;
+#pragma unroll
+        for (int o = 0; o < RW; o += 2)
+            *reinterpret_cast<ulonglong2 *>(dst_p + (uint64_t)r * RW + o) = *reinterpret_cast<const ulonglong2 *>(src + o);
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
-    const uint64_t *__restrict__ recs, const uint32_t *__restrict__ fill, PartParams pp, uint32_t threshold,
+    RunView rvw, uint32_t threshold,
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
     unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags) {
@@ -342,25 +411,25 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     __shared__ CountCtl ctl;
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const int k = pp.k;
-    // exclusive prefix of the slice fills of this partition
+    const int k = rvw.k;
+    const uint32_t S_runs = rvw.S;
+    // exclusive prefix of the run lengths of this partition
     if (threadIdx.x < 64) {
         uint32_t run = 0;
-        for (uint32_t g0 = 0; g0 < pp.G; g0 += 64) {
+        for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
             const uint32_t g = g0 + threadIdx.x;
-            uint32_t f = g < pp.G ? min(fill[(uint64_t)p * pp.G + g], pp.slice_cap) : 0u;
+            uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
             uint32_t incl = f;
             for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            if (g < pp.G) ctl.pre[g] = run + incl - f;
+            if (g < S_runs) ctl.pre[g] = run + incl - f;
             run += __shfl(incl, 63);
         }
         if (threadIdx.x == 0) {
-            ctl.pre[pp.G] = run; ctl.sp = 1; ctl.stack_res[0] = 0; ctl.stack_mod[0] = 1; ctl.n_inst = 0;
+            ctl.pre[S_runs] = run; ctl.sp = 1; ctl.stack_res[0] = 0; ctl.stack_mod[0] = 1; ctl.n_inst = 0;
         }
     }
     __syncthreads();
-    const uint32_t R = ctl.pre[pp.G];
-    const uint64_t *prec = recs + (uint64_t)p * pp.G * pp.slice_cap * RW;
+    const uint32_t R = ctl.pre[S_runs];
 
     while (true) {
         __syncthreads();
@@ -382,9 +451,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             Rec<RW> rec;
             if (r < R) {
                 // slice g with pre[g] <= r < pre[g+1]
-                uint32_t lo = 0, hi = pp.G;
+                uint32_t lo = 0, hi = S_runs;
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
-                const uint64_t *src = prec + ((uint64_t)lo * pp.slice_cap + (r - ctl.pre[lo])) * RW;
+                const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
 #pragma unroll
                 for (int o = 0; o < RW; o += 2) {
                     const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);

@@ -40,6 +40,17 @@ public:
     virtual int collapse(std::vector<RawContig> &out, std::string &err) = 0;
     virtual int get_adjacency(uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
                               uint64_t cap, std::string &err) = 0;
+    // shard layer (one process per GPU): partition -> pack -> [all-to-all] -> count -> rows ->
+    // [all-gather] -> set_solid -> build_graph/correct/collapse as usual
+    virtual int shard_partition(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+                                uint32_t n_partitions, std::vector<uint64_t> &part_records, std::string &err) = 0;
+    virtual uint32_t rec_words() const = 0;
+    virtual int shard_pack(void *d_send, const uint64_t *base_records, uint32_t n_partitions, std::string &err) = 0;
+    virtual int shard_count(const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt, uint32_t n_owned,
+                            uint32_t n_sources, uint32_t emit_threshold, uint64_t histo[500], std::string &err) = 0;
+    virtual int shard_rows(uint32_t threshold, const void **keys_soa, const void **cnt, uint64_t *n, std::string &err) = 0;
+    virtual int shard_set_solid(const void *const *keys_soa, const void *cnt, uint64_t n, const uint64_t histo[500],
+                                uint64_t total_instances, std::string &err) = 0;
     virtual StageTimes &times() = 0;
     virtual void *stream() = 0;
 };

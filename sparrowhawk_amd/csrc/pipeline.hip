@@ -1007,6 +1007,7 @@ public:
         const uint64_t per_part = env_u64("SHK_PART_INST", 400000);
         while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
         if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
+        if (forced_P_) P = forced_P_;
         pp_.P = P;
         uint64_t cap = inst_ub / (4ull * P * pp_.G) + 32;
         for (int attempt = 0; attempt < 2; attempt++) {
@@ -1030,7 +1031,19 @@ public:
             const uint32_t *fl = (const uint32_t *)&h[0];
             if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
             const uint32_t max_fill = (uint32_t)h[1];
-            if (max_fill <= cap) { times_.add("partition_kernel", ms); have_parts_ = true; return 0; }
+            if (max_fill <= cap) {
+                times_.add("partition_kernel", ms);
+                have_parts_ = true;
+                // run table of the local layout: one run per (partition, producer workgroup)
+                if (int rc = run_off_.alloc(n_slices, err)) return rc;
+                if (int rc = run_cnt_.alloc(n_slices, err)) return rc;
+                hipLaunchKernelGGL(k_make_runs, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, pp_, run_off_.p,
+                                   run_cnt_.p);
+                HIPCHK(hipGetLastError());
+                run_view_.recs = recs_.p; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P;
+                return 0;
+            }
             times_.add("partition_retry", ms);
             cap = (uint64_t)max_fill + 8;               // exact from the counting run
         }
@@ -1039,9 +1052,10 @@ public:
     }
 
     // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying
-    int run_count_partitions(uint32_t threshold, DevBuf<uint64_t> (&keys)[W], DevBuf<uint32_t> &cnt,
-                             uint64_t &n_rows, uint64_t hist_out[500], uint64_t &inst_out, uint64_t cap_hint,
-                             double &ms_out, std::string &err) {
+    int run_count_partitions(const RunView &rv, uint32_t n_parts, uint32_t threshold, DevBuf<uint64_t> (&keys)[W],
+                             DevBuf<uint32_t> &cnt, uint64_t &n_rows, uint64_t hist_out[500], uint64_t &inst_out,
+                             uint64_t cap_hint, double &ms_out, std::string &err) {
+        if (n_parts == 0) { n_rows = 0; inst_out = 0; memset(hist_out, 0, 500 * 8); ms_out = 0; return 0; }
         DevBuf<unsigned long long> dh;
         if (int rc = dh.alloc(500, err)) return rc;
         uint64_t cap = cap_hint;
@@ -1052,8 +1066,8 @@ public:
             HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             EvTimer t(stream_);
-            hipLaunchKernelGGL(k_count_partitions<W>, dim3(pp_.P), dim3(COUNT_THREADS), 0, stream_, recs_.p, fill_.p,
-                               pp_, threshold, dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
+            hipLaunchKernelGGL(k_count_partitions<W>, dim3(n_parts), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
+                               dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2));
             HIPCHK(hipGetLastError());
             ms_out = t.stop();
@@ -1077,7 +1091,8 @@ public:
             if (have_parts_) {
                 const uint64_t inst_ub_rows = total_rows_hint();
                 double ms = 0; uint64_t inst = 0;
-                if (int rc = run_count_partitions(emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst, inst_ub_rows, ms, err)) return rc;
+                if (int rc = run_count_partitions(run_view_, n_count_parts_, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
+                                                  inst_ub_rows, ms, err)) return rc;
                 times_.add("count_kernel", ms);
                 total_instances_ = inst;
             }
@@ -1182,7 +1197,7 @@ public:
             // stage inspection: run the counting pass again keeping every row
             if (!have_parts_ || !recs_.p) { err = "partition buffers already released"; return -2; }
             uint64_t rows = 0, hist[500], inst = 0; double ms = 0;
-            if (int rc = run_count_partitions(0, dk, dc, rows, hist, inst, n_distinct_, ms, err)) return rc;
+            if (int rc = run_count_partitions(run_view_, n_count_parts_, 0, dk, dc, rows, hist, inst, n_distinct_, ms, err)) return rc;
             if (rows != n_distinct_) { err = "distinct row count mismatch"; return -6; }
         }
         return copy_out(dk, dc, n_distinct_, keys, counts, err);
@@ -1190,6 +1205,102 @@ public:
     int get_solid(uint64_t *keys, uint32_t *counts, uint64_t cap, std::string &err) override {
         if (cap < n_solid_) { err = "buffer too small"; return -1; }
         return copy_out(skeys_, scnt_, n_solid_, keys, counts, err);
+    }
+
+    // ---- shard layer (one process per GPU; DESIGN.md "Multi-GPU") --------------------------------
+    int shard_partition(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+                        uint32_t n_partitions, std::vector<uint64_t> &part_records, std::string &err) override {
+        if (global_mode_) { err = "shard layer needs the partitioned counting mode"; return -1; }
+        if (n_partitions < 1 || n_partitions > (uint32_t)PART_MAX_P || (n_partitions & (n_partitions - 1))) {
+            err = "n_partitions must be a power of two <= 4096"; return -1;
+        }
+        forced_P_ = n_partitions;
+        part_records.assign(n_partitions, 0);
+        if (int rc = count_batch(d_bases, d_seg_off, n_seg, n_bases, err)) return rc;
+        if (!have_parts_) return 0;                       // no segments on this rank
+        DevBuf<unsigned long long> tot;
+        if (int rc = tot.alloc(pp_.P, err)) return rc;
+        hipLaunchKernelGGL(k_part_totals, dim3(pp_.P), dim3(256), 0, stream_, fill_.p, pp_, tot.p);
+        HIPCHK(hipGetLastError());
+        std::vector<unsigned long long> h(pp_.P);
+        HIPCHK(hipMemcpyAsync(h.data(), tot.p, (size_t)pp_.P * 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (uint32_t p = 0; p < pp_.P; p++) part_records[p] = h[p];
+        return 0;
+    }
+    uint32_t rec_words() const override { return 2 * W; }
+
+    int shard_pack(void *d_send, const uint64_t *base_records, uint32_t n_partitions, std::string &err) override {
+        if (!have_parts_) return 0;
+        if (n_partitions != pp_.P) { err = "partition count mismatch"; return -1; }
+        DevBuf<unsigned long long> base;
+        if (int rc = base.alloc(pp_.P, err)) return rc;
+        HIPCHK(hipMemcpyAsync(base.p, base_records, (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
+        EvTimer t(stream_);
+        hipLaunchKernelGGL((k_pack_partition<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, recs_.p, fill_.p, pp_, base.p,
+                           (uint64_t *)d_send);
+        HIPCHK(hipGetLastError());
+        times_.add("shard_pack_kernel", t.stop());
+        HIPCHK(hipStreamSynchronize(stream_));
+        // the local slices are no longer needed once packed
+        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
+        return 0;
+    }
+
+    // d_recv: records received from all sources; run tables [n_owned][n_sources] on the host
+    int shard_count(const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt, uint32_t n_owned,
+                    uint32_t n_sources, uint32_t emit_threshold, uint64_t histo[500], std::string &err) override {
+        if (n_sources < 1 || n_sources > 256) { err = "1..256 sources"; return -1; }
+        const uint64_t n_runs = (uint64_t)n_owned * n_sources;
+        if (int rc = run_off_.alloc(n_runs, err)) return rc;
+        if (int rc = run_cnt_.alloc(n_runs, err)) return rc;
+        if (n_runs) {
+            HIPCHK(hipMemcpyAsync(run_off_.p, run_off, n_runs * 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(run_cnt_.p, run_cnt, n_runs * 4, hipMemcpyHostToDevice, stream_));
+        }
+        shard_recv_ = d_recv;
+        run_view_.recs = (const uint64_t *)d_recv; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+        run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned;
+        uint64_t total_recs = 0;
+        for (uint64_t i = 0; i < n_runs; i++) total_recs += run_cnt[i];
+        memset(histo, 0, 500 * 8);
+        n_emitted_ = 0; emit_threshold_ = emit_threshold; n_distinct_ = 0;
+        double ms = 0; uint64_t inst = 0;
+        have_parts_ = n_runs != 0;
+        if (int rc = run_count_partitions(run_view_, n_owned, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
+                                          std::max<uint64_t>(1u << 16, total_recs), ms, err)) return rc;
+        times_.add("count_kernel", ms);
+        total_instances_ = inst;
+        for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
+        return 0;
+    }
+
+    // local rows with count > threshold; device pointers stay owned by the pipeline
+    int shard_rows(uint32_t threshold, const void **keys_soa, const void **cnt, uint64_t *n, std::string &err) override {
+        if (int rc = filter(threshold, err)) return rc;
+        for (int j = 0; j < W; j++) keys_soa[j] = skeys_[j].p;
+        *cnt = scnt_.p; *n = n_solid_;
+        return 0;
+    }
+
+    // install the gathered solid set (every rank holds all of it) and the global statistics
+    int shard_set_solid(const void *const *keys_soa, const void *cnt, uint64_t n, const uint64_t histo[500],
+                        uint64_t total_instances, std::string &err) override {
+        if (n >= 0x7FFFFFFFull) { err = "too many solid k-mers for 32-bit node ids"; return -1; }
+        DevBuf<uint64_t> nk[W]; DevBuf<uint32_t> nc;
+        for (int j = 0; j < W; j++) {
+            if (int rc = nk[j].alloc(n, err)) return rc;
+            if (n) HIPCHK(hipMemcpyAsync(nk[j].p, keys_soa[j], n * 8, hipMemcpyDeviceToDevice, stream_));
+        }
+        if (int rc = nc.alloc(n, err)) return rc;
+        if (n) HIPCHK(hipMemcpyAsync(nc.p, cnt, n * 4, hipMemcpyDeviceToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        for (int j = 0; j < W; j++) skeys_[j].swap(nk[j]);
+        scnt_.swap(nc);
+        n_solid_ = n; total_instances_ = total_instances; n_distinct_ = 0;
+        for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
+        graph_ready_ = false;
+        return 0;
     }
 
     // ---- graph -----------------------------------------------------------------------------
@@ -1206,7 +1317,7 @@ public:
         // count table is no longer needed once the solid set exists
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
-        recs_.release(); fill_.release();
+        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr;
         gt_slots_ = 1ull << 10;
         while (gt_slots_ < 2 * n + 16) gt_slots_ <<= 1;
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
@@ -1527,6 +1638,9 @@ private:
     bool have_parts_ = false;
     PartParams pp_{};
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
+    DevBuf<unsigned long long> run_off_; DevBuf<uint32_t> run_cnt_;
+    RunView run_view_{}; uint32_t n_count_parts_ = 0; uint32_t forced_P_ = 0;
+    const void *shard_recv_ = nullptr;
     DevBuf<uint64_t> ekeys_[W]; DevBuf<uint32_t> ecnt_;
     uint64_t n_emitted_ = 0; uint32_t emit_threshold_ = 0;
     // solid set / graph

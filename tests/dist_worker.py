@@ -1,0 +1,83 @@
+"""Worker for the multi-process tests (launched with torch.distributed.run).
+
+mode "plan": CPU only — exercises plan_exchange + the record exchange with tagged fake records.
+mode "gpu" : every rank drives the real HIP path on cuda:0 (ranks share the one GPU of the test
+             box; collectives go through gloo with host staging) and rank 0 writes the result.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, out_path = sys.argv[1], sys.argv[2]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from sparrowhawk_amd.dist import Comm, plan_exchange, choose_partitions
+
+    if mode == "plan":
+        comm = Comm(device=torch.device("cpu"))
+        P = 64
+        rng = np.random.default_rng(100 + rank)
+        part = rng.integers(0, 40, P).astype(np.uint64)
+        part[rng.integers(0, P, 5)] = 0
+        allp = comm.all_gather_u64(part)
+        plan = plan_exchange(allp, rank)
+        # fake 16-byte records tagged (src, partition, index)
+        recs = np.zeros((int(part.sum()), 2), dtype=np.uint64)
+        for p in range(P):
+            b = int(plan["base"][p])
+            for i in range(int(part[p])):
+                recs[b + i] = (rank << 32 | p, i)
+        send = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy())
+        recv = comm.all_to_all_bytes(send, plan["send_counts"] * 16, plan["recv_counts"] * 16)
+        got = recv.numpy().view(np.uint64).reshape(-1, 2)
+        ok = True
+        for j, p in enumerate(plan["owned"]):
+            for s in range(world):
+                o, c = int(plan["run_off"][j, s]), int(plan["run_cnt"][j, s])
+                assert c == int(allp[s, p])
+                blk = got[o:o + c]
+                ok &= bool((blk[:, 0] == (s << 32 | int(p))).all() and (blk[:, 1] == np.arange(c)).all())
+        ok &= int(plan["recv_counts"].sum()) == got.shape[0]
+        tot = comm.all_reduce_u64(np.array([got.shape[0]], dtype=np.uint64))[0]
+        ok &= int(tot) == int(allp.sum())
+        res = {"ok": bool(ok), "rank": rank, "P": choose_partitions(10 ** 9, world)}
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(res, f)
+    else:
+        from sparrowhawk_amd import AssemblyHelper, pack_fastq
+        from sparrowhawk_amd.dist import sharded_preprocess
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        comm = Comm(device=dev)
+        cfg = json.load(open(sys.argv[3]))
+        fq = open(cfg["fastq"], "rb").read()
+        k = cfg["k"]
+        # this rank's share of the reads: records rank, rank+world, ...
+        recs = fq.decode().split("@r")[1:]
+        mine = ("@r" + "@r".join(recs[rank::world])).encode() if recs[rank::world] else b""
+        bases, seg, nb, nr = pack_fastq(mine, k, cfg["min_qual"])
+        d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+        d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+        h = AssemblyHelper.new(k, True, cfg["min_count"], cfg["min_qual"], 0, False, cfg["do_fit"], False, False)
+        info = sharded_preprocess(h, d_bases, d_seg, len(seg) - 1, nb, nr, comm, n_partitions=cfg.get("P"))
+        h.assemble()
+        res = {"pre": h.get_preprocessing_info(), "asm": h.get_assembly(), "info": info, "states": h.states,
+               "total_instances": h.total_instances}
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(res, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
