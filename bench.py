@@ -23,13 +23,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def make_reads_on_device(torch, dev, genome_len, coverage, read_len, seed):
+def make_reads_on_device(torch, dev, genome_len, coverage, read_len, seed, read_seed=None, n_reads=None):
     """Synthetic isolate + error-free reads, generated and 2-bit packed on the GPU (SURVEY §8d cfg 2).
     Returns (d_bases int32[words], d_seg_off int32[n_reads+1], n_reads, n_bases, genome codes)."""
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    n_reads = (genome_len * coverage + read_len - 1) // read_len
+    if n_reads is None:
+        n_reads = (genome_len * coverage + read_len - 1) // read_len
     genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.int32)
+    if read_seed is not None:
+        g.manual_seed(read_seed)
     n_bases = n_reads * read_len
     n_words = (n_bases + 15) // 16 + 1
     words = torch.zeros(n_words, dtype=torch.int32, device=dev)
@@ -88,6 +91,13 @@ def main():
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--min-count", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "the N>1 code path on a one-GPU box together with --one-gpu)")
+    ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--mode", choices=["isolates", "sharded"], default="isolates",
+                    help="N>1: 'isolates' = every rank assembles its own isolate (independent objects, no "
+                         "data-path collective); 'sharded' = ONE pooled sample of N isolates, k-mer space "
+                         "partitioned across ranks with one RCCL all-to-all (sparrowhawk_amd/dist.py)")
     args = ap.parse_args()
 
     import torch                                         # before libshk_hip.so: one HIP runtime
@@ -99,24 +109,41 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if args.one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from sparrowhawk_amd import AssemblyHelper, _lib
     import ctypes
     L = _lib.load()
     raw_get_assembly = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)(("shk_get_assembly", L))
 
-    # every rank owns one isolate of the batch (independent objects: no data-path collective)
-    d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
-        torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
+    sharded = world > 1 and args.mode == "sharded"
+    if sharded:
+        # one pooled sample: N isolates, every rank holds an equal share of reads drawn from all of them
+        from sparrowhawk_amd.dist import Comm, sharded_preprocess
+        comm = Comm(device=dev)
+        d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
+            torch, dev, args.genome * world, args.coverage, args.read_len, 0xEC02, read_seed=0x5EED + rank,
+            n_reads=(args.genome * args.coverage + args.read_len - 1) // args.read_len)
+    else:
+        # every rank owns one isolate of the batch (independent objects: no data-path collective)
+        d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
+            torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
 
     def one_step(keep=False):
         h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
-        h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
+        if sharded:
+            sharded_preprocess(h, d_bases, d_seg, n_reads, n_bases, n_reads, comm)
+        else:
+            h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
         h.assemble()
         # the JSON (contigs as FASTA/GFA/DOT) is on the host now; take the pointer without making
         # a Python copy of ~15 MB inside the timed region (copied once, after timing, for checking)
@@ -146,7 +173,7 @@ def main():
     dt = time.perf_counter() - t0
     out, _, _ = one_step(keep=True)                      # untimed: fetch the result for checking
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -155,7 +182,7 @@ def main():
     ncontigs = res["ncontigs"]
     # closed-form check of the last result: error-free reads of a repeat-free isolate
     # give one contig that is a substring of the genome (up to strand), ends trimmed by the filter
-    if args.coverage >= 30 and ncontigs == 1:
+    if args.coverage >= 30 and ncontigs == 1 and not sharded:
         contig = res["outfasta"].split("\n")[1]
         gs = "".join("ACGT"[int(c)] for c in genome.cpu().tolist()) if args.genome <= 20_000_000 else None
         if gs is not None:
@@ -179,7 +206,9 @@ def main():
         "config": {"workload": f"{args.genome} bp isolate per GPU, {args.coverage}x {args.read_len} bp reads "
                                f"({n_reads} reads, {n_bases} bases per GPU), k={args.k}, min_count={args.min_count}, "
                                f"error-free, packed 2-bit in HBM",
-                   "parallelism": "one isolate per rank, no data-path collective" if world > 1 else "single GPU",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "one pooled sample, k-mer space sharded by minimiser partition, one RCCL all-to-all"
+                                   if sharded else "one isolate per rank (batch of isolates), no data-path collective"),
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": "k_count_partitions", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,

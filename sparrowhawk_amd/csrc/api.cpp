@@ -90,6 +90,7 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
 
 void shk_free(shk_handle *h) {
     if (!h) return;
+    give_big_string(std::move(h->asm_json));
     delete h->pipe;
     delete h;
 }

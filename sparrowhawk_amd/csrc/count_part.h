@@ -83,13 +83,29 @@ __device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t
     }
 }
 
+static constexpr uint32_t DESC_CHUNK = 128;          // descriptors a wave reserves at a time
+static constexpr uint32_t DESC_NONE = 0xFFFFFFFFu;
+
+// Descriptor list: each wave reserves DESC_CHUNK entries with one LDS atomic and then fills them
+// with a wave-local counter (ballot + popcount), so the per-step append has no LDS round trip.
+// Unused entries of a chunk hold DESC_NONE.
+struct WaveChunk { uint32_t base, used; };
+
+__device__ __forceinline__ void chunk_close(PartShared &sh, WaveChunk &wc, int lane) {
+    // invalidate what is left of the wave's current chunk
+    for (uint32_t i = wc.used + (uint32_t)lane; i < DESC_CHUNK; i += 64) sh.desc_a[wc.base + i] = DESC_NONE;
+    wc.used = DESC_CHUNK;
+}
+
 template <int RW>
 __device__ __noinline__ void part_flush(PartShared &sh, const PartParams &pp, uint32_t g,
-                                        uint64_t *__restrict__ recs) {
+                                        uint64_t *__restrict__ recs, WaveChunk &wc) {
+    if (wc.used < DESC_CHUNK) chunk_close(sh, wc, threadIdx.x & 63);
     __syncthreads();
     const uint32_t n = sh.desc_count;
     for (uint32_t d = threadIdx.x; d < n; d += PART_THREADS) {
         const uint32_t a = sh.desc_a[d];
+        if (a == DESC_NONE) continue;
         const uint32_t p = sh.desc_p[d];
         const uint32_t idx = atomicAdd(&sh.cursor[p], 1u);          // LDS cursor of slice [p][g]
         if (idx < pp.slice_cap) {
@@ -119,6 +135,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     // cursors continue where an earlier batch left this workgroup's slices
     for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) sh.cursor[p] = fill[(uint64_t)p * pp.G + g];
     if (threadIdx.x == 0) sh.desc_count = 0;
+    WaveChunk wc{0u, DESC_CHUNK};                      // no chunk yet
     // pre-rotated ntHash seeds for the m-mer window (SPEC S3)
     const uint64_t so0 = rol64(SHK_NT_A, (unsigned)m), so1 = rol64(SHK_NT_C, (unsigned)m),
                    so2 = rol64(SHK_NT_G, (unsigned)m), so3 = rol64(SHK_NT_T, (unsigned)m);
@@ -157,15 +174,19 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             const uint32_t maxL = sh.max_len;
 
             // ---- per-lane walk; every lane runs the same (block, t) schedule -------------------
+            // Bases come from 64-bit windows loaded at uniform points (a block of WBLK <= 16 bases
+            // spans at most two packed words), never from per-lane reloads inside the step loop.
+            auto window = [&](uint32_t pos) -> uint64_t {
+                const uint32_t wi = min(pos >> 4, (uint32_t)(STAGE_WORDS + 14));
+                return (uint64_t)sh.stage[wi] | ((uint64_t)sh.stage[wi + 1] << 32);
+            };
             NtState nt{0, 0};
-            uint32_t lead = 0, trail = 0;
             // prologue: bases 0 .. m-2
-            for (int j = 0; j < m - 1; j++) {
-                if ((uint32_t)j < L) {
-                    const uint32_t pos = rel + (uint32_t)j;
-                    if (j == 0 || (pos & 15u) == 0) lead = sh.stage[pos >> 4];
-                    nt_init_step(nt, (lead >> (2 * (pos & 15u))) & 3u, (unsigned)j);
-                }
+            for (int jb = 0; jb < m - 1; jb += 16) {
+                const uint64_t wv = window(rel + (uint32_t)jb);
+                const uint32_t s0 = 2u * ((rel + (uint32_t)jb) & 15u);
+                for (int t = 0; t < 16 && jb + t < m - 1; t++)
+                    if ((uint32_t)(jb + t) < L) nt_init_step(nt, (uint32_t)(wv >> (s0 + 2 * t)) & 3u, (unsigned)(jb + t));
             }
             uint32_t hreg[WBLK], sreg[WBLK];
 #pragma unroll
@@ -174,24 +195,29 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
             const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
             for (uint32_t bq = 0; bq < n_blocks; bq++) {
-                // keep room for this block's descriptors (uniform decision)
-                // (the OR over all threads sees the count after every wave finished the previous block)
-                if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (WBLK + 1))))
-                    part_flush<RW>(sh, pp, g, recs);
+                // keep room for this block's descriptors (uniform decision; the OR over all threads
+                // sees the count after every wave finished the previous block)
+                if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (WBLK + 1) - 8 * DESC_CHUNK)))
+                    part_flush<RW>(sh, pp, g, recs, wc);
+                const uint32_t j0 = bq * WBLK + (uint32_t)m - 1u;          // base completing m-mer q at t = 0
+                const uint64_t lead = window(rel + j0);
+                const uint32_t ls = 2u * ((rel + j0) & 15u);
+                // the base leaving the m-window at step t is base j-m; in block 0 that is base t-1
+                // (steps t >= 1 only), so its window starts at the segment start, one step late
+                const uint32_t tpos = bq == 0 ? rel : rel + j0 - (uint32_t)m;
+                const int tadj = bq == 0 ? -1 : 0;
+                const uint64_t trail = window(tpos);
+                const uint32_t ts = 2u * (tpos & 15u);
                 uint32_t pm = 0xFFFFFFFFu;
 #pragma unroll
                 for (int t = 0; t < WBLK; t++) {
-                    const uint32_t j = bq * WBLK + (uint32_t)t + (uint32_t)m - 1u;     // base completing m-mer q
+                    const uint32_t j = j0 + (uint32_t)t;
                     uint32_t h = 0xFFFFFFFFu;
                     const bool have = j < L;
                     if (have) {
-                        const uint32_t pos = rel + j;
-                        if (j == 0 || (pos & 15u) == 0) lead = sh.stage[pos >> 4];
-                        const uint32_t b = (lead >> (2 * (pos & 15u))) & 3u;
+                        const uint32_t b = (uint32_t)(lead >> (ls + 2 * t)) & 3u;
                         if (j >= (uint32_t)m) {
-                            const uint32_t tpos = pos - (uint32_t)m;
-                            if (j == (uint32_t)m || (tpos & 15u) == 0) trail = sh.stage[tpos >> 4];
-                            const uint32_t out = (trail >> (2 * (tpos & 15u))) & 3u;
+                            const uint32_t out = (uint32_t)(trail >> (ts + 2 * (t + tadj))) & 3u;
                             nt.fh = rol64(nt.fh, 1) ^ sel4(out, so0, so1, so2, so3) ^ nt_seed(b);
                             nt.rh = ror64(nt.rh, 1) ^ sel4(out, ro0, ro1, ro2, ro3) ^ sel4(b, ri0, ri1, ri2, ri3);
                         } else {
@@ -209,16 +235,20 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                     const bool cut = valid && run_len > 0 && (p != run_p || run_len >= pp.max_n);
                     const unsigned long long em = __ballot(cut);
                     if (em) {
-                        uint32_t base = 0;
-                        const int leader = __ffsll((long long)em) - 1;
-                        if (lane == leader) base = atomicAdd(&sh.desc_count, (uint32_t)__popcll(em));
-                        base = __shfl(base, leader);
+                        const uint32_t c = (uint32_t)__popcll(em);
+                        if (wc.used + c > DESC_CHUNK) {                     // wave-uniform
+                            if (wc.used < DESC_CHUNK) chunk_close(sh, wc, lane);
+                            uint32_t nb = 0;
+                            if (lane == 0) nb = atomicAdd(&sh.desc_count, DESC_CHUNK);
+                            wc.base = __shfl(nb, 0); wc.used = 0;
+                        }
                         if (cut) {
-                            const uint32_t d = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                            const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
                             sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
                             sh.desc_p[d] = (uint16_t)run_p;
                             run_len = 0;
                         }
+                        wc.used += c;
                     }
                     if (valid) {
                         if (run_len == 0) { run_start = i; run_p = p; }
@@ -235,18 +265,22 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 const bool cut = run_len > 0;
                 const unsigned long long em = __ballot(cut);
                 if (em) {
-                    uint32_t base = 0;
-                    const int leader = __ffsll((long long)em) - 1;
-                    if (lane == leader) base = atomicAdd(&sh.desc_count, (uint32_t)__popcll(em));
-                    base = __shfl(base, leader);
+                    const uint32_t c = (uint32_t)__popcll(em);
+                    if (wc.used + c > DESC_CHUNK) {
+                        if (wc.used < DESC_CHUNK) chunk_close(sh, wc, lane);
+                        uint32_t nb = 0;
+                        if (lane == 0) nb = atomicAdd(&sh.desc_count, DESC_CHUNK);
+                        wc.base = __shfl(nb, 0); wc.used = 0;
+                    }
                     if (cut) {
-                        const uint32_t d = base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+                        const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
                         sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
                         sh.desc_p[d] = (uint16_t)run_p;
                     }
+                    wc.used += c;
                 }
             }
-            part_flush<RW>(sh, pp, g, recs);          // the stage is about to be replaced
+            part_flush<RW>(sh, pp, g, recs, wc);      // the stage is about to be replaced
             first += cnt;
         }
     }
@@ -258,7 +292,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 template <int W> struct CountShared;
 template <> struct CountShared<1> {
     static constexpr uint32_t S = 12288;                // 12 B / slot -> 144 KB
-    uint64_t key0[S];
+    static constexpr uint32_t NB = S / 4;               // buckets of 4 keys = two ds_read_b128
+    __attribute__((aligned(16))) uint64_t key0[S];
     uint32_t cnt[S];
 };
 template <> struct CountShared<2> {
@@ -297,19 +332,32 @@ template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) 
 template <int W>
 __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h) {
     constexpr uint32_t S = CountShared<W>::S;
-    uint32_t slot = (uint32_t)(((uint64_t)h * S) >> 32);
     if constexpr (W == 1) {
-        for (uint32_t probes = 0; probes < S; probes++) {
-            unsigned long long cur = tb.key0[slot];
-            if (cur == ~0ull) {
-                cur = atomicCAS((unsigned long long *)&tb.key0[slot], ~0ull, (unsigned long long)key.w[0]);
-                if (cur == ~0ull) { atomicAdd(&ctl.n_used, 1u); cur = key.w[0]; }
+        // 4-way buckets: the whole bucket comes back from one pair of 16-byte LDS reads, so a hit
+        // (the common case at >1x coverage) costs one LDS round trip instead of a serial probe chain.
+        // A key lives in the first bucket of its probe sequence that had a free slot when it arrived;
+        // slots never change once written, so "bucket has a free slot and no match" proves absence.
+        constexpr uint32_t NB = CountShared<1>::NB;
+        uint32_t b = (uint32_t)(((uint64_t)h * NB) >> 32);
+        const unsigned long long kk = key.w[0];
+        for (uint32_t probes = 0; probes < NB;) {
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tb.key0[4 * b]);
+            const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(&tb.key0[4 * b + 2]);
+            int j = a.x == kk ? 0 : a.y == kk ? 1 : c.x == kk ? 2 : c.y == kk ? 3 : -1;
+            if (j < 0) {
+                const int e = a.x == ~0ull ? 0 : a.y == ~0ull ? 1 : c.x == ~0ull ? 2 : c.y == ~0ull ? 3 : -1;
+                if (e < 0) { b = b + 1 == NB ? 0 : b + 1; probes++; continue; }      // bucket full
+                const unsigned long long old = atomicCAS((unsigned long long *)&tb.key0[4 * b + e], ~0ull, kk);
+                if (old == ~0ull) { atomicAdd(&ctl.n_used, 1u); j = e; }
+                else if (old == kk) j = e;
+                else continue;                              // lost the slot to another key: look again
             }
-            if (cur == key.w[0]) { atomicAdd(&tb.cnt[slot], 1u); return true; }
-            slot = slot + 1 == S ? 0 : slot + 1;
+            atomicAdd(&tb.cnt[4 * b + j], 1u);
+            return true;
         }
         return false;
     } else {
+        uint32_t slot = (uint32_t)(((uint64_t)h * S) >> 32);
         uint32_t probes = 0;
         for (;;) {
             uint32_t st = __hip_atomic_load(&tb.state[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -445,22 +493,28 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         __syncthreads();
 
         unsigned long long mine = 0;
-        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
-            const uint32_t r = r0 + threadIdx.x;
-            uint32_t n = 0;
-            Rec<RW> rec;
-            if (r < R) {
-                // slice g with pre[g] <= r < pre[g+1]
-                uint32_t lo = 0, hi = S_runs;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
-                const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
+        // the record of the NEXT batch is requested before the current one is expanded, so its
+        // HBM/L2 latency hides behind ~n*60 instructions of work
+        auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
+            if (r >= R) return 0u;
+            uint32_t lo = 0, hi = S_runs;                   // run with pre[lo] <= r < pre[lo+1]
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
+            const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
 #pragma unroll
-                for (int o = 0; o < RW; o += 2) {
-                    const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
-                    rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
-                }
-                n = (uint32_t)(rec.w[RW - 1] >> 58) + 1u;
+            for (int o = 0; o < RW; o += 2) {
+                const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
+                rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
             }
+            return 1u;
+        };
+        Rec<RW> nxt;
+#pragma unroll
+        for (int o = 0; o < RW; o++) nxt.w[o] = 0;
+        uint32_t have_nxt = fetch(threadIdx.x, nxt);
+        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
+            Rec<RW> rec = nxt;
+            const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
+            have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
             // Window s of the record (little-endian 2-bit) read as an integer IS the reverse
             // complement k-mer, complemented: rc = ~(rec >> 2s) & mask.  The forward k-mer is its
             // revcomp once, then rolls.  No priming over the first k-1 bases.

@@ -18,5 +18,7 @@ struct AssemblyText {
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out);
 std::string preprocessing_json(uint64_t nkmers, const uint64_t *histo500, uint32_t used_min_count);
 void json_escape_into(std::string &dst, const std::string &s);
+std::string take_big_string();
+void give_big_string(std::string &&s);
 
 }  // namespace shk

@@ -38,7 +38,7 @@ namespace shk {
 static constexpr uint32_t NIL = 0xFFFFFFFFu;
 static constexpr uint64_t EMPTY64 = ~0ull;
 static constexpr int MAX_PROBE = 4096;
-static constexpr int SPLIT_LOG = 6;            // one splitter every ~64 oriented nodes
+static constexpr int SPLIT_LOG_DEFAULT = 5;    // one sampled splitter every ~32 oriented nodes
 
 // ------------------------------------------------------------------------------------------
 // device-side views
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_
                                                         uint8_t *__restrict__ flags,
                                                         uint32_t *__restrict__ spl,
                                                         uint32_t *__restrict__ owner,
-                                                        unsigned int *__restrict__ n_spl) {
+                                                        unsigned int *__restrict__ n_spl, uint32_t split_mask) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t blk_base;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_
         if (v < total && alive[v >> 1]) {
             const bool head = succ[v ^ 1u] == NIL;
             const uint64_t h = km_hash<W>(g.keys.load(v >> 1)) + (uint64_t)(v & 1u) * 0x9E3779B97F4A7C15ull;
-            const bool samp = ((h >> 17) & ((1u << SPLIT_LOG) - 1u)) == 0;
+            const bool samp = ((h >> 17) & split_mask) == 0;
             p = head || samp;
             f = (uint8_t)((p ? 1 : 0) | (head ? 2 : 0));
         }
@@ -1004,7 +1004,7 @@ public:
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
         uint32_t P = 64;
-        const uint64_t per_part = env_u64("SHK_PART_INST", 400000);
+        const uint64_t per_part = env_u64("SHK_PART_INST", 200000);
         while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
         if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
         if (forced_P_) P = forced_P_;
@@ -1472,7 +1472,8 @@ public:
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p);
         hipLaunchKernelGGL(k_mark_splitters<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p,
-                           flags.p, spl.p, owner.p, (unsigned int *)(ctl_.p + 5));
+                           flags.p, spl.p, owner.p, (unsigned int *)(ctl_.p + 5),
+                           (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1559,11 +1560,10 @@ public:
             times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
         }
         // ---- circular unitigs (no head): rare; resolved on the host from succ[] (SPEC S10)
-        std::vector<uint8_t> halive(n);
-        HIPCHK(hipMemcpy(halive.data(), alive_.p, n, hipMemcpyDeviceToHost));
-        uint64_t n_alive = 0;
-        for (uint32_t i = 0; i < n; i++) n_alive += halive[i];
+        const uint64_t n_alive = (uint64_t)n - tips_removed_ - bubbles_removed_;
         if (covered != 2 * n_alive) {
+            std::vector<uint8_t> halive(n);
+            HIPCHK(hipMemcpy(halive.data(), alive_.p, n, hipMemcpyDeviceToHost));
             auto tc0 = std::chrono::steady_clock::now();
             std::vector<uint32_t> hsucc(total), howner(total), hcnt(n);
             std::vector<uint64_t> hkeys((size_t)n * W);
