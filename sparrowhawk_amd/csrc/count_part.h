@@ -24,10 +24,10 @@
 
 namespace shk {
 
-static constexpr int PART_THREADS = 512;
+static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
 static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
 static constexpr int PART_MAX_P = 4096;
-static constexpr int STAGE_WORDS = 8192;             // 131072 bases of a read tile in LDS
+static constexpr int STAGE_WORDS = 10240;            // 163840 bases of a read tile in LDS
 static constexpr int DESC_CAP = 16384;
 static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
 
@@ -49,9 +49,10 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 // ---- pass 1 -------------------------------------------------------------------------------
 struct PartShared {
     uint32_t stage[STAGE_WORDS + 16];
-    uint32_t desc_a[DESC_CAP];        // tile-relative base offset (17 bits) | (n-1) << 17
+    uint32_t desc_a[DESC_CAP];        // tile-relative base offset (18 bits) | (n-1) << 18
     uint16_t desc_p[DESC_CAP];
     uint32_t cursor[PART_MAX_P];
+    ulonglong2 nt_lut[16];            // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1)
     uint32_t desc_count;
     uint32_t max_len;
 };
@@ -110,7 +111,7 @@ __device__ __noinline__ void part_flush(PartShared &sh, const PartParams &pp, ui
         const uint32_t idx = atomicAdd(&sh.cursor[p], 1u);          // LDS cursor of slice [p][g]
         if (idx < pp.slice_cap) {
             uint64_t *dst = recs + (((uint64_t)p * pp.G + g) * pp.slice_cap + idx) * RW;
-            part_write_record<RW>(sh, a & 0x1FFFFu, (a >> 17) + 1u, pp.k, dst);
+            part_write_record<RW>(sh, a & 0x3FFFFu, (a >> 18) + 1u, pp.k, dst);
         }
     }
     __syncthreads();
@@ -136,13 +137,15 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) sh.cursor[p] = fill[(uint64_t)p * pp.G + g];
     if (threadIdx.x == 0) sh.desc_count = 0;
     WaveChunk wc{0u, DESC_CHUNK};                      // no chunk yet
-    // pre-rotated ntHash seeds for the m-mer window (SPEC S3)
-    const uint64_t so0 = rol64(SHK_NT_A, (unsigned)m), so1 = rol64(SHK_NT_C, (unsigned)m),
-                   so2 = rol64(SHK_NT_G, (unsigned)m), so3 = rol64(SHK_NT_T, (unsigned)m);
-    const uint64_t ro0 = ror64(SHK_NT_T, 1), ro1 = ror64(SHK_NT_G, 1), ro2 = ror64(SHK_NT_C, 1),
-                   ro3 = ror64(SHK_NT_A, 1);
-    const uint64_t ri0 = rol64(SHK_NT_T, (unsigned)(m - 1)), ri1 = rol64(SHK_NT_G, (unsigned)(m - 1)),
-                   ri2 = rol64(SHK_NT_C, (unsigned)(m - 1)), ri3 = rol64(SHK_NT_A, (unsigned)(m - 1));
+    // ntHash roll terms (SPEC S3) for every (outgoing, incoming) base pair: 16 x 16 B in LDS, one
+    // conflict-free ds_read_b128 per step instead of three 4-way register selects
+    if (threadIdx.x < 16) {
+        const uint32_t out = threadIdx.x >> 2, in = threadIdx.x & 3u;
+        ulonglong2 v;
+        v.x = rol64(nt_seed(out), (unsigned)m) ^ nt_seed(in);
+        v.y = ror64(nt_seed(3u - out), 1) ^ rol64(nt_seed(3u - in), (unsigned)(m - 1));
+        sh.nt_lut[threadIdx.x] = v;
+    }
     __syncthreads();
 
     for (uint32_t st = g * PART_THREADS; st < n_seg; st += gridDim.x * PART_THREADS) {
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 return (uint64_t)sh.stage[wi] | ((uint64_t)sh.stage[wi + 1] << 32);
             };
             NtState nt{0, 0};
-            // prologue: bases 0 .. m-2
-            for (int jb = 0; jb < m - 1; jb += 16) {
+            // prologue: the first m-mer (bases 0 .. m-1)
+            for (int jb = 0; jb < m; jb += 16) {
                 const uint64_t wv = window(rel + (uint32_t)jb);
                 const uint32_t s0 = 2u * ((rel + (uint32_t)jb) & 15u);
-                for (int t = 0; t < 16 && jb + t < m - 1; t++)
-                    if ((uint32_t)(jb + t) < L) nt_init_step(nt, (uint32_t)(wv >> (s0 + 2 * t)) & 3u, (unsigned)(jb + t));
+                for (int t = 0; t < 16 && jb + t < m; t++)
+                    nt_init_step(nt, (uint32_t)(wv >> (s0 + 2 * t)) & 3u, (unsigned)(jb + t));
             }
             uint32_t hreg[WBLK], sreg[WBLK];
 #pragma unroll
@@ -194,36 +197,35 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             uint32_t run_start = 0, run_len = 0, run_p = 0;
             const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
             const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
+            constexpr int CHECK_EVERY = 8;                  // descriptor-room check twice per 16-step block
             for (uint32_t bq = 0; bq < n_blocks; bq++) {
-                // keep room for this block's descriptors (uniform decision; the OR over all threads
-                // sees the count after every wave finished the previous block)
-                if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (WBLK + 1) - 8 * DESC_CHUNK)))
-                    part_flush<RW>(sh, pp, g, recs, wc);
-                const uint32_t j0 = bq * WBLK + (uint32_t)m - 1u;          // base completing m-mer q at t = 0
-                const uint64_t lead = window(rel + j0);
-                const uint32_t ls = 2u * ((rel + j0) & 15u);
-                // the base leaving the m-window at step t is base j-m; in block 0 that is base t-1
-                // (steps t >= 1 only), so its window starts at the segment start, one step late
-                const uint32_t tpos = bq == 0 ? rel : rel + j0 - (uint32_t)m;
-                const int tadj = bq == 0 ? -1 : 0;
-                const uint64_t trail = window(tpos);
-                const uint32_t ts = 2u * (tpos & 15u);
+                const uint32_t q0 = bq * WBLK;                             // first m-mer of the block
+                // the state holds m-mer q; after using it, base q leaves and base q+m enters
+                const uint64_t trail = window(rel + q0);
+                const uint32_t ts = 2u * ((rel + q0) & 15u);
+                const uint64_t lead = window(rel + q0 + (uint32_t)m);
+                const uint32_t ls = 2u * ((rel + q0 + (uint32_t)m) & 15u);
                 uint32_t pm = 0xFFFFFFFFu;
 #pragma unroll
                 for (int t = 0; t < WBLK; t++) {
-                    const uint32_t j = j0 + (uint32_t)t;
-                    uint32_t h = 0xFFFFFFFFu;
+                    if (t % CHECK_EVERY == 0) {
+                        // keep room for the next CHECK_EVERY steps' descriptors (uniform decision; the OR
+                        // over all threads sees the count after every wave finished the previous steps)
+                        if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (CHECK_EVERY + 1) -
+                                                                        (PART_THREADS / 64) * DESC_CHUNK)))
+                            part_flush<RW>(sh, pp, g, recs, wc);
+                    }
+                    const uint32_t q = q0 + (uint32_t)t;
+                    const uint32_t j = q + (uint32_t)m - 1u;               // last base of m-mer q
                     const bool have = j < L;
-                    if (have) {
-                        const uint32_t b = (uint32_t)(lead >> (ls + 2 * t)) & 3u;
-                        if (j >= (uint32_t)m) {
-                            const uint32_t out = (uint32_t)(trail >> (ts + 2 * (t + tadj))) & 3u;
-                            nt.fh = rol64(nt.fh, 1) ^ sel4(out, so0, so1, so2, so3) ^ nt_seed(b);
-                            nt.rh = ror64(nt.rh, 1) ^ sel4(out, ro0, ro1, ro2, ro3) ^ sel4(b, ri0, ri1, ri2, ri3);
-                        } else {
-                            nt_init_step(nt, b, (unsigned)j);
-                        }
-                        h = (uint32_t)(nt_canonical(nt) >> 32);
+                    const uint32_t h = have ? (uint32_t)(nt_canonical(nt) >> 32) : 0xFFFFFFFFu;
+                    // roll to m-mer q+1 (unconditionally: a state past the segment end is never used)
+                    {
+                        const uint32_t out = (uint32_t)(trail >> (ts + 2 * t)) & 3u;
+                        const uint32_t in = (uint32_t)(lead >> (ls + 2 * t)) & 3u;
+                        const ulonglong2 term = sh.nt_lut[(out << 2) | in];
+                        nt.fh = rol64(nt.fh, 1) ^ term.x;
+                        nt.rh = ror64(nt.rh, 1) ^ term.y;
                     }
                     hreg[t] = h;
                     pm = min(pm, h);
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                         }
                         if (cut) {
                             const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                            sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
+                            sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 18);
                             sh.desc_p[d] = (uint16_t)run_p;
                             run_len = 0;
                         }
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                     }
                     if (cut) {
                         const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                        sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 17);
+                        sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 18);
                         sh.desc_p[d] = (uint16_t)run_p;
                     }
                     wc.used += c;
@@ -291,10 +293,18 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 // ---- pass 2 -------------------------------------------------------------------------------
 template <int W> struct CountShared;
 template <> struct CountShared<1> {
-    static constexpr uint32_t S = 12288;                // 12 B / slot -> 144 KB
+    static constexpr uint32_t S = 5376;                 // k-mer table: 12 B / slot -> 63 KB
     static constexpr uint32_t NB = S / 4;               // buckets of 4 keys = two ds_read_b128
+    static constexpr uint32_t SR = 4096;                // record table: 20 B / slot -> 80 KB
     __attribute__((aligned(16))) uint64_t key0[S];
     uint32_t cnt[S];
+    // record-level dedupe (phase A): whole super-k-mer records with a multiplicity.
+    // rst: 0 empty, 1 being written, >= 3 ready with multiplicity rst-2
+    uint64_t rlo[SR];
+    uint64_t rhi[SR];
+    uint32_t rst[SR];
+    uint16_t order[SR];                                 // occupied record slots, sorted by record length
+    uint32_t nhist[64], nbase[64];
 };
 template <> struct CountShared<2> {
     static constexpr uint32_t S = 6144;                 // 24 B / slot -> 144 KB
@@ -307,7 +317,7 @@ template <> struct CountShared<2> {
 struct CountCtl {
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
     uint32_t histo[500];
-    uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor;
+    uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor, rec_used, n_recs;
     uint32_t stack_res[32], stack_mod[32];
     unsigned long long n_inst;
 };
@@ -330,7 +340,8 @@ template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) 
 
 // insert into the LDS table; returns false when the probe sequence is exhausted
 template <int W>
-__device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h) {
+__device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h,
+                                           uint32_t weight) {
     constexpr uint32_t S = CountShared<W>::S;
     if constexpr (W == 1) {
         // 4-way buckets: the whole bucket comes back from one pair of 16-byte LDS reads, so a hit
@@ -352,7 +363,7 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
                 else if (old == kk) j = e;
                 else continue;                              // lost the slot to another key: look again
             }
-            atomicAdd(&tb.cnt[4 * b + j], 1u);
+            atomicAdd(&tb.cnt[4 * b + j], weight);
             return true;
         }
         return false;
@@ -367,15 +378,41 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
                 tb.key0[slot] = key.w[0]; tb.key1[slot] = key.w[1];
                 __hip_atomic_store(&tb.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 atomicAdd(&ctl.n_used, 1u);
-                atomicAdd(&tb.cnt[slot], 1u);
+                atomicAdd(&tb.cnt[slot], weight);
                 return true;
             }
             if (st == 1) continue;                          // owner is mid-write
-            if (tb.key0[slot] == key.w[0] && tb.key1[slot] == key.w[1]) { atomicAdd(&tb.cnt[slot], 1u); return true; }
+            if (tb.key0[slot] == key.w[0] && tb.key1[slot] == key.w[1]) { atomicAdd(&tb.cnt[slot], weight); return true; }
             slot = slot + 1 == S ? 0 : slot + 1;
             if (++probes >= S) return false;
         }
     }
+}
+
+// phase A: count a whole record; false = table saturated (the caller then expands it directly)
+__device__ __forceinline__ bool rec_insert(CountShared<1> &tb, CountCtl &ctl, uint64_t lo, uint64_t hi) {
+    constexpr uint32_t SR = CountShared<1>::SR;
+    uint32_t h = mix32((uint32_t)lo ^ __builtin_amdgcn_alignbit((uint32_t)(lo >> 32), (uint32_t)(lo >> 32), 9));
+    h = mix32(h ^ (uint32_t)hi ^ __builtin_amdgcn_alignbit((uint32_t)(hi >> 32), (uint32_t)(hi >> 32), 21));
+    uint32_t slot = (uint32_t)(((uint64_t)h * SR) >> 32);
+    for (uint32_t probes = 0; probes < 64;) {
+        uint32_t st = __hip_atomic_load(&tb.rst[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (st == 0) {
+            if (ctl.rec_used >= (SR / 8) * 7) return false;             // keep the probe chains short
+            st = atomicCAS(&tb.rst[slot], 0u, 1u);
+            if (st == 0) {
+                tb.rlo[slot] = lo; tb.rhi[slot] = hi;
+                __hip_atomic_fetch_add(&tb.rst[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 3
+                atomicAdd(&ctl.rec_used, 1u);
+                return true;
+            }
+        }
+        if (st == 1) continue;                                          // owner is mid-write
+        if (tb.rlo[slot] == lo && tb.rhi[slot] == hi) { atomicAdd(&tb.rst[slot], 1u); return true; }
+        slot = slot + 1 == SR ? 0 : slot + 1;
+        probes++;
+    }
+    return false;
 }
 
 // A partition's records arrive as S runs (local: one per producer workgroup; sharded: one per
@@ -484,11 +521,13 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         if (ctl.sp == 0) break;
         const uint32_t res = ctl.stack_res[ctl.sp - 1], mod = ctl.stack_mod[ctl.sp - 1];
         __syncthreads();
-        if (threadIdx.x == 0) { ctl.sp--; ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; }
+        if (threadIdx.x == 0) { ctl.sp--; ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0; }
         for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
             tb.cnt[s] = 0;
             if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
         }
+        if constexpr (W == 1)
+            for (uint32_t s = threadIdx.x; s < CountShared<1>::SR; s += COUNT_THREADS) tb.rst[s] = 0;
         for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
         __syncthreads();
 
@@ -507,17 +546,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             }
             return 1u;
         };
-        Rec<RW> nxt;
-#pragma unroll
-        for (int o = 0; o < RW; o++) nxt.w[o] = 0;
-        uint32_t have_nxt = fetch(threadIdx.x, nxt);
-        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
-            Rec<RW> rec = nxt;
-            const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
-            have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
-            // Window s of the record (little-endian 2-bit) read as an integer IS the reverse
-            // complement k-mer, complemented: rc = ~(rec >> 2s) & mask.  The forward k-mer is its
-            // revcomp once, then rolls.  No priming over the first k-1 bases.
+        // expand one record: window s of the record (little-endian 2-bit) read as an integer IS the
+        // reverse-complement k-mer, complemented: rc = ~(rec >> 2s) & mask.  The forward k-mer is
+        // its revcomp once, then rolls.  No priming over the first k-1 bases.  Each k-mer is
+        // added with `weight` (the multiplicity of the record).
+        auto expand = [&](Rec<RW> rec, uint32_t n, uint32_t weight) {
             Kmer<W> f = km_zero<W>();
             for (uint32_t s = 0; s < n; s++) {
                 if (s) {
@@ -537,9 +570,53 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
                 const uint32_t h = km_mix32<W>(c);
                 if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {         // sub-round filter: bits 20.. of h
-                    if (!lds_insert<W>(tb, ctl, c, h ^ (h << 13))) ctl.overflow = 1;
-                    mine++;
+                    if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), weight)) ctl.overflow = 1;
+                    mine += weight;
                 }
+            }
+        };
+        Rec<RW> nxt;
+#pragma unroll
+        for (int o = 0; o < RW; o++) nxt.w[o] = 0;
+        uint32_t have_nxt = fetch(threadIdx.x, nxt);
+        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
+            Rec<RW> rec = nxt;
+            const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
+            have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
+            if constexpr (W == 1) {
+                // phase A: identical records (the same genomic run seen in many reads) are counted
+                // once here and expanded once, with their multiplicity, in phase B
+                if (n && !rec_insert(tb, ctl, rec.w[0], rec.w[1])) expand(rec, n, 1u);
+            } else {
+                expand(rec, n, 1u);
+            }
+        }
+        if constexpr (W == 1) {
+            // phase B: every distinct record once, weighted.  The occupied slots are first listed in
+            // order of record length (counting sort in LDS) so that the 64 records a wave expands
+            // together have (nearly) the same number of k-mers: no lanes idling behind the longest.
+            constexpr uint32_t SRc = CountShared<1>::SR;
+            if (threadIdx.x < 64) tb.nhist[threadIdx.x] = 0;
+            __syncthreads();
+            for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
+                if (tb.rst[s] >= 3u) atomicAdd(&tb.nhist[(uint32_t)(tb.rhi[s] >> 58)], 1u);
+            __syncthreads();
+            if (threadIdx.x < 64) {
+                const uint32_t v = tb.nhist[threadIdx.x];
+                uint32_t incl = v;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+                tb.nbase[threadIdx.x] = incl - v;
+                if (threadIdx.x == 63) ctl.n_recs = incl;
+            }
+            __syncthreads();
+            for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
+                if (tb.rst[s] >= 3u) tb.order[atomicAdd(&tb.nbase[(uint32_t)(tb.rhi[s] >> 58)], 1u)] = (uint16_t)s;
+            __syncthreads();
+            const uint32_t n_recs = ctl.n_recs;
+            for (uint32_t i = threadIdx.x; i < n_recs; i += COUNT_THREADS) {
+                const uint32_t s = tb.order[i];
+                Rec<RW> rec; rec.w[0] = tb.rlo[s]; rec.w[1] = tb.rhi[s];
+                expand(rec, (uint32_t)(rec.w[1] >> 58) + 1u, tb.rst[s] - 2u);
             }
         }
         __syncthreads();

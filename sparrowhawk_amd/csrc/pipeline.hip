@@ -1004,12 +1004,14 @@ public:
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
         uint32_t P = 64;
-        const uint64_t per_part = env_u64("SHK_PART_INST", 200000);
+        const uint64_t per_part = env_u64("SHK_PART_INST", 100000);
         while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
         if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
         if (forced_P_) P = forced_P_;
         pp_.P = P;
-        uint64_t cap = inst_ub / (4ull * P * pp_.G) + 32;
+        // records per slice: mean run length is ~(WBLK+1)/2 k-mers (shorter if max_n caps it); 2x slack
+        const uint64_t per_rec = pp_.max_n >= 16 ? 4 : 2;
+        uint64_t cap = inst_ub / (per_rec * P * pp_.G) + 32;
         for (int attempt = 0; attempt < 2; attempt++) {
             pp_.slice_cap = (uint32_t)cap;
             const uint64_t n_slices = (uint64_t)P * pp_.G;

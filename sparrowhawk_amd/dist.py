@@ -23,7 +23,7 @@ from . import _lib
 from .helper import AssemblyHelper, ShkError
 
 
-def choose_partitions(total_instances_ub, world, per_part=200_000):
+def choose_partitions(total_instances_ub, world, per_part=100_000):
     """Power of two in [64, 4096], >= world, ~per_part k-mer instances per partition."""
     P = 64
     while P < 4096 and P * per_part < total_instances_ub:
