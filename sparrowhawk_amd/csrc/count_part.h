@@ -28,7 +28,6 @@ static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
 static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
 static constexpr int PART_MAX_P = 4096;
 static constexpr int STAGE_WORDS = 10240;            // 163840 bases of a read tile in LDS
-static constexpr int DESC_CAP = 16384;
 static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
 
 struct PartParams {
@@ -47,14 +46,24 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 }
 
 // ---- pass 1 -------------------------------------------------------------------------------
+// One 1024-thread workgroup per CU, one lane per read segment.  A tile of segments is staged in LDS
+// by coalesced dword loads; every lane then walks its segment base by base: rolling canonical
+// ntHash (32-bit state, kmer.h) of the m-mers, sliding-window minimum in registers, run detection.
+// Finished runs go to a WAVE-PRIVATE descriptor list in LDS (ballot + popcount, no atomics); a
+// wave turns its descriptors into records by itself whenever the list fills up and at the end of
+// the tile, so the walk needs no workgroup barrier (the first version shared one list and paid two
+// 16-wave barriers per 16 bases: 68 % of the wave cycles were waits, profiles/r01_s2_start).
+static constexpr int PART_WAVES = PART_THREADS / 64;
+static constexpr uint32_t WDESC_CAP = 1024;          // descriptors per wave
+static constexpr int DESC_CHECK = 4;                 // steps between room checks (64 new per step at most)
+
 struct PartShared {
     uint32_t stage[STAGE_WORDS + 16];
-    uint32_t desc_a[DESC_CAP];        // tile-relative base offset (18 bits) | (n-1) << 18
-    uint16_t desc_p[DESC_CAP];
+    uint32_t desc_a[PART_WAVES][WDESC_CAP];   // tile-relative base offset (18 bits) | (n-1) << 18
+    uint16_t desc_p[PART_WAVES][WDESC_CAP];
     uint32_t cursor[PART_MAX_P];
-    ulonglong2 nt_lut[16];            // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1)
-    uint32_t desc_count;
-    uint32_t max_len;
+    uint2 nt_lut[16];                 // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1)
+    uint32_t red[PART_WAVES];
 };
 
 // build one record from the staged tile and store it
@@ -84,39 +93,23 @@ __device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t
     }
 }
 
-static constexpr uint32_t DESC_CHUNK = 128;          // descriptors a wave reserves at a time
-static constexpr uint32_t DESC_NONE = 0xFFFFFFFFu;
-
-// Descriptor list: each wave reserves DESC_CHUNK entries with one LDS atomic and then fills them
-// with a wave-local counter (ballot + popcount), so the per-step append has no LDS round trip.
-// Unused entries of a chunk hold DESC_NONE.
-struct WaveChunk { uint32_t base, used; };
-
-__device__ __forceinline__ void chunk_close(PartShared &sh, WaveChunk &wc, int lane) {
-    // invalidate what is left of the wave's current chunk
-    for (uint32_t i = wc.used + (uint32_t)lane; i < DESC_CHUNK; i += 64) sh.desc_a[wc.base + i] = DESC_NONE;
-    wc.used = DESC_CHUNK;
-}
-
+// a wave writes the records of its own descriptor list (no workgroup barrier: the stage is read-only
+// while a tile is walked, the slice cursors are LDS atomics)
 template <int RW>
-__device__ __noinline__ void part_flush(PartShared &sh, const PartParams &pp, uint32_t g,
-                                        uint64_t *__restrict__ recs, WaveChunk &wc) {
-    if (wc.used < DESC_CHUNK) chunk_close(sh, wc, threadIdx.x & 63);
-    __syncthreads();
-    const uint32_t n = sh.desc_count;
-    for (uint32_t d = threadIdx.x; d < n; d += PART_THREADS) {
-        const uint32_t a = sh.desc_a[d];
-        if (a == DESC_NONE) continue;
-        const uint32_t p = sh.desc_p[d];
-        const uint32_t idx = atomicAdd(&sh.cursor[p], 1u);          // LDS cursor of slice [p][g]
-        if (idx < pp.slice_cap) {
-            uint64_t *dst = recs + (((uint64_t)p * pp.G + g) * pp.slice_cap + idx) * RW;
-            part_write_record<RW>(sh, a & 0x3FFFFu, (a >> 18) + 1u, pp.k, dst);
+__device__ __noinline__ void wave_flush(PartShared *sh, uint32_t wave, uint32_t wn, int k, uint32_t G,
+                                        uint32_t slice_cap, uint32_t g, uint64_t *__restrict__ recs) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t d = threadIdx.x & 63u; d < wn; d += 64) {
+        const uint32_t a = sh->desc_a[wave][d];
+        const uint32_t p = sh->desc_p[wave][d];
+        const uint32_t idx = atomicAdd(&sh->cursor[p], 1u);          // LDS cursor of slice [p][g]
+        if (idx < slice_cap) {
+            uint64_t *dst = recs + (((uint64_t)p * G + g) * slice_cap + idx) * RW;
+            part_write_record<RW>(*sh, a & 0x3FFFFu, (a >> 18) + 1u, k, dst);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) sh.desc_count = 0;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 }
 
 // W: key words (records have RW = 2W words); WBLK: k-mers per minimiser window block (= w)
@@ -128,22 +121,24 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                                                             uint32_t *__restrict__ fill,
                                                             uint32_t *__restrict__ flags) {
     constexpr int RW = 2 * W;
+    static_assert(WBLK <= 16 && WBLK % 2 == 0, "a block of m-mers must fit one 32-bit window");
     __shared__ PartShared sh;
     const uint32_t g = blockIdx.x;
     const int lane = threadIdx.x & 63;
+    const uint32_t wave = threadIdx.x >> 6;
     const int k = pp.k, m = pp.m;
     const uint32_t pmask = pp.P - 1u;
+    const uint32_t max_n = pp.max_n;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // cursors continue where an earlier batch left this workgroup's slices
     for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) sh.cursor[p] = fill[(uint64_t)p * pp.G + g];
-    if (threadIdx.x == 0) sh.desc_count = 0;
-    WaveChunk wc{0u, DESC_CHUNK};                      // no chunk yet
-    // ntHash roll terms (SPEC S3) for every (outgoing, incoming) base pair: 16 x 16 B in LDS, one
-    // conflict-free ds_read_b128 per step instead of three 4-way register selects
+    // ntHash roll terms (SPEC S3) for every (outgoing, incoming) base pair: 16 x 8 B in LDS, one
+    // ds_read_b64 per step instead of three 4-way register selects
     if (threadIdx.x < 16) {
         const uint32_t out = threadIdx.x >> 2, in = threadIdx.x & 3u;
-        ulonglong2 v;
-        v.x = rol64(nt_seed(out), (unsigned)m) ^ nt_seed(in);
-        v.y = ror64(nt_seed(3u - out), 1) ^ rol64(nt_seed(3u - in), (unsigned)(m - 1));
+        uint2 v;
+        v.x = rol32(nt32_seed(out), (unsigned)m) ^ nt32_seed(in);
+        v.y = ror32(nt32_seed(3u - out), 1) ^ rol32(nt32_seed(3u - in), (unsigned)(m - 1));
         sh.nt_lut[threadIdx.x] = v;
     }
     __syncthreads();
@@ -162,70 +157,69 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 first += cnt;
                 continue;
             }
+            __syncthreads();                                 // every wave is done with the previous tile
             // coalesced load of the tile's words into LDS (one dword per lane per pass)
             for (uint32_t i = threadIdx.x; i < nwords + 8; i += PART_THREADS)
                 sh.stage[i] = (i < nwords + 1) ? bases[w0 + i] : 0u;     // +1: the spare word
-            if (threadIdx.x == 0) sh.max_len = 0;
-            __syncthreads();
             uint32_t L = 0, rel = 0;
             if (threadIdx.x < cnt) {
                 const uint32_t s0 = seg_off[first + threadIdx.x], s1 = seg_off[first + threadIdx.x + 1];
                 L = s1 - s0; rel = s0 - (w0 << 4);
             }
-            atomicMax(&sh.max_len, L);
+            uint32_t maxL = L;                               // over the wave
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, o));
+            maxL = __builtin_amdgcn_readfirstlane(maxL);
             __syncthreads();
-            const uint32_t maxL = sh.max_len;
 
-            // ---- per-lane walk; every lane runs the same (block, t) schedule -------------------
-            // Bases come from 64-bit windows loaded at uniform points (a block of WBLK <= 16 bases
-            // spans at most two packed words), never from per-lane reloads inside the step loop.
-            auto window = [&](uint32_t pos) -> uint64_t {
+            // ---- per-lane walk; every lane of the wave runs the same (block, t) schedule ----------
+            // Bases come from 64-bit windows loaded once per block (a block of WBLK <= 16 bases spans
+            // at most two packed words), never from per-lane reloads inside the step loop.
+            auto window32 = [&](uint32_t pos) -> uint32_t {  // the 16 bases from stream position pos
                 const uint32_t wi = min(pos >> 4, (uint32_t)(STAGE_WORDS + 14));
-                return (uint64_t)sh.stage[wi] | ((uint64_t)sh.stage[wi + 1] << 32);
+                return __builtin_amdgcn_alignbit(sh.stage[wi + 1], sh.stage[wi], 2u * (pos & 15u));
             };
-            NtState nt{0, 0};
+            Nt32State nt{0, 0};
             // prologue: the first m-mer (bases 0 .. m-1)
             for (int jb = 0; jb < m; jb += 16) {
-                const uint64_t wv = window(rel + (uint32_t)jb);
-                const uint32_t s0 = 2u * ((rel + (uint32_t)jb) & 15u);
+                const uint32_t wv = window32(rel + (uint32_t)jb);
                 for (int t = 0; t < 16 && jb + t < m; t++)
-                    nt_init_step(nt, (uint32_t)(wv >> (s0 + 2 * t)) & 3u, (unsigned)(jb + t));
+                    nt32_init_step(nt, (wv >> (2 * t)) & 3u, (unsigned)(jb + t));
             }
             uint32_t hreg[WBLK], sreg[WBLK];
 #pragma unroll
             for (int t = 0; t < WBLK; t++) { hreg[t] = 0xFFFFFFFFu; sreg[t] = 0xFFFFFFFFu; }
             uint32_t run_start = 0, run_len = 0, run_p = 0;
+            uint32_t wn = 0;                                 // descriptors in this wave's list (wave-uniform)
             const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
             const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
-            constexpr int CHECK_EVERY = 8;                  // descriptor-room check twice per 16-step block
             for (uint32_t bq = 0; bq < n_blocks; bq++) {
                 const uint32_t q0 = bq * WBLK;                             // first m-mer of the block
-                // the state holds m-mer q; after using it, base q leaves and base q+m enters
-                const uint64_t trail = window(rel + q0);
-                const uint32_t ts = 2u * ((rel + q0) & 15u);
-                const uint64_t lead = window(rel + q0 + (uint32_t)m);
-                const uint32_t ls = 2u * ((rel + q0 + (uint32_t)m) & 15u);
+                // the state holds m-mer q; after using it, base q leaves and base q+m enters.
+                // zo/ze: nibble j = (outgoing << 2 | incoming) of step t = 2j+1 / 2j  -> LUT index
+                const uint32_t X = window32(rel + q0), Y = window32(rel + q0 + (uint32_t)m);
+                const uint32_t ze = ((X & 0x33333333u) << 2) | (Y & 0x33333333u);
+                const uint32_t zo = (X & 0xCCCCCCCCu) | ((Y >> 2) & 0x33333333u);
                 uint32_t pm = 0xFFFFFFFFu;
 #pragma unroll
                 for (int t = 0; t < WBLK; t++) {
-                    if (t % CHECK_EVERY == 0) {
-                        // keep room for the next CHECK_EVERY steps' descriptors (uniform decision; the OR
-                        // over all threads sees the count after every wave finished the previous steps)
-                        if (__syncthreads_or(sh.desc_count > (uint32_t)(DESC_CAP - PART_THREADS * (CHECK_EVERY + 1) -
-                                                                        (PART_THREADS / 64) * DESC_CHUNK)))
-                            part_flush<RW>(sh, pp, g, recs, wc);
+                    if (t % DESC_CHECK == 0) {
+                        if (wn > WDESC_CAP - 64u * DESC_CHECK) {            // wave-uniform
+                            wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs);
+                            wn = 0;
+                        }
                     }
                     const uint32_t q = q0 + (uint32_t)t;
                     const uint32_t j = q + (uint32_t)m - 1u;               // last base of m-mer q
                     const bool have = j < L;
-                    const uint32_t h = have ? (uint32_t)(nt_canonical(nt) >> 32) : 0xFFFFFFFFu;
+                    const uint32_t h = have ? nt32_canonical(nt) : 0xFFFFFFFFu;
                     // roll to m-mer q+1 (unconditionally: a state past the segment end is never used)
                     {
-                        const uint32_t out = (uint32_t)(trail >> (ts + 2 * t)) & 3u;
-                        const uint32_t in = (uint32_t)(lead >> (ls + 2 * t)) & 3u;
-                        const ulonglong2 term = sh.nt_lut[(out << 2) | in];
-                        nt.fh = rol64(nt.fh, 1) ^ term.x;
-                        nt.rh = ror64(nt.rh, 1) ^ term.y;
+                        const uint32_t z = (t & 1) ? zo : ze;
+                        const uint32_t idx = (z >> (4 * (t >> 1))) & 15u;
+                        const uint2 term = sh.nt_lut[idx];
+                        nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ term.x;   // rol 1
+                        nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ term.y;    // ror 1
                     }
                     hreg[t] = h;
                     pm = min(pm, h);
@@ -234,23 +228,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                     const bool valid = have && (bq > 0 || t == WBLK - 1);
                     const uint32_t i = j - (uint32_t)k + 1u;
                     const uint32_t p = kmin & pmask;
-                    const bool cut = valid && run_len > 0 && (p != run_p || run_len >= pp.max_n);
+                    const bool cut = valid && run_len > 0 && (p != run_p || run_len >= max_n);
                     const unsigned long long em = __ballot(cut);
                     if (em) {
-                        const uint32_t c = (uint32_t)__popcll(em);
-                        if (wc.used + c > DESC_CHUNK) {                     // wave-uniform
-                            if (wc.used < DESC_CHUNK) chunk_close(sh, wc, lane);
-                            uint32_t nb = 0;
-                            if (lane == 0) nb = atomicAdd(&sh.desc_count, DESC_CHUNK);
-                            wc.base = __shfl(nb, 0); wc.used = 0;
-                        }
                         if (cut) {
-                            const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                            sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 18);
-                            sh.desc_p[d] = (uint16_t)run_p;
+                            const uint32_t d = wn + (uint32_t)__popcll(em & lt_mask);
+                            sh.desc_a[wave][d] = (rel + run_start) | ((run_len - 1u) << 18);
+                            sh.desc_p[wave][d] = (uint16_t)run_p;
                             run_len = 0;
                         }
-                        wc.used += c;
+                        wn += (uint32_t)__popcll(em);
                     }
                     if (valid) {
                         if (run_len == 0) { run_start = i; run_p = p; }
@@ -264,30 +251,37 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             }
             // close the last run of every segment
             {
+                if (wn > WDESC_CAP - 64u) { wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs); wn = 0; }
                 const bool cut = run_len > 0;
                 const unsigned long long em = __ballot(cut);
-                if (em) {
-                    const uint32_t c = (uint32_t)__popcll(em);
-                    if (wc.used + c > DESC_CHUNK) {
-                        if (wc.used < DESC_CHUNK) chunk_close(sh, wc, lane);
-                        uint32_t nb = 0;
-                        if (lane == 0) nb = atomicAdd(&sh.desc_count, DESC_CHUNK);
-                        wc.base = __shfl(nb, 0); wc.used = 0;
-                    }
-                    if (cut) {
-                        const uint32_t d = wc.base + wc.used + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                        sh.desc_a[d] = (rel + run_start) | ((run_len - 1u) << 18);
-                        sh.desc_p[d] = (uint16_t)run_p;
-                    }
-                    wc.used += c;
+                if (cut) {
+                    const uint32_t d = wn + (uint32_t)__popcll(em & lt_mask);
+                    sh.desc_a[wave][d] = (rel + run_start) | ((run_len - 1u) << 18);
+                    sh.desc_p[wave][d] = (uint16_t)run_p;
                 }
+                wn += (uint32_t)__popcll(em);
             }
-            part_flush<RW>(sh, pp, g, recs, wc);      // the stage is about to be replaced
+            if (wn) wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs);
             first += cnt;
         }
     }
-    // publish this workgroup's slice fills (may exceed slice_cap: the host then retries bigger)
-    for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) fill[(uint64_t)p * pp.G + g] = sh.cursor[p];
+    __syncthreads();
+    // publish this workgroup's slice fills (may exceed slice_cap: the host then retries bigger) and
+    // their maximum (one global atomic per workgroup)
+    uint32_t mx = 0;
+    for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) {
+        const uint32_t c = sh.cursor[p];
+        fill[(uint64_t)p * pp.G + g] = c;
+        mx = max(mx, c);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o));
+    if (lane == 0) sh.red[wave] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PART_WAVES; w++) mx = max(mx, sh.red[w]);
+        if (mx) atomicMax(&flags[2], mx);
+    }
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------

@@ -149,4 +149,24 @@ SHK_HD void nt_roll(NtState &s, uint32_t out, uint32_t in, unsigned m) {
 }
 SHK_HD uint64_t nt_canonical(const NtState &s) { return s.fh < s.rh ? s.fh : s.rh; }
 
+// ---- ntHash with a 32-bit state (minimiser ordering in pass 1 of the counting step) ----------
+// The same construction (Mohamadi et al. 2016) over 32-bit words: seeds = the high halves of the
+// published 64-bit seeds, rotations are rol32/ror32.  CDNA's VALU is 32 bits wide: a 64-bit
+// rotate-xor step costs 4-5 instructions per strand, the 32-bit one 2 (v_alignbit + v_xor).
+// For m > 32 bases 32 positions apart share a rotation (as positions 64 apart do in the 64-bit
+// form): still a strand-symmetric hash of the m-mer, which is all a minimiser order needs.
+SHK_HD uint32_t rol32(uint32_t v, unsigned s) { s &= 31; return s ? (v << s) | (v >> (32 - s)) : v; }
+SHK_HD uint32_t ror32(uint32_t v, unsigned s) { s &= 31; return s ? (v >> s) | (v << (32 - s)) : v; }
+SHK_HD uint32_t nt32_seed(uint32_t b) { return (uint32_t)(nt_seed(b) >> 32); }
+struct Nt32State { uint32_t fh, rh; };
+SHK_HD void nt32_init_step(Nt32State &s, uint32_t b, unsigned i) {
+    s.fh = rol32(s.fh, 1) ^ nt32_seed(b);
+    s.rh ^= rol32(nt32_seed(3 - b), i);
+}
+SHK_HD void nt32_roll(Nt32State &s, uint32_t out, uint32_t in, unsigned m) {
+    s.fh = rol32(s.fh, 1) ^ rol32(nt32_seed(out), m) ^ nt32_seed(in);
+    s.rh = ror32(s.rh, 1) ^ ror32(nt32_seed(3 - out), 1) ^ rol32(nt32_seed(3 - in), m - 1);
+}
+SHK_HD uint32_t nt32_canonical(const Nt32State &s) { return s.fh < s.rh ? s.fh : s.rh; }
+
 }  // namespace shk

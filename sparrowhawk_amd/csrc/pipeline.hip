@@ -1024,9 +1024,6 @@ public:
             else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
             HIPCHK(hipGetLastError());
             const double ms = t.stop();
-            hipLaunchKernelGGL(k_max_u32, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, n_slices,
-                               (uint32_t *)(ctl_.p + 9));
-            HIPCHK(hipGetLastError());
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
