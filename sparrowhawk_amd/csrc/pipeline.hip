@@ -286,23 +286,65 @@ __device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr
 }
 
 // adjacency byte (SPEC S8): bit b = successor by appended base b; bit 4+b = predecessor by
-// prepended base b, both relative to the canonical orientation.
+// prepended base b, both relative to the canonical orientation.  Also nb[2i+o]: the out-neighbour
+// of oriented node (i,o) when it has exactly one (NIL otherwise) — the correction and collapse
+// kernels then follow non-branching paths without hashing.
+// The 8 membership probes of a node are independent: all first-slot loads are issued before any is
+// looked at, then all key loads of the fingerprint hits (memory-level parallelism instead of 8
+// dependent round trips).
 template <int W>
 __global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
-                                                   uint8_t *__restrict__ adj) {
+                                                   uint8_t *__restrict__ adj, uint32_t *__restrict__ nb) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Kmer<W> x = keys.load(i);
-        uint32_t a = 0;
+        Kmer<W> c[8];
+        uint64_t slot[8], e[8];
+        uint32_t fp[8], orient = 0;
 #pragma unroll
-        for (uint32_t b = 0; b < 4; b++) {
-            Kmer<W> s = x; km_push_back<W>(s, b, k);
-            int o; Kmer<W> c = km_canonical<W>(s, k, o);
-            if (gt_lookup<W>(gt, keys, c) != NIL) a |= 1u << b;
-            Kmer<W> p = x; km_push_front<W>(p, b, k);
-            c = km_canonical<W>(p, k, o);
-            if (gt_lookup<W>(gt, keys, c) != NIL) a |= 1u << (4 + b);
+        for (int j = 0; j < 8; j++) {
+            Kmer<W> s = x;
+            if (j < 4) km_push_back<W>(s, (uint32_t)j, k); else km_push_front<W>(s, (uint32_t)(j - 4), k);
+            int o; c[j] = km_canonical<W>(s, k, o);
+            orient |= (uint32_t)o << j;
+            const uint64_t h = km_hash<W>(c[j]);
+            fp[j] = (uint32_t)(h >> 32); slot[j] = h & gt.mask;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) e[j] = gt.e[slot[j]];
+        Kmer<W> kk[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const bool m = e[j] != EMPTY64 && (uint32_t)(e[j] >> 32) == fp[j];
+            kk[j] = keys.load(m ? (uint32_t)e[j] : i);          // own row when there is nothing to check
+        }
+        uint32_t idx[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t r = NIL;
+            if (e[j] != EMPTY64) {
+                if ((uint32_t)(e[j] >> 32) == fp[j] && km_eq<W>(kk[j], c[j])) r = (uint32_t)e[j];
+                else {                                          // occupied by another key: keep probing
+                    uint64_t sl = (slot[j] + 1) & gt.mask;
+                    for (int p = 1; p < MAX_PROBE; p++) {
+                        const uint64_t ee = gt.e[sl];
+                        if (ee == EMPTY64) break;
+                        if ((uint32_t)(ee >> 32) == fp[j] && km_eq<W>(keys.load((uint32_t)ee), c[j])) { r = (uint32_t)ee; break; }
+                        sl = (sl + 1) & gt.mask;
+                    }
+                }
+            }
+            idx[j] = r;
+        }
+        uint32_t a = 0, n_out = 0, n_in = 0, u_out = NIL, u_in = NIL;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (idx[j] != NIL) { a |= 1u << j; n_out++; u_out = idx[j] * 2u + ((orient >> j) & 1u); }
+            // predecessor p -> (x,0) is the edge (x,1) -> rc(p)
+            if (idx[4 + j] != NIL) { a |= 1u << (4 + j); n_in++; u_in = idx[4 + j] * 2u + (((orient >> (4 + j)) & 1u) ^ 1u); }
         }
         adj[i] = (uint8_t)a;
+        uint2 v; v.x = n_out == 1 ? u_out : NIL; v.y = n_in == 1 ? u_in : NIL;
+        *reinterpret_cast<uint2 *>(nb + 2ull * i) = v;
     }
 }
 
@@ -322,6 +364,7 @@ template <int W> struct Graph {
     const uint32_t *cnt;
     uint8_t *adj;
     GraphTable gt;
+    const uint32_t *nb;                        // unique out-neighbour at build time (NIL: none or several)
     int k;
     uint32_t n;
     __device__ __forceinline__ uint32_t outmask(uint32_t v) const { return outmask_of(adj[v >> 1], v & 1); }
@@ -340,6 +383,10 @@ template <int W> struct Graph {
         return idx == NIL ? NIL : idx * 2 + (uint32_t)o;
     }
     __device__ __forceinline__ uint32_t only_out(uint32_t v) const {   // outdeg(v) must be 1
+        // edges are only ever removed: a node that had one out-edge when the graph was built and has
+        // one now still has that one.  Otherwise (it had several) look the survivor up.
+        const uint32_t c = nb[v];
+        if (c != NIL) return c;
         return follow(v, (uint32_t)__ffs((int)outmask(v)) - 1);
     }
 };
@@ -589,91 +636,101 @@ __global__ __launch_bounds__(256) void k_apply_removed(Graph<W> g, const uint32_
 }
 
 // ------------------------------------------------------------------------------------------
-// a12: collapse (SPEC S10).  succ[] over oriented nodes, splitters every ~64 nodes plus all
-// heads, one walker per splitter, splitter list ranked on the host (it is ~2N/64 long), then
-// every node scatters its base into the contig buffer.
+// a12: collapse (SPEC S10).  Simple links over oriented nodes, splitters = all heads plus a 1/32
+// sample, one walker per splitter, the splitter list ranked by pointer jumping, then every node
+// scatters its base into the contig buffer.
+//   winfo[v] = {succ(v) or NIL, count(v>>1)}   one 8-byte read per walker step
+//   ol[v]    = {owner splitter, position in its segment}
+// A node is sampled by a hash of its ID: a walker decides "is my successor a splitter" from the id it
+// just read, without touching the successor (heads are never reached through a simple link: a node
+// with a simple predecessor is not a head).
 // ------------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(256) void k_succ(Graph<W> g, const uint8_t *__restrict__ alive,
-                                              uint32_t *__restrict__ succ) {
-    const uint32_t total = g.n * 2;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
-        uint32_t s = NIL;
-        if (alive[v >> 1] && g.outdeg(v) == 1) {
-            const uint32_t u = g.only_out(v);
-            if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
-        }
-        succ[v] = s;
-    }
+__device__ __forceinline__ bool node_sampled(uint32_t v, uint32_t split_mask) {
+    return ((mix32(v ^ 0x5bd1e995u) >> 9) & split_mask) == 0;
 }
 
-// flags: bit0 splitter, bit1 head.  Compacts splitters, owner[v] = splitter index for them.
-// One global atomic per block-step (returning atomics on one address serialise at ~88 / us).
+static constexpr int SS_ITEMS = 16;            // oriented nodes per thread of k_succ_split
+
 template <int W>
-__global__ __launch_bounds__(256) void k_mark_splitters(Graph<W> g, const uint8_t *__restrict__ alive,
-                                                        const uint32_t *__restrict__ succ,
-                                                        uint8_t *__restrict__ flags,
-                                                        uint32_t *__restrict__ spl,
-                                                        uint32_t *__restrict__ owner,
-                                                        unsigned int *__restrict__ n_spl, uint32_t split_mask) {
-    __shared__ uint32_t wave_tot[4];
+__global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *__restrict__ alive,
+                                                    uint2 *__restrict__ winfo, uint32_t *__restrict__ spl,
+                                                    uint2 *__restrict__ ol, unsigned int *__restrict__ n_spl,
+                                                    uint32_t split_mask) {
+    __shared__ uint32_t wtot[SS_ITEMS * 4];
+    __shared__ uint32_t woff[SS_ITEMS * 4];
     __shared__ uint32_t blk_base;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t total = g.n * 2;
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (total + stride - 1) / stride * stride;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
-        bool p = false; uint8_t f = 0;
-        if (v < total && alive[v >> 1]) {
-            const bool head = succ[v ^ 1u] == NIL;
-            const uint64_t h = km_hash<W>(g.keys.load(v >> 1)) + (uint64_t)(v & 1u) * 0x9E3779B97F4A7C15ull;
-            const bool samp = ((h >> 17) & split_mask) == 0;
-            p = head || samp;
-            f = (uint8_t)((p ? 1 : 0) | (head ? 2 : 0));
+    const uint32_t base = blockIdx.x * (256u * SS_ITEMS);          // even: v and v^1 sit in adjacent lanes
+    uint32_t pbits = 0;
+#pragma unroll 1
+    for (int it = 0; it < SS_ITEMS; it++) {
+        const uint32_t v = base + (uint32_t)it * 256u + threadIdx.x;
+        uint32_t s = NIL, c = 0; bool al = false;
+        if (v < total) {
+            al = alive[v >> 1] != 0;
+            if (al) {
+                c = g.cnt[v >> 1];
+                if (g.outdeg(v) == 1) {
+                    const uint32_t u = g.only_out(v);
+                    if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
+                }
+            }
+            uint2 w; w.x = s; w.y = c; winfo[v] = w;
         }
-        if (v < total) flags[v] = f;
+        const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node
+        const bool p = al && (sp == NIL || node_sampled(v, split_mask));   // head or sampled
         const unsigned long long m = __ballot(p);
-        if (lane == 0) wave_tot[wid] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t tot = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-            blk_base = tot ? atomicAdd(n_spl, tot) : 0u;
-        }
-        __syncthreads();
+        if (lane == 0) wtot[it * 4 + wid] = (uint32_t)__popcll(m);
+        pbits |= (p ? 1u : 0u) << it;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                                        // exclusive scan of the 64 wave totals
+        const uint32_t t = threadIdx.x < SS_ITEMS * 4 ? wtot[threadIdx.x] : 0u;
+        uint32_t incl = t;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += u; }
+        if (threadIdx.x < SS_ITEMS * 4) woff[threadIdx.x] = incl - t;
+        if (threadIdx.x == 63) blk_base = incl ? atomicAdd(n_spl, incl) : 0u;      // ONE global atomic per block
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int it = 0; it < SS_ITEMS; it++) {
+        const uint32_t v = base + (uint32_t)it * 256u + threadIdx.x;
+        const bool p = (pbits >> it) & 1u;
+        const unsigned long long m = __ballot(p);
+        uint2 o; o.x = NIL; o.y = 0;
         if (p) {
-            uint32_t i = blk_base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            for (int w = 0; w < wid; w++) i += wave_tot[w];
-            spl[i] = v; owner[v] = i;
+            const uint32_t i = blk_base + woff[it * 4 + wid] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            spl[i] = v; o.x = i;
         }
-        __syncthreads();
+        if (v < total) ol[v] = o;
     }
 }
 
 struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, pad; };
 
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint32_t *__restrict__ succ,
-                                                       const uint8_t *__restrict__ flags,
+__global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__ winfo,
                                                        const uint32_t *__restrict__ spl, uint32_t n_spl,
-                                                       uint32_t *__restrict__ owner,
-                                                       uint32_t *__restrict__ local,
-                                                       SegRec *__restrict__ segs) {
+                                                       uint2 *__restrict__ ol, SegRec *__restrict__ segs,
+                                                       uint32_t split_mask) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
         uint32_t cur = s, len = 0, nxt;
         unsigned long long sum = 0;
         for (;;) {
-            if (cur != s) owner[cur] = i;
-            local[cur] = len;
-            sum += g.cnt[cur >> 1];
+            const uint2 w = winfo[cur];
+            if (cur != s) { uint2 o; o.x = i; o.y = len; ol[cur] = o; }
+            sum += w.y;
             len++;
-            nxt = succ[cur];
-            if (nxt == NIL || (flags[nxt] & 1)) break;
+            nxt = w.x;
+            if (nxt == NIL || node_sampled(nxt, split_mask)) break;
             cur = nxt;
         }
         SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum;
-        r.next_spl = (nxt == NIL) ? NIL : owner[nxt];      // splitters wrote owner[] before this kernel
-        r.head = (flags[s] >> 1) & 1; r.pad = 0;
+        r.next_spl = (nxt == NIL) ? NIL : ol[nxt].x;       // splitters got their owner in k_succ_split
+        r.head = winfo[s ^ 1u].x == NIL ? 1u : 0u; r.pad = 0;
         segs[i] = r;
     }
 }
@@ -731,8 +788,7 @@ __global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__
 // per node: splitter -> chain head -> output offset (~0 = chain not emitted)
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
-                                              const uint32_t *__restrict__ owner,
-                                              const uint32_t *__restrict__ local,
+                                              const uint2 *__restrict__ ol,
                                               const uint32_t *__restrict__ P,
                                               const uint32_t *__restrict__ A,
                                               const uint32_t *__restrict__ slot_of,
@@ -741,13 +797,14 @@ __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restr
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1]) continue;
-        const uint32_t s = owner[v];
+        const uint2 own = ol[v];
+        const uint32_t s = own.x;
         if (s == NIL) continue;
         const uint32_t slot = slot_of[P[s]];
         if (slot == NIL) continue;
         const unsigned long long off = head_off[slot];
         if (off == ~0ull) continue;
-        const uint32_t pos = A[s] + local[v];
+        const uint32_t pos = A[s] + own.y;
         const Kmer<W> x = g.seq(v);
         char *dst = out + off;
         const uint32_t ACGT = 0x54474341u;                 // 'A','C','G','T' little-endian
@@ -1306,7 +1363,7 @@ public:
     Graph<W> graph_view() {
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
-        g.cnt = scnt_.p; g.adj = adj_.p; g.gt.e = gt_.p; g.gt.mask = gt_slots_ - 1; g.k = k_;
+        g.cnt = scnt_.p; g.adj = adj_.p; g.gt.e = gt_.p; g.gt.mask = gt_slots_ - 1; g.nb = nb_.p; g.k = k_;
         g.n = (uint32_t)n_solid_;
         return g;
     }
@@ -1322,6 +1379,7 @@ public:
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
         if (int rc = adj0_.alloc(n, err)) return rc;
+        if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
         HIPCHK(hipMemsetAsync(gt_.p, 0xFF, gt_slots_ * 8, stream_));
         HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
@@ -1336,7 +1394,7 @@ public:
             times_.add("graph_table_kernel", t.stop());
             EvTimer t2(stream_);
             hipLaunchKernelGGL(k_adjacency<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_,
-                               g.gt, adj_.p);
+                               g.gt, adj_.p, nb_.p);
             HIPCHK(hipGetLastError());
             times_.add("adjacency_kernel", t2.stop());
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
@@ -1458,21 +1516,17 @@ public:
         if (n == 0) return 0;
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
-        DevBuf<uint32_t> succ, spl, owner, local;
-        DevBuf<uint8_t> flags;
+        DevBuf<uint32_t> spl;
+        DevBuf<uint2> winfo, ol;
         DevBuf<SegRec> segs;
-        if (int rc = succ.alloc(total, err)) return rc;
+        if (int rc = winfo.alloc(total, err)) return rc;
         if (int rc = spl.alloc(total, err)) return rc;
-        if (int rc = owner.alloc(total, err)) return rc;
-        if (int rc = local.alloc(total, err)) return rc;
-        if (int rc = flags.alloc(total, err)) return rc;
-        HIPCHK(hipMemsetAsync(owner.p, 0xFF, (size_t)total * 4, stream_));
+        if (int rc = ol.alloc(total, err)) return rc;
         HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 8, stream_));
+        const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
         EvTimer t1(stream_);
-        hipLaunchKernelGGL(k_succ<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p);
-        hipLaunchKernelGGL(k_mark_splitters<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, succ.p,
-                           flags.p, spl.p, owner.p, (unsigned int *)(ctl_.p + 5),
-                           (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u);
+        hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
+                           alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1481,8 +1535,8 @@ public:
         if (n_spl) {
             if (int rc = segs.alloc(n_spl, err)) return rc;
             EvTimer t2(stream_);
-            hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, g, succ.p,
-                               flags.p, spl.p, n_spl, owner.p, local.p, segs.p);
+            hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
+                               spl.p, n_spl, ol.p, segs.p, split_mask);
             HIPCHK(hipGetLastError());
             times_.add("collapse_walk", t2.stop());
         }
@@ -1543,7 +1597,7 @@ public:
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
             HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * 8, hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
-            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, owner.p, local.p,
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p,
                                Pf, Af, slot_of.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
@@ -1564,9 +1618,13 @@ public:
             std::vector<uint8_t> halive(n);
             HIPCHK(hipMemcpy(halive.data(), alive_.p, n, hipMemcpyDeviceToHost));
             auto tc0 = std::chrono::steady_clock::now();
-            std::vector<uint32_t> hsucc(total), howner(total), hcnt(n);
+            std::vector<uint32_t> hsucc(total), hcnt(n);
             std::vector<uint64_t> hkeys((size_t)n * W);
-            HIPCHK(hipMemcpy(hsucc.data(), succ.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            {
+                std::vector<uint2> hw(total);
+                HIPCHK(hipMemcpy(hw.data(), winfo.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost));
+                for (uint32_t v = 0; v < total; v++) hsucc[v] = hw[v].x;
+            }
             HIPCHK(hipMemcpy(hcnt.data(), scnt_.p, (size_t)n * 4, hipMemcpyDeviceToHost));
             {
                 std::vector<uint64_t> tmp(n);
@@ -1646,6 +1704,7 @@ private:
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
     DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0;
     DevBuf<uint8_t> adj_, adj0_, alive_;
+    DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;
     uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;
 };
