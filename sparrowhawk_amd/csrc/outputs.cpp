@@ -14,16 +14,15 @@ namespace shk {
 
 static inline char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
 
-static std::string revcomp(const std::string &s) {
-    std::string r(s.size(), 'A');
-    const size_t n = s.size();
+static std::string revcomp(const char *s, size_t n) {
+    std::string r(n, 'A');
     for (size_t i = 0; i < n; i++) r[i] = comp(s[n - 1 - i]);
     return r;
 }
+static std::string revcomp(const std::string &s) { return revcomp(s.data(), s.size()); }
 
 // is revcomp(s) < s ?  decided at the first differing position, without materialising it
-static bool revcomp_is_smaller(const std::string &s) {
-    const size_t n = s.size();
+static bool revcomp_is_smaller(const char *s, size_t n) {
     for (size_t i = 0; i < n; i++) {
         const char a = comp(s[n - 1 - i]), b = s[i];
         if (a != b) return a < b;
@@ -81,6 +80,7 @@ struct Esc {
     void quote() { s += "\\\""; }
     void raw(const char *p) { s += p; }                      // text without specials
     void raw(const std::string &p) { s += p; }
+    void raw(const char *p, size_t n) { s.append(p, n); }
     void num(uint64_t v) { s += std::to_string(v); }
 };
 }  // namespace
@@ -88,11 +88,11 @@ struct Esc {
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out) {
     // SPEC S10: each unitig is emitted as min(seq, revcomp(seq))
     for (auto &c : contigs)
-        if (revcomp_is_smaller(c.seq)) c.seq = revcomp(c.seq);
+        if (revcomp_is_smaller(c.data(), c.size())) { c.own = revcomp(c.data(), c.size()); c.ext = nullptr; c.ext_n = 0; }
     // SPEC S11: order by (length desc, sequence asc)
     std::sort(contigs.begin(), contigs.end(), [](const RawContig &a, const RawContig &b) {
-        if (a.seq.size() != b.seq.size()) return a.seq.size() > b.seq.size();
-        return a.seq < b.seq;
+        if (a.size() != b.size()) return a.size() > b.size();
+        return memcmp(a.data(), b.data(), a.size()) < 0;
     });
     const size_t nc = contigs.size();
     out.ncontigs = nc;
@@ -101,11 +101,10 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     std::unordered_map<std::string, uint64_t> head;
     head.reserve(nc * 2 + 1);
     std::vector<std::string> tail_plus(nc), tail_minus(nc);
-    for (size_t i = 0; i < nc; i++) head.emplace(contigs[i].seq.substr(0, k), i * 2);
+    for (size_t i = 0; i < nc; i++) head.emplace(std::string(contigs[i].data(), k), i * 2);
     for (size_t i = 0; i < nc; i++) {
-        const std::string &s = contigs[i].seq;
-        std::string last = s.substr(s.size() - k, k);
-        std::string first = s.substr(0, k);
+        std::string last(contigs[i].data() + contigs[i].size() - k, k);
+        std::string first(contigs[i].data(), k);
         head.emplace(revcomp(last), i * 2 + 1);       // first k-mer of the '-' orientation
         tail_plus[i] = std::move(last);               // last k-mer of '+'
         tail_minus[i] = revcomp(first);               // last k-mer of '-'
@@ -128,56 +127,66 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     std::sort(links.begin(), links.end());
     links.erase(std::unique(links.begin(), links.end()), links.end());
 
+    // One pass, straight into the JSON text in key order (a 5 Mbp contig is copied three times —
+    // FASTA, GFA1, GFA2 — and never staged in per-format strings).
     size_t seq_bytes = 0;
-    for (auto &c : contigs) seq_bytes += c.seq.size();
-    Esc fa, g1, g2, dt;
-    fa.s = take_big_string(); g1.s = take_big_string(); g2.s = take_big_string();
-    fa.s.reserve(seq_bytes + nc * 64 + 16);
-    g1.s.reserve(seq_bytes + nc * 80 + links.size() * 40 + 32);
-    g2.s.reserve(seq_bytes + nc * 80 + links.size() * 64 + 32);
-    g1.raw("H"); g1.tab(); g1.raw("VN:Z:1.0"); g1.nl();
-    g2.raw("H"); g2.tab(); g2.raw("VN:Z:2.0"); g2.nl();
-    dt.raw("digraph sparrowhawk {"); dt.nl();
+    for (auto &c : contigs) seq_bytes += c.size();
+    Esc w;
+    w.s = take_big_string();
+    w.s.reserve(3 * seq_bytes + nc * 320 + links.size() * 200 + 256);
+    std::vector<std::string> ids(nc), lens(nc), kcs(nc);
     for (size_t i = 0; i < nc; i++) {
-        const std::string id = std::to_string(i + 1), len = std::to_string(contigs[i].seq.size()),
-                          kc = std::to_string(contigs[i].kc);
-        fa.raw(">contig_"); fa.raw(id); fa.raw(" len="); fa.raw(len); fa.raw(" kc="); fa.raw(kc); fa.nl();
-        fa.raw(contigs[i].seq); fa.nl();
-        g1.raw("S"); g1.tab(); g1.raw(id); g1.tab(); g1.raw(contigs[i].seq); g1.tab(); g1.raw("LN:i:"); g1.raw(len);
-        g1.tab(); g1.raw("KC:i:"); g1.raw(kc); g1.nl();
-        g2.raw("S"); g2.tab(); g2.raw(id); g2.tab(); g2.raw(len); g2.tab(); g2.raw(contigs[i].seq); g2.tab();
-        g2.raw("KC:i:"); g2.raw(kc); g2.nl();
-        dt.raw("  "); dt.quote(); dt.raw(id); dt.quote(); dt.raw(" [label="); dt.quote(); dt.raw(id); dt.raw(" len=");
-        dt.raw(len); dt.raw(" kc="); dt.raw(kc); dt.quote(); dt.raw("];"); dt.nl();
+        ids[i] = std::to_string(i + 1); lens[i] = std::to_string(contigs[i].size()); kcs[i] = std::to_string(contigs[i].kc);
     }
     const std::string ov = std::to_string(k - 1);
+    w.raw("{\"outfasta\":\"");
+    for (size_t i = 0; i < nc; i++) {
+        w.raw(">contig_"); w.raw(ids[i]); w.raw(" len="); w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.nl();
+        w.raw(contigs[i].data(), contigs[i].size()); w.nl();
+    }
+    w.raw("\",\"ncontigs\":"); w.num(nc);
+    w.raw(",\"outdot\":\"");
+    w.raw("digraph sparrowhawk {"); w.nl();
+    for (size_t i = 0; i < nc; i++) {
+        w.raw("  "); w.quote(); w.raw(ids[i]); w.quote(); w.raw(" [label="); w.quote(); w.raw(ids[i]); w.raw(" len=");
+        w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.quote(); w.raw("];"); w.nl();
+    }
     for (const Link &L : links) {
         const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-        const uint64_t la = contigs[a - 1].seq.size(), lb = contigs[b - 1].seq.size();
-        g1.raw("L"); g1.tab(); g1.num(a); g1.tab(); g1.raw(ao ? "-" : "+"); g1.tab(); g1.num(b); g1.tab();
-        g1.raw(bo ? "-" : "+"); g1.tab(); g1.raw(ov); g1.raw("M"); g1.nl();
-        g2.raw("E"); g2.tab(); g2.raw("*"); g2.tab(); g2.num(a); g2.raw(ao ? "-" : "+"); g2.tab(); g2.num(b);
-        g2.raw(bo ? "-" : "+"); g2.tab();
-        if (!ao) { g2.num(la - (k - 1)); g2.tab(); g2.num(la); g2.raw("$"); g2.tab(); }
-        else { g2.raw("0"); g2.tab(); g2.raw(ov); if ((uint64_t)(k - 1) == la) g2.raw("$"); g2.tab(); }
-        if (!bo) { g2.raw("0"); g2.tab(); g2.raw(ov); if ((uint64_t)(k - 1) == lb) g2.raw("$"); g2.tab(); }
-        else { g2.num(lb - (k - 1)); g2.tab(); g2.num(lb); g2.raw("$"); g2.tab(); }
-        g2.raw(ov); g2.raw("M"); g2.nl();
-        dt.raw("  "); dt.quote(); dt.num(a); dt.quote(); dt.raw(" -> "); dt.quote(); dt.num(b); dt.quote();
-        dt.raw(" [label="); dt.quote(); dt.raw(ao ? "-" : "+"); dt.raw(bo ? "-" : "+"); dt.quote(); dt.raw("];"); dt.nl();
+        w.raw("  "); w.quote(); w.num(a); w.quote(); w.raw(" -> "); w.quote(); w.num(b); w.quote();
+        w.raw(" [label="); w.quote(); w.raw(ao ? "-" : "+"); w.raw(bo ? "-" : "+"); w.quote(); w.raw("];"); w.nl();
     }
-    dt.raw("}"); dt.nl();
-
-    std::string &js = out.json;
-    js = take_big_string();
-    js.reserve(fa.s.size() + g1.s.size() + g2.s.size() + dt.s.size() + 128);
-    js += "{\"outfasta\":\""; js += fa.s;
-    js += "\",\"ncontigs\":" + std::to_string(nc);
-    js += ",\"outdot\":\""; js += dt.s;
-    js += "\",\"outgfa\":\""; js += g1.s;
-    js += "\",\"outgfav2\":\""; js += g2.s;
-    js += "\"}";
-    give_big_string(std::move(fa.s)); give_big_string(std::move(g1.s)); give_big_string(std::move(g2.s));
+    w.raw("}"); w.nl();
+    w.raw("\",\"outgfa\":\"");
+    w.raw("H"); w.tab(); w.raw("VN:Z:1.0"); w.nl();
+    for (size_t i = 0; i < nc; i++) {
+        w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab(); w.raw("LN:i:"); w.raw(lens[i]);
+        w.tab(); w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
+    }
+    for (const Link &L : links) {
+        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+        w.raw("L"); w.tab(); w.num(a); w.tab(); w.raw(ao ? "-" : "+"); w.tab(); w.num(b); w.tab();
+        w.raw(bo ? "-" : "+"); w.tab(); w.raw(ov); w.raw("M"); w.nl();
+    }
+    w.raw("\",\"outgfav2\":\"");
+    w.raw("H"); w.tab(); w.raw("VN:Z:2.0"); w.nl();
+    for (size_t i = 0; i < nc; i++) {
+        w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(lens[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab();
+        w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
+    }
+    for (const Link &L : links) {
+        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+        const uint64_t la = contigs[a - 1].size(), lb = contigs[b - 1].size();
+        w.raw("E"); w.tab(); w.raw("*"); w.tab(); w.num(a); w.raw(ao ? "-" : "+"); w.tab(); w.num(b);
+        w.raw(bo ? "-" : "+"); w.tab();
+        if (!ao) { w.num(la - (k - 1)); w.tab(); w.num(la); w.raw("$"); w.tab(); }
+        else { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == la) w.raw("$"); w.tab(); }
+        if (!bo) { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == lb) w.raw("$"); w.tab(); }
+        else { w.num(lb - (k - 1)); w.tab(); w.num(lb); w.raw("$"); w.tab(); }
+        w.raw(ov); w.raw("M"); w.nl();
+    }
+    w.raw("\"}");
+    out.json = std::move(w.s);
     out.fasta.clear(); out.gfa1.clear(); out.gfa2.clear(); out.dot.clear();
 }
 

@@ -9,8 +9,13 @@
 namespace shk {
 
 struct RawContig {            // one unitig as spelled by the device, arbitrary strand
-    std::string seq;
-    uint64_t kc;              // sum of k-mer counts over its nodes
+    // The sequence either lives in the pipeline's pinned download buffer (ext: valid until the next
+    // collapse() or the pipeline's destruction — a 5 Mbp contig is not copied again) or in `own`.
+    const char *ext = nullptr; size_t ext_n = 0;
+    std::string own;
+    uint64_t kc = 0;          // sum of k-mer counts over its nodes
+    const char *data() const { return ext ? ext : own.data(); }
+    size_t size() const { return ext ? ext_n : own.size(); }
 };
 
 struct StageTimes {           // milliseconds (HIP events on the pipeline's stream / host clock)

@@ -929,6 +929,8 @@ struct PinnedBuf {
     ~PinnedBuf() { if (p) { std::lock_guard<std::mutex> lk(mu()); cache().emplace(bytes, p); } }
     int alloc(size_t b, std::string &err) {
         b = (b + 4095) & ~(size_t)4095; if (!b) b = 4096;
+        if (p && bytes >= b) return 0;
+        if (p) { std::lock_guard<std::mutex> lk(mu()); cache().emplace(bytes, p); p = nullptr; bytes = 0; }
         {
             std::lock_guard<std::mutex> lk(mu());
             auto it = cache().lower_bound(b);
@@ -939,6 +941,22 @@ struct PinnedBuf {
         bytes = b; return 0;
     }
 };
+
+// streams of freed handles are reused too (create + destroy cost ~0.2 ms per handle); every use of a
+// handle's stream ends in a synchronize, so a pooled stream is idle
+static std::mutex g_stream_mu;
+static std::multimap<int, hipStream_t> &stream_cache() { static auto *c = new std::multimap<int, hipStream_t>(); return *c; }
+static hipStream_t stream_pool_get(int dev) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    auto it = stream_cache().find(dev);
+    if (it == stream_cache().end()) return nullptr;
+    hipStream_t s = it->second; stream_cache().erase(it); return s;
+}
+static void stream_pool_put(int dev, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    if (stream_cache().size() < 16) { stream_cache().emplace(dev, s); return; }
+    (void)hipStreamDestroy(s);
+}
 
 static inline int grid_for(uint64_t work, int block = 256, int max_blocks = 256 * 16) {
     uint64_t b = (work + block - 1) / block;
@@ -970,9 +988,11 @@ static inline uint64_t env_u64(const char *name, uint64_t dflt) {
 template <int W> class Pipeline : public IPipeline {
 public:
     explicit Pipeline(int k) : k_(k) {}
-    ~Pipeline() override { if (stream_) (void)hipStreamDestroy(stream_); }
+    ~Pipeline() override { if (stream_) stream_pool_put(stream_dev_, stream_); }
     int init(std::string &err) {
-        HIPCHK(hipStreamCreate(&stream_));
+        HIPCHK(hipGetDevice(&stream_dev_));
+        stream_ = stream_pool_get(stream_dev_);
+        if (!stream_) HIPCHK(hipStreamCreate(&stream_));
         HIPCHK(ctl_.alloc(16, err) ? hipErrorOutOfMemory : hipSuccess);
         return 0;
     }
@@ -1591,7 +1611,7 @@ public:
             }
         }
         if (!emitted.empty()) {
-            PinnedBuf hout;
+            PinnedBuf &hout = hout_;
             if (int rc = hout.alloc(out_bytes, err)) return rc;
             if (int rc = d_off.alloc(head_off.size(), err)) return rc;
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
@@ -1607,7 +1627,7 @@ public:
             out.reserve(emitted.size());
             for (uint32_t i : emitted) {
                 RawContig rc; rc.kc = heads[i].kc;
-                rc.seq.assign(hout.p + head_off[i], hout.p + head_off[i] + heads[i].len + (uint64_t)(k_ - 1));
+                rc.ext = hout.p + head_off[i]; rc.ext_n = heads[i].len + (uint64_t)(k_ - 1);
                 out.push_back(std::move(rc));
             }
             times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
@@ -1662,13 +1682,13 @@ public:
                 const char B[4] = {'A', 'C', 'G', 'T'};
                 v = best * 2;
                 Kmer<W> x = key_of(best);
-                for (int q = 0; q < k_; q++) rc.seq.push_back(B[km_bits2<W>(x, 2 * (k_ - 1 - q))]);
+                for (int q = 0; q < k_; q++) rc.own.push_back(B[km_bits2<W>(x, 2 * (k_ - 1 - q))]);
                 for (uint64_t q = 0; q < len; q++) {
                     done[v >> 1] = 1; rc.kc += hcnt[v >> 1];
                     if (q > 0) {
                         Kmer<W> y = key_of(v >> 1);
                         if (v & 1) y = km_revcomp<W>(y, k_);
-                        rc.seq.push_back(B[km_last_base<W>(y)]);
+                        rc.own.push_back(B[km_last_base<W>(y)]);
                     }
                     v = hsucc[v];
                 }
@@ -1681,7 +1701,7 @@ public:
 
 private:
     int k_;
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr; int stream_dev_ = 0;
     StageTimes times_;
     DevBuf<unsigned long long> ctl_;
     // count table
@@ -1704,6 +1724,7 @@ private:
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
     DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0;
     DevBuf<uint8_t> adj_, adj0_, alive_;
+    PinnedBuf hout_;                  // contigs as downloaded; RawContig::ext points into it
     DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;
     uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;
