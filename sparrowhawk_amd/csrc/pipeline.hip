@@ -64,9 +64,17 @@ template <int W> struct CountTable {           // open addressing, linear probin
     uint64_t mask;
 };
 
+// Graph membership table, split into GP mini tables by minimiser partition: a k-mer and its graph
+// neighbours share their minimiser nine times out of ten, and the rows arrive grouped by partition
+// (pass 2 emits partition by partition), so the 8 probes of a node and of the rows around it go to
+// one ~32 KB region that stays in the XCD's L2 — instead of 8 scattered 64-byte fabric requests per
+// node into one 134 MB table (the flat version: 3.2 GB fetched for 5 M nodes, profiles/r01_s2_start).
 struct GraphTable {                            // entry = fingerprint<<32 | node index
     uint64_t *e;
-    uint64_t mask;
+    const unsigned long long *off;             // [GP] first slot of the partition's table
+    const uint32_t *msk;                       // [GP] its size - 1 (power of two)
+    uint32_t gp_mask;                          // GP - 1
+    int gm;                                    // minimiser length of the graph partition function
 };
 
 }  // namespace shk
@@ -246,101 +254,183 @@ __global__ __launch_bounds__(256) void k_compact(CountTable<W> tab, uint64_t n_s
 }
 
 // ------------------------------------------------------------------------------------------
-// a10: graph table over the solid set (keys are distinct: claim the first empty slot)
+// a10: graph table over the solid set
 // ------------------------------------------------------------------------------------------
+// Graph partition of a k-mer = low bits of the smallest canonical ntHash (32-bit state) over its
+// gm-mers; strand-symmetric, so a k-mer and its reverse complement agree.
+struct MinScan {
+    Nt32State first, last;      // hash state of the first / last gm-mer
+    uint32_t h_first, h_last;   // their canonical hashes
+    uint32_t min_wo_first;      // min over gm-mers 1 .. w-1
+    uint32_t min_wo_last;       // min over gm-mers 0 .. w-2
+    __device__ __forceinline__ uint32_t min_all() const { return min(min_wo_first, h_first); }
+};
+
+// base j (0 = first) of a k-mer
+template <int W> __device__ __forceinline__ uint32_t km_base(const Kmer<W> &x, int k, int j) {
+    return km_bits2<W>(x, 2 * (k - 1 - j));
+}
+
+template <int W> __device__ __forceinline__ MinScan km_min_scan(const Kmer<W> &x, int k, int gm) {
+    MinScan r;
+    Nt32State nt{0, 0};
+    for (int j = 0; j < gm; j++) nt32_init_step(nt, km_base<W>(x, k, j), (unsigned)j);
+    r.first = nt; r.h_first = nt32_canonical(nt);
+    r.min_wo_first = 0xFFFFFFFFu; r.min_wo_last = r.h_first;
+    const int w = k - gm + 1;
+    uint32_t h = r.h_first;
+    for (int q = 1; q < w; q++) {
+        nt32_roll(nt, km_base<W>(x, k, q - 1), km_base<W>(x, k, q + gm - 1), (unsigned)gm);
+        h = nt32_canonical(nt);
+        r.min_wo_first = min(r.min_wo_first, h);
+        if (q < w - 1) r.min_wo_last = min(r.min_wo_last, h);
+    }
+    r.last = nt; r.h_last = h;
+    return r;
+}
+// the gm-mer that follows the last one when base b is appended / precedes the first when b is prepended
+__device__ __forceinline__ uint32_t nt32_next_hash(Nt32State s, uint32_t out, uint32_t in, unsigned gm) {
+    nt32_roll(s, out, in, gm);
+    return nt32_canonical(s);
+}
+__device__ __forceinline__ uint32_t nt32_prev_hash(const Nt32State &s, uint32_t new_first, uint32_t old_last, unsigned gm) {
+    // inverse of nt32_roll: s is the state of (x0 .. x_{gm-1}); result: state of (b, x0 .. x_{gm-2})
+    const uint32_t fh = ror32(s.fh ^ rol32(nt32_seed(new_first), gm) ^ nt32_seed(old_last), 1);
+    const uint32_t rh = rol32(s.rh ^ ror32(nt32_seed(3u - new_first), 1) ^ rol32(nt32_seed(3u - old_last), gm - 1), 1);
+    return fh < rh ? fh : rh;
+}
+template <int W> __device__ __forceinline__ uint32_t gt_partition_of(const GraphTable &gt, const Kmer<W> &x, int k) {
+    return km_min_scan<W>(x, k, gt.gm).min_all() & gt.gp_mask;
+}
+
+// rows per graph partition (rows arrive grouped: one atomic per run of equal partitions in a wave)
+template <int W>
+__global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
+                                                  uint32_t *__restrict__ gp_of, uint32_t *__restrict__ gp_cnt) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + stride - 1) / stride * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        uint32_t p = 0xFFFFFFFFu;
+        if (i < n) { p = gt_partition_of<W>(gt, keys.load(i), k); gp_of[i] = p; }
+        unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lp = (uint32_t)__shfl((int)p, leader);
+            const unsigned long long same = __ballot(p == lp) & todo;
+            if ((threadIdx.x & 63) == leader) atomicAdd(&gp_cnt[lp], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+}
+
+// table sizes (power of two >= 2 x rows, at least 8) and their exclusive prefix sum; one workgroup
+__global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ gp_cnt, uint32_t GP,
+                                                  unsigned long long *__restrict__ off, uint32_t *__restrict__ msk,
+                                                  unsigned long long *__restrict__ total) {
+    __shared__ unsigned long long wsum[16];
+    const uint32_t per = (GP + 1023) / 1024;
+    const uint32_t p0 = threadIdx.x * per, p1 = min(GP, p0 + per);
+    unsigned long long mine = 0;
+    for (uint32_t p = p0; p < p1; p++) {
+        uint32_t sz = 8; const uint32_t want = 2u * gp_cnt[p];
+        while (sz < want) sz <<= 1;
+        msk[p] = sz - 1u; mine += sz;
+    }
+    unsigned long long incl = mine;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) wsum[wid] = incl;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (int w = 0; w < wid; w++) base += wsum[w];
+    unsigned long long run = base + incl - mine;
+    for (uint32_t p = p0; p < p1; p++) { off[p] = run; run += (unsigned long long)msk[p] + 1ull; }
+    if (threadIdx.x == 1023) *total = base + incl;
+}
+
+// keys are distinct: claim the first empty slot of the partition's table
 template <int W>
 __global__ __launch_bounds__(256) void k_gt_insert(KeyArr<W> keys, uint32_t n, GraphTable gt,
+                                                   const uint32_t *__restrict__ gp_of,
                                                    uint32_t *__restrict__ overflow) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Kmer<W> x = keys.load(i);
         const uint64_t h = km_hash<W>(x);
         const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
-        uint64_t slot = h & gt.mask;
+        const uint32_t p = gp_of[i];
+        const unsigned long long base = gt.off[p];
+        const uint32_t mask = gt.msk[p];
+        uint32_t slot = (uint32_t)h & mask;
         bool done = false;
-        for (int p = 0; p < MAX_PROBE; p++) {
-            unsigned long long old = atomicCAS((unsigned long long *)&gt.e[slot],
+        for (uint32_t t = 0; t <= mask; t++) {
+            unsigned long long old = atomicCAS((unsigned long long *)&gt.e[base + slot],
                                                (unsigned long long)EMPTY64, (unsigned long long)entry);
             if (old == EMPTY64) { done = true; break; }
-            slot = (slot + 1) & gt.mask;
+            slot = (slot + 1) & mask;
         }
         if (!done) *overflow = 1;
     }
 }
 
+// membership probe in partition p's table
 template <int W>
-__device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr<W> &keys,
-                                              const Kmer<W> &q) {
+__device__ __forceinline__ uint32_t gt_lookup_in(const GraphTable &gt, const KeyArr<W> &keys, const Kmer<W> &q,
+                                                 uint32_t p) {
     const uint64_t h = km_hash<W>(q);
     const uint32_t fp = (uint32_t)(h >> 32);
-    uint64_t slot = h & gt.mask;
-    for (int p = 0; p < MAX_PROBE; p++) {
-        const uint64_t e = gt.e[slot];
+    const unsigned long long base = gt.off[p];
+    const uint32_t mask = gt.msk[p];
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t t = 0; t <= mask; t++) {
+        const uint64_t e = gt.e[base + slot];
         if (e == EMPTY64) return NIL;
         if ((uint32_t)(e >> 32) == fp) {
             const uint32_t idx = (uint32_t)e;
             if (km_eq<W>(keys.load(idx), q)) return idx;
         }
-        slot = (slot + 1) & gt.mask;
+        slot = (slot + 1) & mask;
     }
     return NIL;
+}
+// q must be canonical
+template <int W>
+__device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr<W> &keys, const Kmer<W> &q, int k) {
+    return gt_lookup_in<W>(gt, keys, q, gt_partition_of<W>(gt, q, k));
 }
 
 // adjacency byte (SPEC S8): bit b = successor by appended base b; bit 4+b = predecessor by
 // prepended base b, both relative to the canonical orientation.  Also nb[2i+o]: the out-neighbour
 // of oriented node (i,o) when it has exactly one (NIL otherwise) — the correction and collapse
 // kernels then follow non-branching paths without hashing.
-// The 8 membership probes of a node are independent: all first-slot loads are issued before any is
-// looked at, then all key loads of the fingerprint hits (memory-level parallelism instead of 8
-// dependent round trips).
+// A neighbour's partition follows from this node's gm-mer hashes and ONE more hash: appending a base
+// drops the first gm-mer and adds one at the end, prepending drops the last and adds one in front.
 template <int W>
 __global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
                                                    uint8_t *__restrict__ adj, uint32_t *__restrict__ nb) {
+    const unsigned gm = (unsigned)gt.gm;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Kmer<W> x = keys.load(i);
-        Kmer<W> c[8];
-        uint64_t slot[8], e[8];
-        uint32_t fp[8], orient = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            Kmer<W> s = x;
-            if (j < 4) km_push_back<W>(s, (uint32_t)j, k); else km_push_front<W>(s, (uint32_t)(j - 4), k);
-            int o; c[j] = km_canonical<W>(s, k, o);
-            orient |= (uint32_t)o << j;
-            const uint64_t h = km_hash<W>(c[j]);
-            fp[j] = (uint32_t)(h >> 32); slot[j] = h & gt.mask;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) e[j] = gt.e[slot[j]];
-        Kmer<W> kk[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const bool m = e[j] != EMPTY64 && (uint32_t)(e[j] >> 32) == fp[j];
-            kk[j] = keys.load(m ? (uint32_t)e[j] : i);          // own row when there is nothing to check
-        }
-        uint32_t idx[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            uint32_t r = NIL;
-            if (e[j] != EMPTY64) {
-                if ((uint32_t)(e[j] >> 32) == fp[j] && km_eq<W>(kk[j], c[j])) r = (uint32_t)e[j];
-                else {                                          // occupied by another key: keep probing
-                    uint64_t sl = (slot[j] + 1) & gt.mask;
-                    for (int p = 1; p < MAX_PROBE; p++) {
-                        const uint64_t ee = gt.e[sl];
-                        if (ee == EMPTY64) break;
-                        if ((uint32_t)(ee >> 32) == fp[j] && km_eq<W>(keys.load((uint32_t)ee), c[j])) { r = (uint32_t)ee; break; }
-                        sl = (sl + 1) & gt.mask;
-                    }
-                }
-            }
-            idx[j] = r;
-        }
+        const MinScan ms = km_min_scan<W>(x, k, gt.gm);
+        const uint32_t out_b = km_base<W>(x, k, k - (int)gm);      // first base of the last gm-mer
+        const uint32_t last_b = km_base<W>(x, k, (int)gm - 1);     // last base of the first gm-mer
         uint32_t a = 0, n_out = 0, n_in = 0, u_out = NIL, u_in = NIL;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (idx[j] != NIL) { a |= 1u << j; n_out++; u_out = idx[j] * 2u + ((orient >> j) & 1u); }
-            // predecessor p -> (x,0) is the edge (x,1) -> rc(p)
-            if (idx[4 + j] != NIL) { a |= 1u << (4 + j); n_in++; u_in = idx[4 + j] * 2u + (((orient >> (4 + j)) & 1u) ^ 1u); }
+        for (uint32_t b = 0; b < 4; b++) {
+            {
+                Kmer<W> s = x; km_push_back<W>(s, b, k);
+                int o; const Kmer<W> c = km_canonical<W>(s, k, o);
+                const uint32_t p = min(ms.min_wo_first, nt32_next_hash(ms.last, out_b, b, gm)) & gt.gp_mask;
+                const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
+                if (idx != NIL) { a |= 1u << b; n_out++; u_out = idx * 2u + (uint32_t)o; }
+            }
+            {
+                Kmer<W> s = x; km_push_front<W>(s, b, k);
+                int o; const Kmer<W> c = km_canonical<W>(s, k, o);
+                const uint32_t p = min(ms.min_wo_last, nt32_prev_hash(ms.first, b, last_b, gm)) & gt.gp_mask;
+                const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
+                // predecessor q -> (x,0) is the edge (x,1) -> rc(q)
+                if (idx != NIL) { a |= 1u << (4 + b); n_in++; u_in = idx * 2u + ((uint32_t)o ^ 1u); }
+            }
         }
         adj[i] = (uint8_t)a;
         uint2 v; v.x = n_out == 1 ? u_out : NIL; v.y = n_in == 1 ? u_in : NIL;
@@ -379,7 +469,7 @@ template <int W> struct Graph {
         Kmer<W> s = seq(v);
         km_push_back<W>(s, b, k);
         int o; Kmer<W> c = km_canonical<W>(s, k, o);
-        uint32_t idx = gt_lookup<W>(gt, keys, c);
+        uint32_t idx = gt_lookup<W>(gt, keys, c, k);
         return idx == NIL ? NIL : idx * 2 + (uint32_t)o;
     }
     __device__ __forceinline__ uint32_t only_out(uint32_t v) const {   // outdeg(v) must be 1
@@ -620,13 +710,13 @@ __global__ __launch_bounds__(256) void k_apply_removed(Graph<W> g, const uint32_
             if ((a >> b) & 1u) {                            // edge (r,0) -> u
                 Kmer<W> s = x; km_push_back<W>(s, b, g.k);
                 int o; Kmer<W> c = km_canonical<W>(s, g.k, o);
-                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c);
+                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c, g.k);
                 if (u != NIL) adj_clear_bit(g.adj, u, o == 0 ? 4 + fb : 3 - fb);
             }
             if ((a >> (4 + b)) & 1u) {                      // edge p -> (r,0), p spelled b + x[..k-1)
                 Kmer<W> s = x; km_push_front<W>(s, b, g.k);
                 int o; Kmer<W> c = km_canonical<W>(s, g.k, o);
-                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c);
+                const uint32_t u = gt_lookup<W>(g.gt, g.keys, c, g.k);
                 if (u != NIL) adj_clear_bit(g.adj, u, o == 0 ? lb : 4 + (3 - lb));
             }
         }
@@ -984,6 +1074,9 @@ static inline uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *v = getenv(name);
     return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
 }
+
+// minimiser length of the counting partitions and of the graph partitions
+static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
 
 template <int W> class Pipeline : public IPipeline {
 public:
@@ -1383,7 +1476,8 @@ public:
     Graph<W> graph_view() {
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
-        g.cnt = scnt_.p; g.adj = adj_.p; g.gt.e = gt_.p; g.gt.mask = gt_slots_ - 1; g.nb = nb_.p; g.k = k_;
+        g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
+        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_);
         g.n = (uint32_t)n_solid_;
         return g;
     }
@@ -1394,22 +1488,34 @@ public:
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr;
-        gt_slots_ = 1ull << 10;
-        while (gt_slots_ < 2 * n + 16) gt_slots_ <<= 1;
+        // graph partitions: ~1024 rows each; the minimiser length is the counting pass's, so rows that
+        // arrive grouped by counting partition are grouped by graph partition too
+        gp_ = 64;
+        while (gp_ < 65536u && (uint64_t)gp_ * 1024u < n) gp_ <<= 1;
+        gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
+        if (int rc = gt_off_.alloc(gp_, err)) return rc;
+        if (int rc = gt_msk_.alloc(gp_, err)) return rc;
+        DevBuf<uint32_t> gp_of, gp_cnt;
+        if (int rc = gp_of.alloc(n, err)) return rc;
+        if (int rc = gp_cnt.alloc(gp_, err)) return rc;
         if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
         if (int rc = adj0_.alloc(n, err)) return rc;
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
         HIPCHK(hipMemsetAsync(gt_.p, 0xFF, gt_slots_ * 8, stream_));
+        HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));
         HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
         HIPCHK(hipMemsetAsync(alive_.p, 1, n ? n : 1, stream_));
         HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
         if (n) {
             Graph<W> g = graph_view();
             EvTimer t(stream_);
+            hipLaunchKernelGGL(k_gp_count<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_, g.gt,
+                               gp_of.p, gp_cnt.p);
+            hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, ctl_.p + 2);
             hipLaunchKernelGGL(k_gt_insert<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, g.gt,
-                               (uint32_t *)(ctl_.p + 1));
+                               gp_of.p, (uint32_t *)(ctl_.p + 1));
             HIPCHK(hipGetLastError());
             times_.add("graph_table_kernel", t.stop());
             EvTimer t2(stream_);
@@ -1418,10 +1524,10 @@ public:
             HIPCHK(hipGetLastError());
             times_.add("adjacency_kernel", t2.stop());
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
-            unsigned long long h[2];
+            unsigned long long h[3];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
-            if ((uint32_t)h[1]) { err = "graph table overflow"; return -6; }
+            if ((uint32_t)h[1] || h[2] > gt_slots_) { err = "graph table overflow"; return -6; }
         }
         graph_ready_ = true;
         return 0;
@@ -1722,7 +1828,8 @@ private:
     uint64_t n_emitted_ = 0; uint32_t emit_threshold_ = 0;
     // solid set / graph
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
-    DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0;
+    DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
+    DevBuf<unsigned long long> gt_off_; DevBuf<uint32_t> gt_msk_;
     DevBuf<uint8_t> adj_, adj0_, alive_;
     PinnedBuf hout_;                  // contigs as downloaded; RawContig::ext points into it
     DevBuf<uint32_t> nb_;
