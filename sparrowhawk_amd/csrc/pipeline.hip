@@ -288,6 +288,37 @@ template <int W> __device__ __forceinline__ MinScan km_min_scan(const Kmer<W> &x
     r.last = nt; r.h_last = h;
     return r;
 }
+// The same scan with the roll terms taken from a 16-entry LDS table ([out<<2|in], as in pass 1): the
+// two hot kernels (k_gp_count, k_adjacency) do k + 8 hash steps per node.
+__device__ __forceinline__ void nt32_fill_lut(uint2 *lut, unsigned gm) {      // threads 0..15, then __syncthreads()
+    if (threadIdx.x < 16) {
+        const uint32_t out = threadIdx.x >> 2, in = threadIdx.x & 3u;
+        uint2 v;
+        v.x = rol32(nt32_seed(out), gm) ^ nt32_seed(in);
+        v.y = ror32(nt32_seed(3u - out), 1) ^ rol32(nt32_seed(3u - in), gm - 1);
+        lut[threadIdx.x] = v;
+    }
+}
+template <int W> __device__ __forceinline__ MinScan km_min_scan_lut(const Kmer<W> &x, int k, int gm, const uint2 *lut) {
+    MinScan r;
+    Nt32State nt{0, 0};
+    for (int j = 0; j < gm; j++) nt32_init_step(nt, km_base<W>(x, k, j), (unsigned)j);
+    r.first = nt; r.h_first = nt32_canonical(nt);
+    r.min_wo_first = 0xFFFFFFFFu; r.min_wo_last = r.h_first;
+    const int w = k - gm + 1;
+    uint32_t h = r.h_first;
+    for (int q = 1; q < w; q++) {
+        const uint32_t idx = (km_base<W>(x, k, q - 1) << 2) | km_base<W>(x, k, q + gm - 1);
+        const uint2 t = lut[idx];
+        nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t.x;
+        nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t.y;
+        h = nt32_canonical(nt);
+        r.min_wo_first = min(r.min_wo_first, h);
+        if (q < w - 1) r.min_wo_last = min(r.min_wo_last, h);
+    }
+    r.last = nt; r.h_last = h;
+    return r;
+}
 // the gm-mer that follows the last one when base b is appended / precedes the first when b is prepended
 __device__ __forceinline__ uint32_t nt32_next_hash(Nt32State s, uint32_t out, uint32_t in, unsigned gm) {
     nt32_roll(s, out, in, gm);
@@ -299,6 +330,19 @@ __device__ __forceinline__ uint32_t nt32_prev_hash(const Nt32State &s, uint32_t 
     const uint32_t rh = rol32(s.rh ^ ror32(nt32_seed(3u - new_first), 1) ^ rol32(nt32_seed(3u - old_last), gm - 1), 1);
     return fh < rh ? fh : rh;
 }
+// Placement inside a mini table: its keys share a minimiser but are otherwise unrelated; an
+// add/shift/xor mix of the key words spreads them (integer multiplies are quarter rate on CDNA).
+template <int W> __device__ __forceinline__ uint64_t gt_hash(const Kmer<W> &x) {
+    uint32_t a = 0x9E3779B9u, b = 0x85EBCA6Bu;
+#pragma unroll
+    for (int j = 0; j < W; j++) {
+        const uint32_t lo = (uint32_t)x.w[j], hi = (uint32_t)(x.w[j] >> 32);
+        a = mix32(a ^ lo ^ __builtin_amdgcn_alignbit(hi, hi, 17));
+        b = (b ^ hi) + __builtin_amdgcn_alignbit(lo, lo, 11);
+        b ^= b >> 15; b += b << 7;
+    }
+    return ((uint64_t)(b ^ a) << 32) | a;          // high word: fingerprint, low word: slot
+}
 template <int W> __device__ __forceinline__ uint32_t gt_partition_of(const GraphTable &gt, const Kmer<W> &x, int k) {
     return km_min_scan<W>(x, k, gt.gm).min_all() & gt.gp_mask;
 }
@@ -307,11 +351,14 @@ template <int W> __device__ __forceinline__ uint32_t gt_partition_of(const Graph
 template <int W>
 __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
                                                   uint32_t *__restrict__ gp_of, uint32_t *__restrict__ gp_cnt) {
+    __shared__ uint2 lut[16];
+    nt32_fill_lut(lut, (unsigned)gt.gm);
+    __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_round = (n + stride - 1) / stride * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         uint32_t p = 0xFFFFFFFFu;
-        if (i < n) { p = gt_partition_of<W>(gt, keys.load(i), k); gp_of[i] = p; }
+        if (i < n) { p = km_min_scan_lut<W>(keys.load(i), k, gt.gm, lut).min_all() & gt.gp_mask; gp_of[i] = p; }
         unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
@@ -323,29 +370,61 @@ __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, in
     }
 }
 
-// table sizes (power of two >= 2 x rows, at least 8) and their exclusive prefix sum; one workgroup
+// table sizes (power of two >= 2 x rows, at least 8) and their exclusive prefix sum, plus the
+// exclusive prefix sum of the row counts (row list offsets); one workgroup
 __global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ gp_cnt, uint32_t GP,
                                                   unsigned long long *__restrict__ off, uint32_t *__restrict__ msk,
-                                                  unsigned long long *__restrict__ total) {
+                                                  uint32_t *__restrict__ roff, unsigned long long *__restrict__ total) {
     __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t rsum[16];
     const uint32_t per = (GP + 1023) / 1024;
     const uint32_t p0 = threadIdx.x * per, p1 = min(GP, p0 + per);
-    unsigned long long mine = 0;
+    unsigned long long mine = 0; uint32_t rmine = 0;
     for (uint32_t p = p0; p < p1; p++) {
-        uint32_t sz = 8; const uint32_t want = 2u * gp_cnt[p];
+        const uint32_t c = gp_cnt[p];
+        uint32_t sz = 8; const uint32_t want = 2u * c;
         while (sz < want) sz <<= 1;
-        msk[p] = sz - 1u; mine += sz;
+        msk[p] = sz - 1u; mine += sz; rmine += c;
     }
-    unsigned long long incl = mine;
+    unsigned long long incl = mine; uint32_t rincl = rmine;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) { const unsigned long long u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-    if (lane == 63) wsum[wid] = incl;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(incl, o); const uint32_t ru = (uint32_t)__shfl_up((int)rincl, o);
+        if (lane >= o) { incl += u; rincl += ru; }
+    }
+    if (lane == 63) { wsum[wid] = incl; rsum[wid] = rincl; }
     __syncthreads();
-    unsigned long long base = 0;
-    for (int w = 0; w < wid; w++) base += wsum[w];
-    unsigned long long run = base + incl - mine;
-    for (uint32_t p = p0; p < p1; p++) { off[p] = run; run += (unsigned long long)msk[p] + 1ull; }
-    if (threadIdx.x == 1023) *total = base + incl;
+    unsigned long long base = 0; uint32_t rbase = 0;
+    for (int w = 0; w < wid; w++) { base += wsum[w]; rbase += rsum[w]; }
+    unsigned long long run = base + incl - mine; uint32_t rrun = rbase + rincl - rmine;
+    for (uint32_t p = p0; p < p1; p++) {
+        off[p] = run; run += (unsigned long long)msk[p] + 1ull;
+        roff[p] = rrun; rrun += gp_cnt[p];
+    }
+    if (threadIdx.x == 1023) { *total = base + incl; roff[GP] = rbase + rincl; }
+}
+
+// row list per graph partition: rows[roff[p] .. roff[p+1]) (order inside a partition is arbitrary)
+__global__ __launch_bounds__(256) void k_gp_rows(const uint32_t *__restrict__ gp_of, uint32_t n,
+                                                 const uint32_t *__restrict__ roff, uint32_t *__restrict__ cursor,
+                                                 uint32_t *__restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + stride - 1) / stride * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const uint32_t p = i < n ? gp_of[i] : 0xFFFFFFFFu;
+        unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t lp = (uint32_t)__shfl((int)p, leader);
+            const unsigned long long same = __ballot(p == lp) & todo;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&cursor[lp], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (p == lp) rows[roff[lp] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+            todo &= ~same;
+        }
+    }
 }
 
 // keys are distinct: claim the first empty slot of the partition's table
@@ -355,7 +434,7 @@ __global__ __launch_bounds__(256) void k_gt_insert(KeyArr<W> keys, uint32_t n, G
                                                    uint32_t *__restrict__ overflow) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const Kmer<W> x = keys.load(i);
-        const uint64_t h = km_hash<W>(x);
+        const uint64_t h = gt_hash<W>(x);
         const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
         const uint32_t p = gp_of[i];
         const unsigned long long base = gt.off[p];
@@ -376,7 +455,7 @@ __global__ __launch_bounds__(256) void k_gt_insert(KeyArr<W> keys, uint32_t n, G
 template <int W>
 __device__ __forceinline__ uint32_t gt_lookup_in(const GraphTable &gt, const KeyArr<W> &keys, const Kmer<W> &q,
                                                  uint32_t p) {
-    const uint64_t h = km_hash<W>(q);
+    const uint64_t h = gt_hash<W>(q);
     const uint32_t fp = (uint32_t)(h >> 32);
     const unsigned long long base = gt.off[p];
     const uint32_t mask = gt.msk[p];
@@ -402,15 +481,51 @@ __device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr
 // prepended base b, both relative to the canonical orientation.  Also nb[2i+o]: the out-neighbour
 // of oriented node (i,o) when it has exactly one (NIL otherwise) — the correction and collapse
 // kernels then follow non-branching paths without hashing.
-// A neighbour's partition follows from this node's gm-mer hashes and ONE more hash: appending a base
-// drops the first gm-mer and adds one at the end, prepending drops the last and adds one in front.
+// One workgroup per graph partition: its mini table is copied to LDS once, and the ~90 % of probes
+// that stay inside the partition never leave the CU.  A neighbour's partition follows from this
+// node's gm-mer hashes and ONE more hash: appending a base drops the first gm-mer and adds one at
+// the end, prepending drops the last and adds one in front.
+static constexpr uint32_t ADJ_LDS_SLOTS = 4096;        // 32 KB; larger (skewed) partitions probe global memory
+
 template <int W>
-__global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, uint32_t n, int k, GraphTable gt,
+__global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, int k, GraphTable gt,
+                                                   const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rows,
                                                    uint8_t *__restrict__ adj, uint32_t *__restrict__ nb) {
     const unsigned gm = (unsigned)gt.gm;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    __shared__ uint2 lut[16];
+    __shared__ uint64_t tab[ADJ_LDS_SLOTS];
+    const uint32_t P = blockIdx.x;
+    const uint32_t r0 = roff[P], r1 = roff[P + 1];
+    if (r0 == r1) return;
+    nt32_fill_lut(lut, gm);
+    const uint32_t pmask = gt.msk[P];
+    const bool in_lds = pmask < ADJ_LDS_SLOTS;
+    if (in_lds) {
+        const uint64_t *src = gt.e + gt.off[P];
+        for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) tab[t] = src[t];
+    }
+    __syncthreads();
+    auto probe = [&](const Kmer<W> &c, uint32_t p) -> uint32_t {
+        if (p != P || !in_lds) return gt_lookup_in<W>(gt, keys, c, p);
+        const uint64_t h = gt_hash<W>(c);
+        const uint32_t fp = (uint32_t)(h >> 32);
+        uint32_t slot = (uint32_t)h & pmask;
+        for (uint32_t t = 0; t <= pmask; t++) {
+            const uint64_t e = tab[slot];
+            if (e == EMPTY64) return NIL;
+            if ((uint32_t)(e >> 32) == fp) {
+                const uint32_t idx = (uint32_t)e;
+                if (km_eq<W>(keys.load(idx), c)) return idx;
+            }
+            slot = (slot + 1) & pmask;
+        }
+        return NIL;
+    };
+    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+        const uint32_t i = rows[r];
         const Kmer<W> x = keys.load(i);
-        const MinScan ms = km_min_scan<W>(x, k, gt.gm);
+        const Kmer<W> rx = km_revcomp<W>(x, k);                    // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
+        const MinScan ms = km_min_scan_lut<W>(x, k, gt.gm, lut);
         const uint32_t out_b = km_base<W>(x, k, k - (int)gm);      // first base of the last gm-mer
         const uint32_t last_b = km_base<W>(x, k, (int)gm - 1);     // last base of the first gm-mer
         uint32_t a = 0, n_out = 0, n_in = 0, u_out = NIL, u_in = NIL;
@@ -418,18 +533,26 @@ __global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, uint32_t n, i
         for (uint32_t b = 0; b < 4; b++) {
             {
                 Kmer<W> s = x; km_push_back<W>(s, b, k);
-                int o; const Kmer<W> c = km_canonical<W>(s, k, o);
+                Kmer<W> rr = rx; km_push_front<W>(rr, 3u - b, k);
+                const bool o = km_less<W>(rr, s);
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = o ? rr.w[j] : s.w[j];
                 const uint32_t p = min(ms.min_wo_first, nt32_next_hash(ms.last, out_b, b, gm)) & gt.gp_mask;
-                const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
-                if (idx != NIL) { a |= 1u << b; n_out++; u_out = idx * 2u + (uint32_t)o; }
+                const uint32_t idx = probe(c, p);
+                if (idx != NIL) { a |= 1u << b; n_out++; u_out = idx * 2u + (o ? 1u : 0u); }
             }
             {
                 Kmer<W> s = x; km_push_front<W>(s, b, k);
-                int o; const Kmer<W> c = km_canonical<W>(s, k, o);
+                Kmer<W> rr = rx; km_push_back<W>(rr, 3u - b, k);
+                const bool o = km_less<W>(rr, s);
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = o ? rr.w[j] : s.w[j];
                 const uint32_t p = min(ms.min_wo_last, nt32_prev_hash(ms.first, b, last_b, gm)) & gt.gp_mask;
-                const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
+                const uint32_t idx = probe(c, p);
                 // predecessor q -> (x,0) is the edge (x,1) -> rc(q)
-                if (idx != NIL) { a |= 1u << (4 + b); n_in++; u_in = idx * 2u + ((uint32_t)o ^ 1u); }
+                if (idx != NIL) { a |= 1u << (4 + b); n_in++; u_in = idx * 2u + (o ? 0u : 1u); }
             }
         }
         adj[i] = (uint8_t)a;
@@ -1496,9 +1619,11 @@ public:
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
         if (int rc = gt_msk_.alloc(gp_, err)) return rc;
-        DevBuf<uint32_t> gp_of, gp_cnt;
+        DevBuf<uint32_t> gp_of, gp_cnt, gp_roff, gp_rows;
         if (int rc = gp_of.alloc(n, err)) return rc;
         if (int rc = gp_cnt.alloc(gp_, err)) return rc;
+        if (int rc = gp_roff.alloc(gp_ + 1, err)) return rc;
+        if (int rc = gp_rows.alloc(n, err)) return rc;
         if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
         if (int rc = adj0_.alloc(n, err)) return rc;
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
@@ -1513,14 +1638,18 @@ public:
             EvTimer t(stream_);
             hipLaunchKernelGGL(k_gp_count<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_, g.gt,
                                gp_of.p, gp_cnt.p);
-            hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, ctl_.p + 2);
+            hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, gp_roff.p,
+                               ctl_.p + 2);
+            HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
+            hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
+                               gp_rows.p);
             hipLaunchKernelGGL(k_gt_insert<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, g.gt,
                                gp_of.p, (uint32_t *)(ctl_.p + 1));
             HIPCHK(hipGetLastError());
             times_.add("graph_table_kernel", t.stop());
             EvTimer t2(stream_);
-            hipLaunchKernelGGL(k_adjacency<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_,
-                               g.gt, adj_.p, nb_.p);
+            hipLaunchKernelGGL(k_adjacency<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
+                               adj_.p, nb_.p);
             HIPCHK(hipGetLastError());
             times_.add("adjacency_kernel", t2.stop());
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
