@@ -70,7 +70,7 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
                     int do_bloom, int do_fit, int no_bubble_collapse, int no_dead_end_removal) {
     g_new_err = 0; g_new_msg.clear();
     if ((k & 1u) == 0 || k < SHK_K_MIN || k > SHK_K_MAX) {
-        g_new_err = SHK_E_PARAM; g_new_msg = "k must be odd and within [15, 63]"; return nullptr;
+        g_new_err = SHK_E_PARAM; g_new_msg = "k must be odd and within [15, 127]"; return nullptr;
     }
     if (min_qual > 93) { g_new_err = SHK_E_PARAM; g_new_msg = "min_qual out of range"; return nullptr; }
     if (min_count >= SHK_HISTO_BINS) { g_new_err = SHK_E_PARAM; g_new_msg = "min_count out of range"; return nullptr; }

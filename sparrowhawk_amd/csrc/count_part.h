@@ -58,7 +58,7 @@ static constexpr uint32_t WDESC_CAP = 1024;          // descriptors per wave
 static constexpr int DESC_CHECK = 4;                 // steps between room checks (64 new per step at most)
 
 struct PartShared {
-    uint32_t stage[STAGE_WORDS + 16];
+    uint32_t stage[STAGE_WORDS + 24];
     uint32_t desc_a[PART_WAVES][WDESC_CAP];   // tile-relative base offset (18 bits) | (n-1) << 18
     uint16_t desc_p[PART_WAVES][WDESC_CAP];
     uint32_t cursor[PART_MAX_P];
@@ -300,12 +300,12 @@ template <> struct CountShared<1> {
     uint16_t order[SR];                                 // occupied record slots, sorted by record length
     uint32_t nhist[64], nbase[64];
 };
-template <> struct CountShared<2> {
-    static constexpr uint32_t S = 6144;                 // 24 B / slot -> 144 KB
-    uint64_t key0[S];
-    uint64_t key1[S];
+// W >= 2: one key array per word, a state word per slot (0 empty, 1 being written, 2 ready)
+template <int W> struct CountShared {
+    static constexpr uint32_t S = (147456u / (8u * W + 8u)) & ~63u;   // 144 KB: 6144 / 4608 / 3584 slots for W = 2 / 3 / 4
+    uint64_t key[W][S];
     uint32_t cnt[S];
-    uint32_t state[S];                                  // 0 empty, 1 being written, 2 ready
+    uint32_t state[S];
 };
 
 struct CountCtl {
@@ -369,14 +369,18 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
             bool won = false;
             if (st == 0) { st = atomicCAS(&tb.state[slot], 0u, 1u); won = (st == 0); }
             if (won) {
-                tb.key0[slot] = key.w[0]; tb.key1[slot] = key.w[1];
+#pragma unroll
+                for (int j = 0; j < W; j++) tb.key[j][slot] = key.w[j];
                 __hip_atomic_store(&tb.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 atomicAdd(&ctl.n_used, 1u);
                 atomicAdd(&tb.cnt[slot], weight);
                 return true;
             }
             if (st == 1) continue;                          // owner is mid-write
-            if (tb.key0[slot] == key.w[0] && tb.key1[slot] == key.w[1]) { atomicAdd(&tb.cnt[slot], weight); return true; }
+            bool eq = true;
+#pragma unroll
+            for (int j = 0; j < W; j++) eq = eq && tb.key[j][slot] == key.w[j];
+            if (eq) { atomicAdd(&tb.cnt[slot], weight); return true; }
             slot = slot + 1 == S ? 0 : slot + 1;
             if (++probes >= S) return false;
         }
@@ -661,8 +665,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             if (e) {
                 const unsigned long long o = gbase + wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
                 if (o < out_cap) {
-                    Kmer<W> x; x.w[0] = tb.key0[s];
-                    if constexpr (W == 2) x.w[1] = tb.key1[s];
+                    Kmer<W> x;
+                    if constexpr (W == 1) x.w[0] = tb.key0[s];
+                    else {
+#pragma unroll
+                        for (int j = 0; j < W; j++) x.w[j] = tb.key[j][s];
+                    }
                     out_keys.store(o, x);
                     out_cnt[o] = c;
                 }

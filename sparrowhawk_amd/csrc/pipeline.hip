@@ -1979,6 +1979,8 @@ IPipeline *make_pipeline(int k, std::string &err) {
     IPipeline *p = nullptr;
     if (W == 1) { auto *q = new Pipeline<1>(k); rc = q->init(err); p = q; }
     else if (W == 2) { auto *q = new Pipeline<2>(k); rc = q->init(err); p = q; }
+    else if (W == 3) { auto *q = new Pipeline<3>(k); rc = q->init(err); p = q; }
+    else if (W == 4) { auto *q = new Pipeline<4>(k); rc = q->init(err); p = q; }
     else { err = "k too large for the compiled key widths"; return nullptr; }
     if (rc != 0) { delete p; return nullptr; }
     return p;

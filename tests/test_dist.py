@@ -57,7 +57,7 @@ def test_record_exchange_gloo_cpu(world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("k,do_fit,P", [(31, False, None), (51, True, 64)])
+@pytest.mark.parametrize("k,do_fit,P", [(31, False, None), (51, True, 64), (89, False, 128)])
 def test_sharded_pipeline_two_ranks_one_gpu(k, do_fit, P):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_dataset, run_oracle

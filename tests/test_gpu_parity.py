@@ -29,7 +29,9 @@ def contig_set(h):
 
 
 @pytest.mark.parametrize("k,err,cov", [(31, 0.0, 30), (31, 0.01, 40), (51, 0.01, 40), (21, 0.005, 25),
-                                        (63, 0.01, 40), (33, 0.0, 20)])
+                                        (63, 0.01, 40), (33, 0.0, 20),
+                                        (65, 0.005, 40), (89, 0.005, 40), (95, 0.0, 30), (97, 0.005, 40),
+                                        (127, 0.002, 40)])
 def test_full_pipeline_parity(k, err, cov):
     g, fq = make_dataset(30000, cov, err=err, seed=k + int(err * 1000))
     h = product(fq, k=k, min_count=3)
@@ -38,7 +40,7 @@ def test_full_pipeline_parity(k, err, cov):
     assert out["ncontigs"] >= 1
 
 
-@pytest.mark.parametrize("k", [31, 51])
+@pytest.mark.parametrize("k", [31, 51, 89, 127])
 def test_distinct_table_parity(k):
     """Stage (a): the complete (canonical k-mer, count) table before filtering."""
     g, fq = make_dataset(20000, 20, err=0.01, seed=40 + k)
@@ -287,7 +289,7 @@ def test_counting_modes_agree():
         assert np.array_equal(a.histo(), b.histo()) and a.total_instances == b.total_instances
 
 
-@pytest.mark.parametrize("k", [31, 51])
+@pytest.mark.parametrize("k", [31, 51, 89, 127])
 def test_partition_subrounds_when_lds_table_overflows(k):
     """Few partitions + many distinct k-mers: each partition exceeds the LDS table and is split
     into residue classes (count_part.h); results must not change."""
@@ -296,7 +298,7 @@ def test_partition_subrounds_when_lds_table_overflows(k):
     o = run_oracle([fq], k=k, min_count=0, min_qual=0)
     hk, hc, _ = sorted_table(*h.distinct())
     ok_, oc_ = o.distinct()
-    assert len(oc_) > 64 * 12288                       # really more than the tables hold
+    assert len(oc_) > 64 * (6144 if k <= 63 else 3648)  # really more than the LDS tables hold
     assert np.array_equal(hk, ok_) and np.array_equal(hc, oc_)
     assert np.array_equal(h.histo(), o.histo()) and h.total_instances == o.total_instances
 

@@ -33,7 +33,7 @@ def test_version(lib):
 
 
 def test_new_rejects_bad_parameters(lib):
-    for k in (30, 13, 65, 255):
+    for k in (30, 13, 64, 129, 255):
         assert not lib.shk_new(k, 1, 5, 20, 0, 0, 0, 0, 0)
         assert lib.shk_new_error() == -1
     assert not lib.shk_new(31, 1, 1, 20, 0, 1, 0, 0, 0)       # Bloom needs min_count >= 3

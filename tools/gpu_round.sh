@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 if [ "$TESTS" = tests ]; then
-  timeout -k 10 900 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1 || { tail -30 "$OUT/pytest.log"; exit 1; }
+  timeout -k 10 900 python -m pytest tests -m gpu -x -q --durations=8 > "$OUT/pytest.log" 2>&1 || { tail -30 "$OUT/pytest.log"; exit 1; }
   tail -3 "$OUT/pytest.log"
 fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench_line.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
