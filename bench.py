@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--k", type=int, default=31)
     ap.add_argument("--min-count", type=int, default=5)
+    ap.add_argument("--err", type=float, default=0.0, help="substitution error rate of the reads (configs[2]: 0.01 with --k 51)")
+    ap.add_argument("--mask-errors", action="store_true", help="erroneous bases carry a low quality and are masked "
+                    "(min_qual): reads are cut into error-free segments before they reach the device entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a one-GPU box together with --one-gpu)")
@@ -133,6 +136,11 @@ def main():
         d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
             torch, dev, args.genome * world, args.coverage, args.read_len, 0xEC02, read_seed=0x5EED + rank,
             n_reads=(args.genome * args.coverage + args.read_len - 1) // args.read_len)
+    elif args.err > 0:
+        from sparrowhawk_amd import synth
+        dr = synth.device_reads(torch, dev, args.genome, (args.genome * args.coverage + args.read_len - 1) // args.read_len,
+                                args.read_len, args.k, 0xEC03 + rank, err=args.err, mask_errors=args.mask_errors)
+        d_bases, d_seg, n_reads, n_bases, genome = dr.words, dr.seg_off, dr.n_seg, dr.n_bases, dr.genome
     else:
         # every rank owns one isolate of the batch (independent objects: no data-path collective)
         d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
@@ -182,7 +190,7 @@ def main():
     ncontigs = res["ncontigs"]
     # closed-form check of the last result: error-free reads of a repeat-free isolate
     # give one contig that is a substring of the genome (up to strand), ends trimmed by the filter
-    if args.coverage >= 30 and ncontigs == 1 and not sharded:
+    if args.coverage >= 30 and ncontigs == 1 and not sharded and args.err == 0:
         contig = res["outfasta"].split("\n")[1]
         gs = "".join("ACGT"[int(c)] for c in genome.cpu().tolist()) if args.genome <= 20_000_000 else None
         if gs is not None:
@@ -214,7 +222,7 @@ def main():
         "config": {"workload": (f"one pooled sample of {args.genome * world} bp, " if sharded else "") +
                                f"{args.genome} bp isolate per GPU, {args.coverage}x {args.read_len} bp reads "
                                f"({n_reads} reads, {n_bases} bases per GPU), k={args.k}, min_count={args.min_count}, "
-                               f"error-free, packed 2-bit in HBM",
+                               f"{'error-free' if args.err == 0 else ('%g substitution errors%s' % (args.err, ', masked by quality' if args.mask_errors else ''))}, packed 2-bit in HBM",
                    "parallelism": ("single GPU" if world == 1 else
                                    "one pooled sample, k-mer space sharded by minimiser partition, one RCCL all-to-all"
                                    if sharded else "one isolate per rank (batch of isolates), no data-path collective"),

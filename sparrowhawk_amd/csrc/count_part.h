@@ -312,7 +312,9 @@ struct CountCtl {
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
     uint32_t histo[500];
     uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor, rec_used, n_recs;
-    uint32_t stack_res[32], stack_mod[32];
+    // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
+    uint32_t st_res[16], st_step[16], st_factor[16], st_next[16];
+    uint32_t prog_num, prog_den;                        // how far the round got when the table filled up
     unsigned long long n_inst;
 };
 
@@ -345,7 +347,7 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
         constexpr uint32_t NB = CountShared<1>::NB;
         uint32_t b = (uint32_t)(((uint64_t)h * NB) >> 32);
         const unsigned long long kk = key.w[0];
-        for (uint32_t probes = 0; probes < NB;) {
+        for (uint32_t probes = 0; probes < 64u;) {          // a longer chain means the table is (locally) full: split
             const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(&tb.key0[4 * b]);
             const ulonglong2 c = *reinterpret_cast<const ulonglong2 *>(&tb.key0[4 * b + 2]);
             int j = a.x == kk ? 0 : a.y == kk ? 1 : c.x == kk ? 2 : c.y == kk ? 3 : -1;
@@ -382,7 +384,7 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
             for (int j = 0; j < W; j++) eq = eq && tb.key[j][slot] == key.w[j];
             if (eq) { atomicAdd(&tb.cnt[slot], weight); return true; }
             slot = slot + 1 == S ? 0 : slot + 1;
-            if (++probes >= S) return false;
+            if (++probes >= 256u) return false;             // table (locally) full: the caller splits the class
         }
     }
 }
@@ -508,7 +510,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             run += __shfl(incl, 63);
         }
         if (threadIdx.x == 0) {
-            ctl.pre[S_runs] = run; ctl.sp = 1; ctl.stack_res[0] = 0; ctl.stack_mod[0] = 1; ctl.n_inst = 0;
+            ctl.pre[S_runs] = run; ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
+            ctl.n_inst = 0;
         }
     }
     __syncthreads();
@@ -517,9 +520,14 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     while (true) {
         __syncthreads();
         if (ctl.sp == 0) break;
-        const uint32_t res = ctl.stack_res[ctl.sp - 1], mod = ctl.stack_mod[ctl.sp - 1];
+        const uint32_t top = ctl.sp - 1;
+        const uint32_t res = ctl.st_res[top] + ctl.st_next[top] * ctl.st_step[top], mod = ctl.st_step[top] * ctl.st_factor[top];
         __syncthreads();
-        if (threadIdx.x == 0) { ctl.sp--; ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0; }
+        if (threadIdx.x == 0) {
+            if (++ctl.st_next[top] == ctl.st_factor[top]) ctl.sp--;
+            ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
+            ctl.prog_num = 0; ctl.prog_den = 1;
+        }
         for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
             tb.cnt[s] = 0;
             if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
@@ -577,7 +585,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
 #pragma unroll
         for (int o = 0; o < RW; o++) nxt.w[o] = 0;
         uint32_t have_nxt = fetch(threadIdx.x, nxt);
+        if (threadIdx.x == 0) ctl.prog_den = R ? R : 1u;
         for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
+            // the table filled up: stop early (every insert into a full table walks a long probe chain);
+            // how far this round got sizes the split
+            if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, r0 + 1u); break; }
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
             have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
@@ -611,7 +623,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 if (tb.rst[s] >= 3u) tb.order[atomicAdd(&tb.nbase[(uint32_t)(tb.rhi[s] >> 58)], 1u)] = (uint16_t)s;
             __syncthreads();
             const uint32_t n_recs = ctl.n_recs;
+            // (a table that filled up in phase A keeps its progress mark; phase B then stops at once)
+            if (threadIdx.x == 0 && ctl.prog_num == 0) ctl.prog_den = n_recs ? n_recs : 1u;
+            __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_recs; i += COUNT_THREADS) {
+                if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i - threadIdx.x + 1u); break; }
                 const uint32_t s = tb.order[i];
                 Rec<RW> rec; rec.w[0] = tb.rlo[s]; rec.w[1] = tb.rhi[s];
                 expand(rec, (uint32_t)(rec.w[1] >> 58) + 1u, tb.rst[s] - 2u);
@@ -621,12 +637,17 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
         if (over) {
             // split this residue class in two and redo it (results of other classes are unaffected)
-            if (mod >= 4096 || ctl.sp + 2 > 32) { if (threadIdx.x == 0) flags[0] = 1; break; }
+            // split this residue class (results of other classes are unaffected).  The table held
+            // n_used keys after prog_num of prog_den records: aim the children at ~60 % of the table.
+            if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
             __syncthreads();
             if (threadIdx.x == 0) {
-                ctl.stack_res[ctl.sp] = res; ctl.stack_mod[ctl.sp] = mod * 2;
-                ctl.stack_res[ctl.sp + 1] = res + mod; ctl.stack_mod[ctl.sp + 1] = mod * 2;
-                ctl.sp += 2;
+                const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
+                const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
+                uint32_t factor = 2;
+                while ((double)factor * (0.6 * S) < est && mod * factor < 4096u) factor <<= 1;
+                ctl.st_res[ctl.sp] = res; ctl.st_step[ctl.sp] = mod; ctl.st_factor[ctl.sp] = factor; ctl.st_next[ctl.sp] = 0;
+                ctl.sp += 1;
             }
             continue;
         }

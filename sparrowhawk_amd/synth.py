@@ -53,3 +53,98 @@ def codes_to_str(codes):
 
 def revcomp_str(s):
     return s[::-1].translate(str.maketrans("ACGT", "TGCA"))
+
+
+# ---- device-side generator (torch on the GPU: plumbing for bench.py and the full-size tests) ----
+class DeviceReads:
+    """Packed reads resident in HBM in the layout shk_preprocess_packed_device takes, plus what the
+    generator knows about them (for closed-form checks)."""
+    def __init__(self):
+        self.words = None       # int32[ceil(n_bases/16)+1]   2-bit packed stream
+        self.seg_off = None     # int32[n_seg+1]
+        self.n_seg = 0
+        self.n_bases = 0
+        self.n_reads = 0
+        self.n_input_bases = 0
+        self.genome = None      # int32[genome_len] codes
+        self.starts = None      # int64[n_reads] (forward-strand start of each read)
+        self.strand = None      # bool[n_reads]  (True: read is the reverse complement)
+        self.err_fwd = None     # bool[n_reads, read_len] substitution flags in FORWARD-strand order (or None)
+        self.instances = 0      # valid k-mer windows (SPEC S4), from the generator's own masks
+
+
+def device_reads(torch, dev, genome_len, n_reads, read_len, k, seed, read_seed=None, err=0.0,
+                 mask_errors=False, keep_meta=False, chunk=1 << 18):
+    """Random genome + reads sampled uniformly from both strands, substitution errors at rate `err`.
+    mask_errors=True reproduces min_qual masking (SPEC S2) of erroneous bases tagged with a low
+    quality: reads are cut into their error-free segments (>= k bases), which gives ragged input."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    genome = torch.randint(0, 4, (genome_len,), generator=g, device=dev, dtype=torch.int32)
+    if read_seed is not None:
+        g.manual_seed(read_seed)
+    ar = torch.arange(read_len, device=dev)
+    out = DeviceReads()
+    out.genome, out.n_reads, out.n_input_bases = genome, n_reads, n_reads * read_len
+    code_chunks, len_chunks, metas = [], [], []
+    instances = 0
+    for r0 in range(0, n_reads, chunk):
+        r1 = min(n_reads, r0 + chunk)
+        R = r1 - r0
+        starts = torch.randint(0, genome_len - read_len + 1, (R,), generator=g, device=dev)
+        strand = torch.randint(0, 2, (R,), generator=g, device=dev).bool()
+        codes = genome[starts[:, None] + ar[None, :]]
+        e = None
+        if err > 0:
+            e = torch.rand((R, read_len), generator=g, device=dev) < err
+            shift = torch.randint(1, 4, (R, read_len), generator=g, device=dev, dtype=torch.int32)
+            codes = torch.where(e, (codes + shift) & 3, codes)
+        if keep_meta:
+            metas.append((starts, strand, e))
+        codes = torch.where(strand[:, None], (3 - codes).flip(1), codes)
+        if err > 0 and mask_errors:
+            ev = torch.where(strand[:, None], e.flip(1), e)
+            valid = ~ev
+            prev = torch.zeros_like(valid)
+            prev[:, 1:] = valid[:, :-1]
+            first = (valid & ~prev).reshape(-1)
+            v = valid.reshape(-1)
+            run_id = torch.cumsum(first.to(torch.int64), 0) - 1
+            n_runs = int(first.sum().item())
+            lens = torch.bincount(run_id[v], minlength=n_runs)
+            keep = lens >= k
+            keep_base = v.clone()
+            keep_base[v] = keep[run_id[v]]
+            code_chunks.append(codes.reshape(-1)[keep_base].to(torch.int8))
+            kl = lens[keep]
+            len_chunks.append(kl)
+            instances += int((kl - (k - 1)).sum().item())
+        else:
+            code_chunks.append(codes.reshape(-1).to(torch.int8))
+            len_chunks.append(torch.full((R,), read_len, device=dev, dtype=torch.int64))
+            instances += R * (read_len - k + 1)
+    codes = torch.cat(code_chunks)
+    lens = torch.cat(len_chunks)
+    del code_chunks
+    n_bases = codes.numel()
+    pad = (-n_bases) % 16
+    if pad:
+        codes = torch.cat([codes, torch.zeros(pad, dtype=torch.int8, device=dev)])
+    shifts = 2 * torch.arange(16, device=dev, dtype=torch.int32)
+    words = torch.empty(codes.numel() // 16 + 1, dtype=torch.int32, device=dev)
+    step = 1 << 26
+    for b0 in range(0, codes.numel(), step):
+        c = codes[b0:b0 + step].to(torch.int32).reshape(-1, 16)
+        words[b0 // 16:b0 // 16 + c.shape[0]] = (c << shifts[None, :]).sum(dim=1, dtype=torch.int32)
+    words[-1] = 0
+    seg_off = torch.zeros(lens.numel() + 1, dtype=torch.int64, device=dev)
+    seg_off[1:] = torch.cumsum(lens, 0)
+    out.words, out.seg_off = words, seg_off.to(torch.int32)
+    out.n_seg, out.n_bases, out.instances = int(lens.numel()), int(n_bases), instances
+    if keep_meta:
+        out.starts = torch.cat([m[0] for m in metas])
+        out.strand = torch.cat([m[1] for m in metas])
+        out.err_fwd = torch.cat([m[2] for m in metas]) if err > 0 else None
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return out
