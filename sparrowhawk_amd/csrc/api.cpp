@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "fastq.h"
+#include "fastq_gpu.h"
 #include "outputs.h"
 #include "pipeline.h"
 
@@ -149,10 +150,41 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
     h->post("preprocess:start");
     h->post_mode("start");
     h->post_mode("loop:start");
-    PackedReads pr;
     std::string err;
     const double t0 = now_ms();
     const size_t total = n1 + (fq2 ? n2 : 0);
+    // ---- device-side parsing (fastq_gpu.hip): regular 4-line FASTQ is parsed, masked, segmented and
+    // packed by streaming kernels; gzip members are inflated on the host first.  Irregular input and
+    // every malformed record go to the host parser below, which owns the error messages.
+    const char *force_host = getenv("SHK_HOST_PARSER");
+    if (!(force_host && *force_host == '1')) {
+        std::vector<uint8_t> st1, st2;
+        const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
+        int rc = maybe_inflate(fq1, n1, st1, t1, l1, err);
+        if (!rc && fq2) rc = maybe_inflate(fq2, n2, st2, t2, l2, err);
+        if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : SHK_E_OOM, err);
+        h->pipe->times().add("gunzip_host_clock", now_ms() - t0);
+        const double t1c = now_ms();
+        GpuPacked gp;
+        rc = gpu_pack_fastq(t1, l1, fq2 ? t2 : nullptr, l2, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err);
+        if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+        if (rc == 0) {
+            h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t1c);
+            const uint64_t every = h->progress_every();
+            for (size_t j = 0; j < gp.progress_bytes.size(); j++) {
+                const bool second = (gp.progress_bytes[j] >> 63) != 0;
+                const uint64_t bytes = gp.progress_bytes[j] & ~(1ull << 63);
+                const uint64_t pct = total ? (100 * ((second ? n1 : 0) + bytes)) / total : 100;
+                h->post_mode(("loop:" + std::to_string(every * (j + 1)) + ":" + std::to_string(pct)).c_str());
+            }
+            h->n_reads = gp.n_reads;
+            rc = run_counting(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases);
+            gpu_packed_free(gp);
+            return rc;
+        }
+        gpu_packed_free(gp);                            // rc == 1: not regular -> host parser
+    }
+    PackedReads pr;
     size_t done_before = 0;
     auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
         const uint64_t pct = total ? (100 * (done_before + bytes)) / total : 100;

@@ -48,6 +48,16 @@ static int inflate_all(const uint8_t *in, size_t n, std::vector<uint8_t> &out, s
     return 0;
 }
 
+int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,
+                  std::string &err) {
+    p = buf; pn = n;
+    if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
+        if (int rc = inflate_all(buf, n, storage, err)) return rc;
+        p = storage.data(); pn = storage.size();
+    }
+    return 0;
+}
+
 namespace {
 struct Lut {
     uint8_t code[256];

@@ -148,3 +148,20 @@ def device_reads(torch, dev, genome_len, n_reads, read_len, k, seed, read_seed=N
     if dev.type == "cuda":
         torch.cuda.synchronize()
     return out
+
+
+def to_fastq_fixed(codes, quals):
+    """Vectorised FASTQ text for large inputs: fixed-width records '@r%09d\\n<seq>\\n+\\n<qual>\\n'."""
+    n, L = codes.shape
+    rec = 11 + 1 + L + 1 + 2 + L + 1
+    out = np.empty((n, rec), dtype=np.uint8)
+    out[:, 0] = ord("@"); out[:, 1] = ord("r")
+    ids = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        out[:, 10 - d] = 48 + (ids // 10 ** d) % 10
+    out[:, 11] = 10
+    out[:, 12:12 + L] = _ASCII[codes]
+    out[:, 12 + L] = 10; out[:, 13 + L] = ord("+"); out[:, 14 + L] = 10
+    out[:, 15 + L:15 + 2 * L] = quals
+    out[:, 15 + 2 * L] = 10
+    return out.tobytes()

@@ -316,3 +316,65 @@ def test_partition_slice_overflow_retry():
     h = _with_env({"SHK_PART_P": 64}, lambda: product(fq, k=31, min_count=1))
     assert "partition_retry" in h.timings()
     compare_all(h, run_oracle([fq], k=31, min_count=1))
+
+
+def _both_parsers(f1, f2=None, k=21, min_count=0, min_qual=20, csize=0):
+    """The same input through the device FASTQ parser (default) and the host parser."""
+    a = product(f1, f2, k=k, min_count=min_count, min_qual=min_qual, csize=csize, assemble=False)
+    b = _with_env({"SHK_HOST_PARSER": 1},
+                  lambda: product(f1, f2, k=k, min_count=min_count, min_qual=min_qual, csize=csize, assemble=False))
+    ak, ac, _ = sorted_table(*a.distinct())
+    bk, bc, _ = sorted_table(*b.distinct())
+    assert np.array_equal(ak, bk) and np.array_equal(ac, bc)
+    assert a.total_instances == b.total_instances
+    assert a.states == b.states                         # progress strings, read counts and percentages included
+    assert a.get_preprocessing_info() == b.get_preprocessing_info()
+    return a, b
+
+
+def test_device_fastq_parser_equals_host_parser():
+    rng = np.random.default_rng(97)
+    g, fq = make_dataset(8000, 25, err=0.02, seed=97)
+    recs = fq.decode().split("\n")
+    # mixed case, N's, low qualities, CRLF on some lines
+    lines = []
+    for i in range(0, len(recs) - 1, 4):
+        name, seq, plus, qual = recs[i:i + 4]
+        seq = list(seq)
+        for j in rng.integers(0, len(seq), size=3):
+            seq[j] = "N" if rng.random() < 0.5 else seq[j].lower()
+        eol = "\r\n" if (i // 4) % 3 == 0 else "\n"
+        lines += [name + eol, "".join(seq) + eol, plus + "extra" + eol, qual + eol]
+    text = "".join(lines).encode()
+    half = text.index(b"@r" + str(len(lines) // 8).encode() + b"\r") if (b"@r" + str(len(lines) // 8).encode() + b"\r") in text else len(text) // 2
+    _both_parsers(text, csize=300)                                     # progress every 300 reads
+    _both_parsers(text[:-1] if text.endswith(b"\n") else text)         # last line not terminated
+    _both_parsers(text + b"\n\r\n\n")                                  # trailing blank lines
+    # two files; the first one unterminated; gzip (two members) for the second
+    cut = text.rfind(b"\n@r", 0, len(text) // 2) + 1
+    f1, f2 = text[:cut], text[cut:]
+    a, _ = _both_parsers(f1.rstrip(b"\r\n"), gzip.compress(f2[:len(f2) // 2]) + gzip.compress(f2[len(f2) // 2:]), csize=200)
+    b, _ = _both_parsers(text)
+    ak, ac, _ = sorted_table(*a.distinct())
+    bk, bc, _ = sorted_table(*b.distinct())
+    assert np.array_equal(ak, bk) and np.array_equal(ac, bc)
+    # against the oracle as well
+    o = run_oracle([text], k=21, min_count=0, min_qual=20)
+    ok_, oc_ = o.distinct()
+    assert np.array_equal(bk, ok_) and np.array_equal(bc, oc_)
+    # irregular framing (a blank line between records) is parsed by the host parser: same result
+    irregular = f1 + b"\n" + f2
+    c = product(irregular, k=21, min_count=0, assemble=False)
+    ck, cc, _ = sorted_table(*c.distinct())
+    assert np.array_equal(ck, bk) and np.array_equal(cc, bc)
+    # malformed records keep their error code and message whichever parser looks first
+    bad = text.replace(b"+extra", b"-extra", 1)
+    for data in (bad, text[: len(text) // 2 + 7], b"@x\nACGT\n+\nIII\n"):
+        h = AssemblyHelper.new(21, True, 0, 20, 0, False, False, False, False)
+        with pytest.raises(ShkError) as ei:
+            h.preprocess(data)
+        assert ei.value.code == -3
+    # empty inputs
+    for data in (b"", b"\n", b"\r\n\n"):
+        h = product(data, k=21, min_count=0, assemble=False)
+        assert h.n_distinct == 0
