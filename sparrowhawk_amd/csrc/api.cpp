@@ -170,6 +170,8 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
         if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
         if (rc == 0) {
             h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t1c);
+            h->pipe->times().add("fastq_h2d_text", gp.h2d_ms);
+            h->pipe->times().add("fastq_device_kernels", gp.kernels_ms);
             const uint64_t every = h->progress_every();
             for (size_t j = 0; j < gp.progress_bytes.size(); j++) {
                 const bool second = (gp.progress_bytes[j] >> 63) != 0;

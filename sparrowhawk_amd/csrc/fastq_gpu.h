@@ -10,6 +10,8 @@ namespace shk {
 struct GpuPacked {
     uint32_t *d_bases = nullptr;      // device: ceil(n_bases/16)+1 words
     uint32_t *d_seg_off = nullptr;    // device: n_seg+1
+    size_t bases_bytes = 0, seg_off_bytes = 0;      // pool block sizes
+    double h2d_ms = 0, kernels_ms = 0;
     uint64_t n_seg = 0, n_bases = 0, n_reads = 0, n_input_bases = 0;
     // one entry per `every` reads: bytes consumed inside the file the batch ends in; bit 63 = second file
     std::vector<unsigned long long> progress_bytes;

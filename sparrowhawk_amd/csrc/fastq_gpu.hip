@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "fastq_gpu.h"
+#include "pipeline.h"
 
 namespace shk {
 
@@ -65,16 +66,17 @@ static inline unsigned grid1(uint64_t work, unsigned block = 256, unsigned cap =
     uint64_t b = (work + block - 1) / block; if (b < 1) b = 1; if (b > cap) b = cap; return (unsigned)b;
 }
 
-struct Scratch {                                  // plain device allocations, freed on scope exit
-    std::vector<void *> ptrs;
-    ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
+struct Scratch {                                  // blocks of the process-wide device pool, returned on scope exit
+    std::vector<std::pair<void *, size_t>> ptrs;
+    ~Scratch() { for (auto &p : ptrs) if (p.first) device_pool_release(p.first, p.second); }
     template <typename T> T *get(size_t count, std::string &err) {
-        void *p = nullptr;
-        if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) { err = "hipMalloc failed (FASTQ parser)"; return nullptr; }
-        ptrs.push_back(p);
+        size_t bytes = (count ? count : 1) * sizeof(T);
+        void *p = device_pool_alloc(bytes);
+        if (!p) { err = "device allocation failed (FASTQ parser)"; return nullptr; }
+        ptrs.emplace_back(p, bytes);
         return (T *)p;
     }
-    void keep(void *p) { for (auto &q : ptrs) if (q == p) q = nullptr; }
+    size_t keep(void *p) { for (auto &q : ptrs) if (q.first == p) { q.first = nullptr; return q.second; } return 0; }
 };
 
 // in-place exclusive scan of a[0..n); *total (device) receives the sum
@@ -297,20 +299,25 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     const size_t off2 = e1 + ((unterm1 && e2) ? 1 : 0);
     const size_t e = off2 + e2;
     if (e == 0) {                                        // no records at all
-        uint32_t *so = nullptr;
-        FQCHK(hipMalloc((void **)&so, 8)); FQCHK(hipMemsetAsync(so, 0, 8, st));
-        uint32_t *bs = nullptr;
-        FQCHK(hipMalloc((void **)&bs, 8)); FQCHK(hipMemsetAsync(bs, 0, 8, st));
+        uint32_t *so = sc.get<uint32_t>(2, err), *bs = sc.get<uint32_t>(2, err);
+        if (!so || !bs) return -4;
+        FQCHK(hipMemsetAsync(so, 0, 8, st)); FQCHK(hipMemsetAsync(bs, 0, 8, st));
         FQCHK(hipStreamSynchronize(st));
+        out.bases_bytes = sc.keep(bs); out.seg_off_bytes = sc.keep(so);
         out.d_bases = bs; out.d_seg_off = so; return 0;
     }
     const bool unterminated = e2 ? unterm2 : unterm1;
     uint8_t *text = sc.get<uint8_t>(e + 32, err);
     if (!text) return -4;
+    hipEvent_t ev0, ev1, ev2;
+    FQCHK(hipEventCreate(&ev0)); FQCHK(hipEventCreate(&ev1)); FQCHK(hipEventCreate(&ev2));
+    struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evg{ev0, ev1, ev2};
+    FQCHK(hipEventRecord(ev0, st));
     if (e1) FQCHK(hipMemcpyAsync(text, t1, e1, hipMemcpyHostToDevice, st));
     if (off2 > e1) FQCHK(hipMemsetAsync(text + e1, '\n', 1, st));
     if (e2) FQCHK(hipMemcpyAsync(text + off2, t2, e2, hipMemcpyHostToDevice, st));
     FQCHK(hipMemsetAsync(text + e, 0, 32, st));
+    FQCHK(hipEventRecord(ev1, st));
 
     const uint64_t n_chunks = (e + NL_CHUNK - 1) / NL_CHUNK;
     unsigned long long *chunk_cnt = sc.get<unsigned long long>(n_chunks, err);
@@ -377,16 +384,18 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
             FQCHK(hipMemcpyAsync(out.progress_bytes.data(), marks, n_marks * 8, hipMemcpyDeviceToHost, st));
         }
     }
+    FQCHK(hipEventRecord(ev2, st));
     FQCHK(hipStreamSynchronize(st));
-    sc.keep(bases); sc.keep(seg_off);
+    { float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); out.h2d_ms = a; out.kernels_ms = b; }
+    out.bases_bytes = sc.keep(bases); out.seg_off_bytes = sc.keep(seg_off);
     out.d_bases = bases; out.d_seg_off = seg_off;
     out.n_seg = n_seg; out.n_bases = n_bases; out.n_reads = n_reads; out.n_input_bases = h[3];
     return 0;
 }
 
 void gpu_packed_free(GpuPacked &p) {
-    if (p.d_bases) (void)hipFree(p.d_bases);
-    if (p.d_seg_off) (void)hipFree(p.d_seg_off);
+    if (p.d_bases) device_pool_release(p.d_bases, p.bases_bytes);
+    if (p.d_seg_off) device_pool_release(p.d_seg_off, p.seg_off_bytes);
     p.d_bases = nullptr; p.d_seg_off = nullptr;
 }
 

@@ -72,5 +72,8 @@ uint64_t host_nthash(const char *seq, uint32_t k);
 int device_upload(const void *host, size_t bytes, void **dptr, std::string &err);
 void device_free(void *dptr);
 void device_pool_trim();
+// the process-wide device block cache (pipeline.hip): bytes is rounded up to the block actually handed out
+void *device_pool_alloc(size_t &bytes);
+void device_pool_release(void *p, size_t bytes);
 
 }  // namespace shk

@@ -427,30 +427,6 @@ __global__ __launch_bounds__(256) void k_gp_rows(const uint32_t *__restrict__ gp
     }
 }
 
-// keys are distinct: claim the first empty slot of the partition's table
-template <int W>
-__global__ __launch_bounds__(256) void k_gt_insert(KeyArr<W> keys, uint32_t n, GraphTable gt,
-                                                   const uint32_t *__restrict__ gp_of,
-                                                   uint32_t *__restrict__ overflow) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const Kmer<W> x = keys.load(i);
-        const uint64_t h = gt_hash<W>(x);
-        const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
-        const uint32_t p = gp_of[i];
-        const unsigned long long base = gt.off[p];
-        const uint32_t mask = gt.msk[p];
-        uint32_t slot = (uint32_t)h & mask;
-        bool done = false;
-        for (uint32_t t = 0; t <= mask; t++) {
-            unsigned long long old = atomicCAS((unsigned long long *)&gt.e[base + slot],
-                                               (unsigned long long)EMPTY64, (unsigned long long)entry);
-            if (old == EMPTY64) { done = true; break; }
-            slot = (slot + 1) & mask;
-        }
-        if (!done) *overflow = 1;
-    }
-}
-
 // membership probe in partition p's table
 template <int W>
 __device__ __forceinline__ uint32_t gt_lookup_in(const GraphTable &gt, const KeyArr<W> &keys, const Kmer<W> &q,
@@ -479,85 +455,157 @@ __device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr
 
 // adjacency byte (SPEC S8): bit b = successor by appended base b; bit 4+b = predecessor by
 // prepended base b, both relative to the canonical orientation.  Also nb[2i+o]: the out-neighbour
-// of oriented node (i,o) when it has exactly one (NIL otherwise) — the correction and collapse
-// kernels then follow non-branching paths without hashing.
-// One workgroup per graph partition: its mini table is copied to LDS once, and the ~90 % of probes
-// that stay inside the partition never leave the CU.  A neighbour's partition follows from this
-// node's gm-mer hashes and ONE more hash: appending a base drops the first gm-mer and adds one at
-// the end, prepending drops the last and adds one in front.
-static constexpr uint32_t ADJ_LDS_SLOTS = 4096;        // 32 KB; larger (skewed) partitions probe global memory
+// of oriented node (i,o) when it has exactly one (NIL none, NB_MULTI several) — the correction and
+// collapse kernels then follow non-branching paths without hashing.
+//
+// Two kernels.  k_graph_local, one workgroup per graph partition: builds the partition's mini table
+// in LDS from its rows (and stores it for everybody else), then resolves every neighbour candidate
+// that falls into the SAME partition (~90 %) against LDS; the others are written, densely, to the
+// partition's own query region (no global atomics).  k_graph_remote then answers those queries from
+// the stored tables with all lanes busy.  A neighbour's partition follows from this node's gm-mer
+// hashes and ONE more hash: appending a base drops the first gm-mer and adds one at the end,
+// prepending drops the last and adds one in front.
+static constexpr uint32_t ADJ_LDS_SLOTS = 4096;        // 32 KB; larger (skewed) partitions work in global memory
+static constexpr uint32_t NB_MULTI = 0xFFFFFFFEu;
+
+// candidate j of node x: j < 4 successor by appended base j, else predecessor by prepended base j-4
+template <int W>
+__device__ __forceinline__ Kmer<W> adj_candidate(const Kmer<W> &x, const Kmer<W> &rx, int k, uint32_t j, bool &o) {
+    Kmer<W> s = x, rr = rx;
+    if (j < 4) { km_push_back<W>(s, j, k); km_push_front<W>(rr, 3u - j, k); }
+    else { km_push_front<W>(s, j - 4u, k); km_push_back<W>(rr, 3u - (j - 4u), k); }
+    o = km_less<W>(rr, s);
+    Kmer<W> c;
+#pragma unroll
+    for (int w = 0; w < W; w++) c.w[w] = o ? rr.w[w] : s.w[w];
+    return c;
+}
 
 template <int W>
-__global__ __launch_bounds__(256) void k_adjacency(KeyArr<W> keys, int k, GraphTable gt,
-                                                   const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rows,
-                                                   uint8_t *__restrict__ adj, uint32_t *__restrict__ nb) {
+__global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, GraphTable gt,
+                                                     const uint32_t *__restrict__ roff, const uint32_t *__restrict__ rows,
+                                                     uint8_t *__restrict__ adj, uint32_t *__restrict__ nb,
+                                                     unsigned long long *__restrict__ queries, uint32_t *__restrict__ qcnt,
+                                                     uint32_t *__restrict__ overflow) {
     const unsigned gm = (unsigned)gt.gm;
     __shared__ uint2 lut[16];
     __shared__ uint64_t tab[ADJ_LDS_SLOTS];
+    __shared__ uint32_t q_fill;
     const uint32_t P = blockIdx.x;
     const uint32_t r0 = roff[P], r1 = roff[P + 1];
-    if (r0 == r1) return;
-    nt32_fill_lut(lut, gm);
     const uint32_t pmask = gt.msk[P];
     const bool in_lds = pmask < ADJ_LDS_SLOTS;
-    if (in_lds) {
-        const uint64_t *src = gt.e + gt.off[P];
-        for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) tab[t] = src[t];
-    }
+    uint64_t *gtab = gt.e + gt.off[P];
+    nt32_fill_lut(lut, gm);
+    if (threadIdx.x == 0) q_fill = 0;
+    // ---- build the mini table (keys are distinct: claim the first empty slot)
+    if (in_lds) { for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) tab[t] = EMPTY64; }
+    else { for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = EMPTY64; }
     __syncthreads();
-    auto probe = [&](const Kmer<W> &c, uint32_t p) -> uint32_t {
-        if (p != P || !in_lds) return gt_lookup_in<W>(gt, keys, c, p);
-        const uint64_t h = gt_hash<W>(c);
-        const uint32_t fp = (uint32_t)(h >> 32);
-        uint32_t slot = (uint32_t)h & pmask;
-        for (uint32_t t = 0; t <= pmask; t++) {
-            const uint64_t e = tab[slot];
-            if (e == EMPTY64) return NIL;
-            if ((uint32_t)(e >> 32) == fp) {
-                const uint32_t idx = (uint32_t)e;
-                if (km_eq<W>(keys.load(idx), c)) return idx;
-            }
-            slot = (slot + 1) & pmask;
-        }
-        return NIL;
-    };
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const uint32_t i = rows[r];
-        const Kmer<W> x = keys.load(i);
-        const Kmer<W> rx = km_revcomp<W>(x, k);                    // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
-        const MinScan ms = km_min_scan_lut<W>(x, k, gt.gm, lut);
-        const uint32_t out_b = km_base<W>(x, k, k - (int)gm);      // first base of the last gm-mer
-        const uint32_t last_b = km_base<W>(x, k, (int)gm - 1);     // last base of the first gm-mer
+        const uint64_t h = gt_hash<W>(keys.load(i));
+        const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
+        uint32_t slot = (uint32_t)h & pmask;
+        bool done = false;
+        for (uint32_t t = 0; t <= pmask; t++) {
+            unsigned long long *cell = in_lds ? (unsigned long long *)&tab[slot] : (unsigned long long *)&gtab[slot];
+            if (atomicCAS(cell, (unsigned long long)EMPTY64, (unsigned long long)entry) == EMPTY64) { done = true; break; }
+            slot = (slot + 1) & pmask;
+        }
+        if (!done) *overflow = 1;
+    }
+    __syncthreads();
+    if (in_lds) for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = tab[t];
+    // ---- neighbours
+    unsigned long long *myq = queries + 8ull * r0;
+    const int lane = threadIdx.x & 63;
+    const uint32_t n_rows = r1 - r0;
+    const uint32_t n_round = (n_rows + blockDim.x - 1) / blockDim.x * blockDim.x;
+    for (uint32_t rr_ = threadIdx.x; rr_ < n_round; rr_ += blockDim.x) {
+        const bool act = rr_ < n_rows;
+        const uint32_t i = act ? rows[r0 + rr_] : 0u;
+        Kmer<W> x = km_zero<W>(), rx = km_zero<W>();
+        MinScan ms{};
+        uint32_t out_b = 0, last_b = 0;
+        if (act) {
+            x = keys.load(i);
+            rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
+            ms = km_min_scan_lut<W>(x, k, gt.gm, lut);
+            out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer
+            last_b = km_base<W>(x, k, (int)gm - 1);                // last base of the first gm-mer
+        }
         uint32_t a = 0, n_out = 0, n_in = 0, u_out = NIL, u_in = NIL;
 #pragma unroll
-        for (uint32_t b = 0; b < 4; b++) {
-            {
-                Kmer<W> s = x; km_push_back<W>(s, b, k);
-                Kmer<W> rr = rx; km_push_front<W>(rr, 3u - b, k);
-                const bool o = km_less<W>(rr, s);
-                Kmer<W> c;
-#pragma unroll
-                for (int j = 0; j < W; j++) c.w[j] = o ? rr.w[j] : s.w[j];
-                const uint32_t p = min(ms.min_wo_first, nt32_next_hash(ms.last, out_b, b, gm)) & gt.gp_mask;
-                const uint32_t idx = probe(c, p);
-                if (idx != NIL) { a |= 1u << b; n_out++; u_out = idx * 2u + (o ? 1u : 0u); }
+        for (uint32_t j = 0; j < 8; j++) {
+            bool remote = false; uint32_t p = 0;
+            if (act) {
+                p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash(ms.last, out_b, j, gm))
+                           : min(ms.min_wo_last, nt32_prev_hash(ms.first, j - 4u, last_b, gm))) & gt.gp_mask;
+                remote = p != P || !in_lds;
+                if (!remote) {
+                    bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
+                    const uint64_t h = gt_hash<W>(c);
+                    const uint32_t fp = (uint32_t)(h >> 32);
+                    uint32_t slot = (uint32_t)h & pmask, idx = NIL;
+                    for (uint32_t t = 0; t <= pmask; t++) {
+                        const uint64_t e = tab[slot];
+                        if (e == EMPTY64) break;
+                        if ((uint32_t)(e >> 32) == fp && km_eq<W>(keys.load((uint32_t)e), c)) { idx = (uint32_t)e; break; }
+                        slot = (slot + 1) & pmask;
+                    }
+                    if (idx != NIL) {
+                        a |= 1u << j;
+                        // a predecessor q -> (x,0) is the edge (x,1) -> rc(q)
+                        if (j < 4) { n_out++; u_out = idx * 2u + (o ? 1u : 0u); }
+                        else { n_in++; u_in = idx * 2u + (o ? 0u : 1u); }
+                    }
+                }
             }
-            {
-                Kmer<W> s = x; km_push_front<W>(s, b, k);
-                Kmer<W> rr = rx; km_push_back<W>(rr, 3u - b, k);
-                const bool o = km_less<W>(rr, s);
-                Kmer<W> c;
-#pragma unroll
-                for (int j = 0; j < W; j++) c.w[j] = o ? rr.w[j] : s.w[j];
-                const uint32_t p = min(ms.min_wo_last, nt32_prev_hash(ms.first, b, last_b, gm)) & gt.gp_mask;
-                const uint32_t idx = probe(c, p);
-                // predecessor q -> (x,0) is the edge (x,1) -> rc(q)
-                if (idx != NIL) { a |= 1u << (4 + b); n_in++; u_in = idx * 2u + (o ? 0u : 1u); }
+            // queue the remote ones: wave-aggregated append to this partition's region
+            const unsigned long long m = __ballot(remote);
+            if (m) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&q_fill, (uint32_t)__popcll(m));
+                base = (uint32_t)__shfl((int)base, 0);
+                if (remote) myq[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
+                    (unsigned long long)i | ((unsigned long long)j << 32) | ((unsigned long long)p << 35);
             }
         }
-        adj[i] = (uint8_t)a;
-        uint2 v; v.x = n_out == 1 ? u_out : NIL; v.y = n_in == 1 ? u_in : NIL;
-        *reinterpret_cast<uint2 *>(nb + 2ull * i) = v;
+        if (act) {
+            adj[i] = (uint8_t)a;
+            uint2 v;
+            v.x = n_out == 0 ? NIL : (n_out == 1 ? u_out : NB_MULTI);
+            v.y = n_in == 0 ? NIL : (n_in == 1 ? u_in : NB_MULTI);
+            *reinterpret_cast<uint2 *>(nb + 2ull * i) = v;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) qcnt[P] = q_fill;
+}
+
+// answers the cross-partition queries of partition blockIdx.x
+template <int W>
+__global__ __launch_bounds__(256) void k_graph_remote(KeyArr<W> keys, int k, GraphTable gt,
+                                                      const uint32_t *__restrict__ roff,
+                                                      const unsigned long long *__restrict__ queries,
+                                                      const uint32_t *__restrict__ qcnt,
+                                                      uint8_t *__restrict__ adj, uint32_t *__restrict__ nb) {
+    const uint32_t P = blockIdx.x;
+    const unsigned long long *myq = queries + 8ull * roff[P];
+    const uint32_t nq = qcnt[P];
+    for (uint32_t t = threadIdx.x; t < nq; t += blockDim.x) {
+        const unsigned long long q = myq[t];
+        const uint32_t i = (uint32_t)q, j = (uint32_t)(q >> 32) & 7u, p = (uint32_t)(q >> 35);
+        const Kmer<W> x = keys.load(i);
+        const Kmer<W> rx = km_revcomp<W>(x, k);
+        bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
+        const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
+        if (idx == NIL) continue;
+        atomicOr((uint32_t *)adj + (i >> 2), (1u << j) << (8 * (i & 3u)));
+        const uint32_t u = j < 4 ? idx * 2u + (o ? 1u : 0u) : idx * 2u + (o ? 0u : 1u);
+        uint32_t *slot = nb + 2ull * i + (j < 4 ? 0 : 1);
+        if (atomicCAS(slot, NIL, u) != NIL) atomicExch(slot, NB_MULTI);     // second neighbour of this side
     }
 }
 
@@ -599,7 +647,7 @@ template <int W> struct Graph {
         // edges are only ever removed: a node that had one out-edge when the graph was built and has
         // one now still has that one.  Otherwise (it had several) look the survivor up.
         const uint32_t c = nb[v];
-        if (c != NIL) return c;
+        if (c < NB_MULTI) return c;                    // NIL cannot occur here (outdeg is 1 now, so it was >= 1)
         return follow(v, (uint32_t)__ffs((int)outmask(v)) - 1);
     }
 };
@@ -1114,6 +1162,8 @@ struct DevPool {
 };
 static DevPool &dev_pool() { static DevPool *p = new DevPool(); return *p; }   // never destroyed (HIP teardown order)
 void device_pool_trim() { dev_pool().trim(); }
+void *device_pool_alloc(size_t &bytes) { hipError_t e; return dev_pool().get(bytes, e); }
+void device_pool_release(void *p, size_t bytes) { dev_pool().put(p, bytes); }
 
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0; size_t bytes = 0;
@@ -1624,12 +1674,13 @@ public:
         if (int rc = gp_cnt.alloc(gp_, err)) return rc;
         if (int rc = gp_roff.alloc(gp_ + 1, err)) return rc;
         if (int rc = gp_rows.alloc(n, err)) return rc;
+        DevBuf<unsigned long long> queries;              // 8 slots per row, grouped by partition; only a prefix is touched
+        if (int rc = queries.alloc(8 * n + 8, err)) return rc;
         if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
         if (int rc = adj0_.alloc(n, err)) return rc;
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
-        HIPCHK(hipMemsetAsync(gt_.p, 0xFF, gt_slots_ * 8, stream_));
-        HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));
+        HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));   // (the mini tables are initialised by their builders)
         HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
         HIPCHK(hipMemsetAsync(alive_.p, 1, n ? n : 1, stream_));
         HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
@@ -1643,13 +1694,13 @@ public:
             HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
-            hipLaunchKernelGGL(k_gt_insert<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, g.gt,
-                               gp_of.p, (uint32_t *)(ctl_.p + 1));
             HIPCHK(hipGetLastError());
             times_.add("graph_table_kernel", t.stop());
             EvTimer t2(stream_);
-            hipLaunchKernelGGL(k_adjacency<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
-                               adj_.p, nb_.p);
+            hipLaunchKernelGGL(k_graph_local<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
+                               adj_.p, nb_.p, queries.p, gp_cnt.p, (uint32_t *)(ctl_.p + 1));
+            hipLaunchKernelGGL(k_graph_remote<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, queries.p,
+                               gp_cnt.p, adj_.p, nb_.p);
             HIPCHK(hipGetLastError());
             times_.add("adjacency_kernel", t2.stop());
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));

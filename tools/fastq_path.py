@@ -19,6 +19,6 @@ for name, env in (("device parser", "0"), ("host parser", "1")):
         t0 = time.perf_counter(); h.preprocess(fq); dt = time.perf_counter() - t0
         t = h.timings()
         print("%-14s run %d: preprocess %.1f ms = %.2f Gbases/s   %s" % (name, it, dt * 1e3, nb / dt / 1e9,
-              {k: round(v, 1) for k, v in t.items() if "host_clock" in k}), flush=True)
+              {k: round(v, 1) for k, v in t.items() if "host_clock" in k or "fastq" in k}), flush=True)
         h.assemble(); n = h.n_solid; h.free()
     print("   n_solid", n)
