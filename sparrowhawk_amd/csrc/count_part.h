@@ -415,6 +415,81 @@ __device__ __forceinline__ bool rec_insert(CountShared<1> &tb, CountCtl &ctl, ui
     return false;
 }
 
+// empty table, zero round-local histogram (all threads; ends with a barrier)
+template <int W> __device__ __forceinline__ void table_reset(CountShared<W> &tb, CountCtl &ctl) {
+    constexpr uint32_t S = CountShared<W>::S;
+    for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
+        tb.cnt[s] = 0;
+        if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
+    }
+    if constexpr (W == 1)
+        for (uint32_t s = threadIdx.x; s < CountShared<1>::SR; s += COUNT_THREADS) tb.rst[s] = 0;
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
+    __syncthreads();
+}
+
+// a finished round: histogram of the table's counts, rows with count > threshold appended to the output
+template <int W>
+__device__ __forceinline__ void table_emit(CountShared<W> &tb, CountCtl &ctl, unsigned long long mine, uint32_t threshold,
+                                           unsigned long long *__restrict__ histo, KeyArr<W> out_keys,
+                                           uint32_t *__restrict__ out_cnt, unsigned long long out_cap,
+                                           unsigned long long *__restrict__ out_cursor) {
+    constexpr uint32_t S = CountShared<W>::S;
+    const int lane = threadIdx.x & 63;
+    // ---- scan 1: histogram + number of rows to emit
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+    if (lane == 0 && mine) atomicAdd(&ctl.n_inst, mine);
+    uint32_t my_emit = 0;
+    for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
+        const uint32_t c = tb.cnt[s];
+        if (c) {
+            atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
+            if (c > threshold) my_emit++;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) my_emit += __shfl_down(my_emit, o);
+    if (lane == 0 && my_emit) atomicAdd(&ctl.n_emit, my_emit);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long base = ctl.n_emit ? atomicAdd(out_cursor, (unsigned long long)ctl.n_emit) : 0ull;
+        ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
+    }
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+        if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
+    __syncthreads();
+    // ---- scan 2: write rows (wave-aggregated reservation inside the workgroup's range)
+    const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
+    const uint32_t s_round = (S + COUNT_THREADS - 1) / COUNT_THREADS * COUNT_THREADS;
+    for (uint32_t s = threadIdx.x; s < s_round; s += COUNT_THREADS) {
+        const uint32_t c = s < S ? tb.cnt[s] : 0u;
+        const bool e = c > threshold && c != 0;
+        const unsigned long long em = __ballot(e);
+        if (!em) continue;
+        uint32_t wb = 0;
+        if (lane == 0) wb = atomicAdd(&ctl.wave_cursor, (uint32_t)__popcll(em));
+        wb = __shfl(wb, 0);
+        if (e) {
+            const unsigned long long o = gbase + wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+            if (o < out_cap) {
+                Kmer<W> x;
+                if constexpr (W == 1) x.w[0] = tb.key0[s];
+                else {
+#pragma unroll
+                    for (int j = 0; j < W; j++) x.w[j] = tb.key[j][s];
+                }
+                out_keys.store(o, x);
+                out_cnt[o] = c;
+            }
+        }
+    }
+}
+
+// a partition whose distinct k-mers do not fit the LDS table (reported by k_count_partitions)
+struct OvfRec { uint32_t p, est_distinct; unsigned long long instances; };
+// ... and how it is repartitioned at k-mer level: F buckets of `cap` k-mers starting at k-mer index `base`
+struct OvfItem { uint32_t p, F, cap, pad; unsigned long long base; };
+static constexpr uint32_t OVF_MAX_F = 256;
+
 // A partition's records arrive as S runs (local: one per producer workgroup; sharded: one per
 // source rank): run j of partition p holds run_cnt[p*S+j] records starting at record run_off[p*S+j].
 struct RunView {
@@ -489,12 +564,15 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     RunView rvw, uint32_t threshold,
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
-    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags) {
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags,
+    const uint32_t *__restrict__ part_list /* nullable: partitions to process */,
+    OvfRec *__restrict__ ovf /* nullable: partitions that do not fit are listed here instead of being split */,
+    uint32_t *__restrict__ ovf_n) {
     constexpr int RW = 2 * W;
     constexpr uint32_t S = CountShared<W>::S;
     __shared__ CountShared<W> tb;
     __shared__ CountCtl ctl;
-    const uint32_t p = blockIdx.x;
+    const uint32_t p = part_list ? part_list[blockIdx.x] : blockIdx.x;
     const int lane = threadIdx.x & 63;
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
@@ -528,14 +606,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
             ctl.prog_num = 0; ctl.prog_den = 1;
         }
-        for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
-            tb.cnt[s] = 0;
-            if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
-        }
-        if constexpr (W == 1)
-            for (uint32_t s = threadIdx.x; s < CountShared<1>::SR; s += COUNT_THREADS) tb.rst[s] = 0;
-        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
-        __syncthreads();
+        table_reset<W>(tb, ctl);
 
         unsigned long long mine = 0;
         // the record of the NEXT batch is requested before the current one is expanded, so its
@@ -635,8 +706,29 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
         __syncthreads();
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
+        if (over && ovf && mod == 1) {
+            // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets):
+            // report the estimated number of distinct k-mers and the exact number of instances
+            unsigned long long inst = 0;
+            for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
+                uint32_t lo = 0, hi = S_runs;
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
+                const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
+                inst += (src[RW - 1] >> 58) + 1ull;
+            }
+            for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+            if (lane == 0 && inst) atomicAdd(&ctl.n_inst, inst);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
+                const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
+                const uint32_t slot = atomicAdd(ovf_n, 1u);
+                OvfRec o; o.p = p; o.est_distinct = est > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)est; o.instances = ctl.n_inst;
+                ovf[slot] = o;
+            }
+            return;
+        }
         if (over) {
-            // split this residue class in two and redo it (results of other classes are unaffected)
             // split this residue class (results of other classes are unaffected).  The table held
             // n_used keys after prog_num of prog_den records: aim the children at ~60 % of the table.
             if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
@@ -651,55 +743,150 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             }
             continue;
         }
-        // ---- scan 1: histogram + number of rows to emit
-        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-        if (lane == 0 && mine) atomicAdd(&ctl.n_inst, mine);
-        uint32_t my_emit = 0;
-        for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
-            const uint32_t c = tb.cnt[s];
-            if (c) {
-                atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
-                if (c > threshold) my_emit++;
-            }
+        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
+}
+
+
+// k-mer-level repartition of one overflowed partition: every canonical k-mer of its records goes to
+// bucket (hash bits 12..) of the item's region; cursors live in LDS, the fills are published at the end
+template <int W>
+__global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, const OvfItem *__restrict__ items,
+                                                               uint64_t *__restrict__ kmers,
+                                                               uint32_t *__restrict__ bucket_fill) {
+    constexpr int RW = 2 * W;
+    __shared__ uint32_t pre[257];
+    __shared__ uint32_t cursor[OVF_MAX_F];
+    const OvfItem it = items[blockIdx.x];
+    const uint32_t p = it.p, S_runs = rvw.S;
+    const int lane = threadIdx.x & 63;
+    const int k = rvw.k;
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
+            const uint32_t g = g0 + threadIdx.x;
+            uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
+            uint32_t incl = f;
+            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (g < S_runs) pre[g] = run + incl - f;
+            run += __shfl(incl, 63);
         }
-        for (int o = 32; o > 0; o >>= 1) my_emit += __shfl_down(my_emit, o);
-        if (lane == 0 && my_emit) atomicAdd(&ctl.n_emit, my_emit);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long base = ctl.n_emit ? atomicAdd(out_cursor, (unsigned long long)ctl.n_emit) : 0ull;
-            ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
-        }
-        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
-            if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
-        __syncthreads();
-        // ---- scan 2: write rows (wave-aggregated reservation inside the workgroup's range)
-        const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
-        const uint32_t s_round = (S + COUNT_THREADS - 1) / COUNT_THREADS * COUNT_THREADS;
-        for (uint32_t s = threadIdx.x; s < s_round; s += COUNT_THREADS) {
-            const uint32_t c = s < S ? tb.cnt[s] : 0u;
-            const bool e = c > threshold && c != 0;
-            const unsigned long long em = __ballot(e);
-            if (!em) continue;
-            uint32_t wb = 0;
-            if (lane == 0) wb = atomicAdd(&ctl.wave_cursor, (uint32_t)__popcll(em));
-            wb = __shfl(wb, 0);
-            if (e) {
-                const unsigned long long o = gbase + wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-                if (o < out_cap) {
-                    Kmer<W> x;
-                    if constexpr (W == 1) x.w[0] = tb.key0[s];
-                    else {
+        if (threadIdx.x == 0) pre[S_runs] = run;
+    }
+    for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) cursor[b] = 0;
+    __syncthreads();
+    const uint32_t R = pre[S_runs];
+    const uint32_t fmask = it.F - 1u;
+    for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
+        uint32_t lo = 0, hi = S_runs;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
+        const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - pre[lo])) * RW;
+        Rec<RW> rec;
 #pragma unroll
-                        for (int j = 0; j < W; j++) x.w[j] = tb.key[j][s];
-                    }
-                    out_keys.store(o, x);
-                    out_cnt[o] = c;
-                }
+        for (int o = 0; o < RW; o += 2) {
+            const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
+            rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
+        }
+        const uint32_t n = (uint32_t)(rec.w[RW - 1] >> 58) + 1u;
+        Kmer<W> f = km_zero<W>();
+        for (uint32_t s = 0; s < n; s++) {
+            if (s) {
+#pragma unroll
+                for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
+                rec.w[RW - 1] >>= 2;
+            }
+            Kmer<W> rv;
+#pragma unroll
+            for (int j = 0; j < W; j++) rv.w[j] = ~rec.w[j];
+            rv.w[W - 1] &= km_topmask<W>(k);
+            if (s) km_push_back<W>(f, (uint32_t)(rec.w[W - 1] >> ((2 * (k - 1)) & 63)) & 3u, k);
+            else f = km_revcomp<W>(rv, k);
+            const bool use_r = km_less<W>(rv, f);
+            Kmer<W> c;
+#pragma unroll
+            for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
+            const uint32_t b = (km_mix32<W>(c) >> 12) & fmask;
+            const uint32_t pos = atomicAdd(&cursor[b], 1u);
+            if (pos < it.cap) {
+                uint64_t *dst = kmers + (it.base + (unsigned long long)b * it.cap + pos) * W;
+#pragma unroll
+                for (int j = 0; j < W; j++) dst[j] = c.w[j];
             }
         }
     }
     __syncthreads();
+    for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) bucket_fill[(uint64_t)blockIdx.x * OVF_MAX_F + b] = cursor[b];
+}
+
+// counts one bucket of canonical k-mers (blockIdx.x = bucket, blockIdx.y = item); the same table, the
+// same emit and — should a bucket still not fit — the same residue-class splitting as k_count_partitions
+template <int W>
+__global__ __launch_bounds__(COUNT_THREADS) void k_count_buckets(
+    const OvfItem *__restrict__ items, const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ bucket_fill,
+    uint32_t threshold, unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
+    unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags) {
+    constexpr uint32_t S = CountShared<W>::S;
+    __shared__ CountShared<W> tb;
+    __shared__ CountCtl ctl;
+    const OvfItem it = items[blockIdx.y];
+    if (blockIdx.x >= it.F) return;
+    const uint32_t nb = min(bucket_fill[(uint64_t)blockIdx.y * OVF_MAX_F + blockIdx.x], it.cap);
+    if (nb == 0) return;
+    const uint64_t *src = kmers + (it.base + (unsigned long long)blockIdx.x * it.cap) * W;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x == 0) {
+        ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0; ctl.n_inst = 0;
+    }
+    while (true) {
+        __syncthreads();
+        if (ctl.sp == 0) break;
+        const uint32_t top = ctl.sp - 1;
+        const uint32_t res = ctl.st_res[top] + ctl.st_next[top] * ctl.st_step[top], mod = ctl.st_step[top] * ctl.st_factor[top];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (++ctl.st_next[top] == ctl.st_factor[top]) ctl.sp--;
+            ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
+            ctl.prog_num = 0; ctl.prog_den = nb;
+        }
+        table_reset<W>(tb, ctl);
+        unsigned long long mine = 0;
+        for (uint32_t i0 = 0; i0 < nb; i0 += COUNT_THREADS) {
+            if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i0 + 1u); break; }
+            const uint32_t i = i0 + threadIdx.x;
+            if (i < nb) {
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = src[(uint64_t)i * W + j];
+                const uint32_t h = km_mix32<W>(c);
+                if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {
+                    if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u)) ctl.overflow = 1;
+                    mine++;
+                }
+            }
+        }
+        __syncthreads();
+        const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
+        if (over) {
+            if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
+                const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
+                uint32_t factor = 2;
+                while ((double)factor * (0.6 * S) < est && mod * factor < 4096u) factor <<= 1;
+                ctl.st_res[ctl.sp] = res; ctl.st_step[ctl.sp] = mod; ctl.st_factor[ctl.sp] = factor; ctl.st_next[ctl.sp] = 0;
+                ctl.sp += 1;
+            }
+            continue;
+        }
+        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor);
+    }
+    __syncthreads();
     if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
+    (void)lane;
 }
 
 }  // namespace shk

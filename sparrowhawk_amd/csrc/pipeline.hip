@@ -1393,13 +1393,20 @@ public:
         return -6;
     }
 
-    // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying
+    // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying.
+    // Partitions whose distinct k-mers do not fit the LDS table are listed by the first launch and
+    // then repartitioned at k-mer level (k_ovf_scatter -> k_count_buckets); should a bucket region
+    // overflow (extreme skew), that partition falls back to in-kernel residue-class re-runs.
     int run_count_partitions(const RunView &rv, uint32_t n_parts, uint32_t threshold, DevBuf<uint64_t> (&keys)[W],
                              DevBuf<uint32_t> &cnt, uint64_t &n_rows, uint64_t hist_out[500], uint64_t &inst_out,
                              uint64_t cap_hint, double &ms_out, std::string &err) {
         if (n_parts == 0) { n_rows = 0; inst_out = 0; memset(hist_out, 0, 500 * 8); ms_out = 0; return 0; }
+        constexpr uint32_t S = CountShared<W>::S;
+        const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0;
         DevBuf<unsigned long long> dh;
+        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list; DevBuf<uint64_t> d_kmers;
         if (int rc = dh.alloc(500, err)) return rc;
+        if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
         uint64_t cap = cap_hint;
         for (int attempt = 0; attempt < 2; attempt++) {
             for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
@@ -1410,11 +1417,67 @@ public:
             EvTimer t(stream_);
             hipLaunchKernelGGL(k_count_partitions<W>, dim3(n_parts), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
-                               (uint32_t *)(ctl_.p + 2));
+                               (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
+                               (uint32_t *)(ctl_.p + 3));
             HIPCHK(hipGetLastError());
             ms_out = t.stop();
-            unsigned long long h[3];
+            unsigned long long h[4];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            const uint32_t n_ovf = (uint32_t)h[3];
+            if (n_ovf) {
+                EvTimer t2(stream_);
+                std::vector<OvfRec> ov(n_ovf);
+                HIPCHK(hipMemcpy(ov.data(), d_ovf.p, (size_t)n_ovf * sizeof(OvfRec), hipMemcpyDeviceToHost));
+                std::vector<OvfItem> items(n_ovf);
+                unsigned long long total = 0;
+                for (uint32_t i = 0; i < n_ovf; i++) {
+                    uint32_t F = 2;
+                    while ((double)F * (0.45 * S) < (double)ov[i].est_distinct && F < OVF_MAX_F) F <<= 1;
+                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 125) / (100ull * F) + 256;   // 25 % slack
+                    items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
+                    items[i].pad = 0; items[i].base = total;
+                    total += (unsigned long long)F * items[i].cap;
+                }
+                if (int rc = d_items.alloc(n_ovf, err)) return rc;
+                if (int rc = d_fill.alloc((size_t)n_ovf * OVF_MAX_F, err)) return rc;
+                if (int rc = d_kmers.alloc(total * W, err)) return rc;
+                HIPCHK(hipMemcpyAsync(d_items.p, items.data(), (size_t)n_ovf * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(n_ovf), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
+                HIPCHK(hipGetLastError());
+                std::vector<uint32_t> fill((size_t)n_ovf * OVF_MAX_F);
+                HIPCHK(hipMemcpyAsync(fill.data(), d_fill.p, fill.size() * 4, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(hipStreamSynchronize(stream_));
+                // items with a bucket region that overflowed are re-run by residue classes instead
+                std::vector<OvfItem> good; std::vector<uint32_t> good_fill, bad;
+                for (uint32_t i = 0; i < n_ovf; i++) {
+                    bool okb = true;
+                    for (uint32_t b = 0; b < items[i].F; b++) okb = okb && fill[(size_t)i * OVF_MAX_F + b] <= items[i].cap;
+                    if (okb) { good.push_back(items[i]); good_fill.insert(good_fill.end(), fill.begin() + (size_t)i * OVF_MAX_F, fill.begin() + (size_t)(i + 1) * OVF_MAX_F); }
+                    else bad.push_back(items[i].p);
+                }
+                if (!good.empty()) {
+                    HIPCHK(hipMemcpyAsync(d_items.p, good.data(), good.size() * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
+                    HIPCHK(hipMemcpyAsync(d_fill.p, good_fill.data(), good_fill.size() * 4, hipMemcpyHostToDevice, stream_));
+                    hipLaunchKernelGGL(k_count_buckets<W>, dim3(OVF_MAX_F, (unsigned)good.size()), dim3(COUNT_THREADS), 0, stream_,
+                                       d_items.p, d_kmers.p, d_fill.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                                       ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2));
+                    HIPCHK(hipGetLastError());
+                }
+                if (!bad.empty()) {
+                    if (int rc = d_list.alloc(bad.size(), err)) return rc;
+                    HIPCHK(hipMemcpyAsync(d_list.p, bad.data(), bad.size() * 4, hipMemcpyHostToDevice, stream_));
+                    hipLaunchKernelGGL(k_count_partitions<W>, dim3((unsigned)bad.size()), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
+                                       dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
+                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr);
+                    HIPCHK(hipGetLastError());
+                }
+                ms_out += t2.stop();
+                times_.add("count_repartitioned_x1", (double)good.size());
+                times_.add("count_residue_rerun_x1", (double)bad.size());
+                HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(hipStreamSynchronize(stream_));
+            }
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
             if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way splitting"; return -6; }

@@ -289,18 +289,35 @@ def test_counting_modes_agree():
         assert np.array_equal(a.histo(), b.histo()) and a.total_instances == b.total_instances
 
 
-@pytest.mark.parametrize("k", [31, 51, 89, 127])
-def test_partition_subrounds_when_lds_table_overflows(k):
-    """Few partitions + many distinct k-mers: each partition exceeds the LDS table and is split
-    into residue classes (count_part.h); results must not change."""
+@pytest.mark.parametrize("k,mode", [(31, "repartition"), (51, "repartition"), (89, "repartition"), (127, "repartition"),
+                                    (31, "residue"), (51, "residue"), (31, "tiny_buckets")])
+def test_partitions_that_exceed_the_lds_table(k, mode):
+    """Few partitions + many distinct k-mers: each partition exceeds the LDS table.  It is then
+    repartitioned at k-mer level (k_ovf_scatter / k_count_buckets); with that switched off, or when a
+    bucket region overflows, it is re-run per residue class of the key hash (count_part.h).  Results
+    must not change."""
     g, fq = make_dataset(150000, 12, err=0.02, seed=92)
-    h = _with_env({"SHK_PART_P": 64}, lambda: product(fq, k=k, min_count=0, min_qual=0, assemble=False))
+    env = {"SHK_PART_P": 64}
+    if mode == "residue":
+        env["SHK_NO_REPARTITION"] = 1
+    if mode == "tiny_buckets":
+        env["SHK_OVF_CAP_PCT"] = 60                      # bucket regions overflow -> residue-class fallback per partition
+    def both():
+        hh = product(fq, k=k, min_count=0, min_qual=0, assemble=False)
+        tt = hh.timings()                                # of the preprocess run (distinct() counts again)
+        return hh, tt, sorted_table(*hh.distinct())
+    h, t, (hk, hc, _) = _with_env(env, both)
     o = run_oracle([fq], k=k, min_count=0, min_qual=0)
-    hk, hc, _ = sorted_table(*h.distinct())
     ok_, oc_ = o.distinct()
     assert len(oc_) > 64 * (6144 if k <= 63 else 3648)  # really more than the LDS tables hold
     assert np.array_equal(hk, ok_) and np.array_equal(hc, oc_)
     assert np.array_equal(h.histo(), o.histo()) and h.total_instances == o.total_instances
+    if mode == "repartition":
+        assert t.get("count_repartitioned_x1", 0) > 0
+    if mode == "residue":
+        assert "count_repartitioned_x1" not in t
+    if mode == "tiny_buckets":
+        assert t.get("count_residue_rerun_x1", 0) > 0
 
 
 def test_partition_slice_overflow_retry():
