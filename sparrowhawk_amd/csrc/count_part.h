@@ -315,7 +315,7 @@ struct CountCtl {
     // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
     uint32_t st_res[16], st_step[16], st_factor[16], st_next[16];
     uint32_t prog_num, prog_den;                        // how far the round got when the table filled up
-    unsigned long long n_inst;
+    unsigned long long n_inst, tried;
 };
 
 // Table placement hash: add/shift/xor only (Jenkins one-at-a-time finaliser); integer multiplies
@@ -384,7 +384,7 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
             for (int j = 0; j < W; j++) eq = eq && tb.key[j][slot] == key.w[j];
             if (eq) { atomicAdd(&tb.cnt[slot], weight); return true; }
             slot = slot + 1 == S ? 0 : slot + 1;
-            if (++probes >= 256u) return false;             // table (locally) full: the caller splits the class
+            if (++probes >= 48u) return false;              // table (locally) full: the caller splits the class
         }
     }
 }
@@ -630,6 +630,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         auto expand = [&](Rec<RW> rec, uint32_t n, uint32_t weight) {
             Kmer<W> f = km_zero<W>();
             for (uint32_t s = 0; s < n; s++) {
+                if (ctl.overflow) return;                   // the round is lost: do not walk full-table probe chains
                 if (s) {
 #pragma unroll
                     for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
@@ -709,6 +710,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         if (over && ovf && mod == 1) {
             // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets):
             // report the estimated number of distinct k-mers and the exact number of instances
+            // distinct / instance ratio of what was inserted before the table filled up, times all instances
+            if (threadIdx.x == 0) ctl.tried = 0;
+            __syncthreads();
+            for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+            if (lane == 0 && mine) atomicAdd(&ctl.tried, mine);
             unsigned long long inst = 0;
             for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
                 uint32_t lo = 0, hi = S_runs;
@@ -720,8 +726,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             if (lane == 0 && inst) atomicAdd(&ctl.n_inst, inst);
             __syncthreads();
             if (threadIdx.x == 0) {
-                const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
-                const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
+                const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.n_inst / (double)ctl.tried : (double)ctl.n_inst;
                 const uint32_t slot = atomicAdd(ovf_n, 1u);
                 OvfRec o; o.p = p; o.est_distinct = est > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)est; o.instances = ctl.n_inst;
                 ovf[slot] = o;

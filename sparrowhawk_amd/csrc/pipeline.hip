@@ -1434,7 +1434,7 @@ public:
                 for (uint32_t i = 0; i < n_ovf; i++) {
                     uint32_t F = 2;
                     while ((double)F * (0.45 * S) < (double)ov[i].est_distinct && F < OVF_MAX_F) F <<= 1;
-                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 125) / (100ull * F) + 256;   // 25 % slack
+                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 150) / (100ull * F) + 256;   // 50 % slack
                     items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
                     items[i].pad = 0; items[i].base = total;
                     total += (unsigned long long)F * items[i].cap;
@@ -1474,6 +1474,8 @@ public:
                 }
                 ms_out += t2.stop();
                 times_.add("count_repartitioned_x1", (double)good.size());
+                { double sf = 0, se = 0, si = 0; for (auto &it : items) sf += it.F; for (auto &o : ov) { se += o.est_distinct; si += (double)o.instances; }
+                  times_.add("count_repart_mean_F", sf / n_ovf); times_.add("count_repart_mean_est", se / n_ovf); times_.add("count_repart_mean_inst", si / n_ovf); }
                 times_.add("count_residue_rerun_x1", (double)bad.size());
                 HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipStreamSynchronize(stream_));
