@@ -285,27 +285,33 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 }
 
 // ---- pass 2 -------------------------------------------------------------------------------
-template <int W> struct CountShared;
-template <> struct CountShared<1> {
-    static constexpr uint32_t S = 5376;                 // k-mer table: 12 B / slot -> 63 KB
-    static constexpr uint32_t NB = S / 4;               // buckets of 4 keys = two ds_read_b128
-    static constexpr uint32_t SR = 4096;                // record table: 20 B / slot -> 80 KB
-    __attribute__((aligned(16))) uint64_t key0[S];
-    uint32_t cnt[S];
-    // record-level dedupe (phase A): whole super-k-mer records with a multiplicity.
-    // rst: 0 empty, 1 being written, >= 3 ready with multiplicity rst-2
-    uint64_t rlo[SR];
-    uint64_t rhi[SR];
+// Record-level dedupe (phase A of pass 2): whole super-k-mer records with a multiplicity.  At high
+// coverage the same genomic run is seen in many reads; it is counted once here and expanded once.
+// rst: 0 empty, 1 being written, >= 3 ready with multiplicity rst-2
+template <int W, uint32_t SR_> struct RecTable {
+    static constexpr uint32_t SR = SR_;
+    uint64_t w[2 * W][SR];
     uint32_t rst[SR];
     uint16_t order[SR];                                 // occupied record slots, sorted by record length
     uint32_t nhist[64], nbase[64];
 };
-// W >= 2: one key array per word, a state word per slot (0 empty, 1 being written, 2 ready)
+
+template <int W> struct CountShared;
+template <> struct CountShared<1> {
+    static constexpr uint32_t S = 5376;                 // k-mer table: 12 B / slot -> 63 KB
+    static constexpr uint32_t NB = S / 4;               // buckets of 4 keys = two ds_read_b128
+    __attribute__((aligned(16))) uint64_t key0[S];
+    uint32_t cnt[S];
+    RecTable<1, 4096> rt;                               // 22 B / slot -> 88 KB
+};
+// W >= 2: one key array per word, a state word per slot (0 empty, 1 being written, 2 ready); the
+// LDS is split between the k-mer table (72 KB) and the record table (~70 KB)
 template <int W> struct CountShared {
-    static constexpr uint32_t S = (147456u / (8u * W + 8u)) & ~63u;   // 144 KB: 6144 / 4608 / 3584 slots for W = 2 / 3 / 4
+    static constexpr uint32_t S = (73728u / (8u * W + 8u)) & ~63u;            // 3072 / 2304 / 1792 slots for W = 2 / 3 / 4
     uint64_t key[W][S];
     uint32_t cnt[S];
     uint32_t state[S];
+    RecTable<W, ((71680u / (16u * W + 6u)) & ~63u)> rt;                       // 1856 / 1280 / 1024 records
 };
 
 struct CountCtl {
@@ -390,25 +396,34 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
 }
 
 // phase A: count a whole record; false = table saturated (the caller then expands it directly)
-__device__ __forceinline__ bool rec_insert(CountShared<1> &tb, CountCtl &ctl, uint64_t lo, uint64_t hi) {
-    constexpr uint32_t SR = CountShared<1>::SR;
-    uint32_t h = mix32((uint32_t)lo ^ __builtin_amdgcn_alignbit((uint32_t)(lo >> 32), (uint32_t)(lo >> 32), 9));
-    h = mix32(h ^ (uint32_t)hi ^ __builtin_amdgcn_alignbit((uint32_t)(hi >> 32), (uint32_t)(hi >> 32), 21));
+template <int W, typename RT>
+__device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * W> &rec) {
+    constexpr uint32_t SR = RT::SR;
+    uint32_t h = 0x9E3779B9u;
+#pragma unroll
+    for (int o = 0; o < 2 * W; o++) {
+        const uint32_t lo = (uint32_t)rec.w[o], hi = (uint32_t)(rec.w[o] >> 32);
+        h = mix32(h ^ lo ^ __builtin_amdgcn_alignbit(hi, hi, 9 + 3 * o));
+    }
     uint32_t slot = (uint32_t)(((uint64_t)h * SR) >> 32);
     for (uint32_t probes = 0; probes < 64;) {
-        uint32_t st = __hip_atomic_load(&tb.rst[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        uint32_t st = __hip_atomic_load(&rt.rst[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (st == 0) {
             if (ctl.rec_used >= (SR / 8) * 7) return false;             // keep the probe chains short
-            st = atomicCAS(&tb.rst[slot], 0u, 1u);
+            st = atomicCAS(&rt.rst[slot], 0u, 1u);
             if (st == 0) {
-                tb.rlo[slot] = lo; tb.rhi[slot] = hi;
-                __hip_atomic_fetch_add(&tb.rst[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 3
+#pragma unroll
+                for (int o = 0; o < 2 * W; o++) rt.w[o][slot] = rec.w[o];
+                __hip_atomic_fetch_add(&rt.rst[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 3
                 atomicAdd(&ctl.rec_used, 1u);
                 return true;
             }
         }
         if (st == 1) continue;                                          // owner is mid-write
-        if (tb.rlo[slot] == lo && tb.rhi[slot] == hi) { atomicAdd(&tb.rst[slot], 1u); return true; }
+        bool eq = true;
+#pragma unroll
+        for (int o = 0; o < 2 * W; o++) eq = eq && rt.w[o][slot] == rec.w[o];
+        if (eq) { atomicAdd(&rt.rst[slot], 1u); return true; }
         slot = slot + 1 == SR ? 0 : slot + 1;
         probes++;
     }
@@ -422,8 +437,7 @@ template <int W> __device__ __forceinline__ void table_reset(CountShared<W> &tb,
         tb.cnt[s] = 0;
         if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
     }
-    if constexpr (W == 1)
-        for (uint32_t s = threadIdx.x; s < CountShared<1>::SR; s += COUNT_THREADS) tb.rst[s] = 0;
+    for (uint32_t s = threadIdx.x; s < decltype(tb.rt)::SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
     for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
     __syncthreads();
 }
@@ -665,34 +679,31 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
             have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
-            if constexpr (W == 1) {
-                // phase A: identical records (the same genomic run seen in many reads) are counted
-                // once here and expanded once, with their multiplicity, in phase B
-                if (n && !rec_insert(tb, ctl, rec.w[0], rec.w[1])) expand(rec, n, 1u);
-            } else {
-                expand(rec, n, 1u);
-            }
+            // phase A: identical records (the same genomic run seen in many reads) are counted
+            // once here and expanded once, with their multiplicity, in phase B
+            if (n && !rec_insert<W>(tb.rt, ctl, rec)) expand(rec, n, 1u);
         }
-        if constexpr (W == 1) {
+        {
             // phase B: every distinct record once, weighted.  The occupied slots are first listed in
             // order of record length (counting sort in LDS) so that the 64 records a wave expands
             // together have (nearly) the same number of k-mers: no lanes idling behind the longest.
-            constexpr uint32_t SRc = CountShared<1>::SR;
-            if (threadIdx.x < 64) tb.nhist[threadIdx.x] = 0;
+            constexpr uint32_t SRc = decltype(tb.rt)::SR;
+            auto &rt = tb.rt;
+            if (threadIdx.x < 64) rt.nhist[threadIdx.x] = 0;
             __syncthreads();
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
-                if (tb.rst[s] >= 3u) atomicAdd(&tb.nhist[(uint32_t)(tb.rhi[s] >> 58)], 1u);
+                if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u);
             __syncthreads();
             if (threadIdx.x < 64) {
-                const uint32_t v = tb.nhist[threadIdx.x];
+                const uint32_t v = rt.nhist[threadIdx.x];
                 uint32_t incl = v;
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-                tb.nbase[threadIdx.x] = incl - v;
+                rt.nbase[threadIdx.x] = incl - v;
                 if (threadIdx.x == 63) ctl.n_recs = incl;
             }
             __syncthreads();
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
-                if (tb.rst[s] >= 3u) tb.order[atomicAdd(&tb.nbase[(uint32_t)(tb.rhi[s] >> 58)], 1u)] = (uint16_t)s;
+                if (rt.rst[s] >= 3u) rt.order[atomicAdd(&rt.nbase[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u)] = (uint16_t)s;
             __syncthreads();
             const uint32_t n_recs = ctl.n_recs;
             // (a table that filled up in phase A keeps its progress mark; phase B then stops at once)
@@ -700,9 +711,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_recs; i += COUNT_THREADS) {
                 if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i - threadIdx.x + 1u); break; }
-                const uint32_t s = tb.order[i];
-                Rec<RW> rec; rec.w[0] = tb.rlo[s]; rec.w[1] = tb.rhi[s];
-                expand(rec, (uint32_t)(rec.w[1] >> 58) + 1u, tb.rst[s] - 2u);
+                const uint32_t s = rt.order[i];
+                Rec<RW> rec;
+#pragma unroll
+                for (int o = 0; o < RW; o++) rec.w[o] = rt.w[o][s];
+                expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
             }
         }
         __syncthreads();

@@ -1133,6 +1133,8 @@ struct DevPool {
     DevPool() { const char *v = getenv("SHK_NO_POOL"); enabled = !(v && *v == '1'); }
     void *get(size_t &bytes, hipError_t &e) {
         bytes = (bytes + 4095) & ~(size_t)4095;
+        // big scratch buffers vary a little from handle to handle: round them up so the cached block fits again
+        if (bytes > ((size_t)256 << 20)) bytes = (bytes + ((size_t)256 << 20) - 1) & ~(((size_t)256 << 20) - 1);
         if (enabled) {
             std::lock_guard<std::mutex> lk(mu);
             auto it = free_blocks.lower_bound(bytes);
@@ -1347,7 +1349,8 @@ public:
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
         uint32_t P = 64;
-        const uint64_t per_part = env_u64("SHK_PART_INST", 100000);
+        // instances per partition: sized so that the distinct k-mers of a 100x isolate load the LDS k-mer table to ~40 %
+        const uint64_t per_part = env_u64("SHK_PART_INST", W == 1 ? 100000 : 40000);
         while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
         if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
         if (forced_P_) P = forced_P_;
@@ -1430,39 +1433,53 @@ public:
                 std::vector<OvfRec> ov(n_ovf);
                 HIPCHK(hipMemcpy(ov.data(), d_ovf.p, (size_t)n_ovf * sizeof(OvfRec), hipMemcpyDeviceToHost));
                 std::vector<OvfItem> items(n_ovf);
-                unsigned long long total = 0;
                 for (uint32_t i = 0; i < n_ovf; i++) {
                     uint32_t F = 2;
                     while ((double)F * (0.45 * S) < (double)ov[i].est_distinct && F < OVF_MAX_F) F <<= 1;
                     const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 150) / (100ull * F) + 256;   // 50 % slack
                     items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
-                    items[i].pad = 0; items[i].base = total;
-                    total += (unsigned long long)F * items[i].cap;
+                    items[i].pad = 0; items[i].base = 0;
                 }
-                if (int rc = d_items.alloc(n_ovf, err)) return rc;
-                if (int rc = d_fill.alloc((size_t)n_ovf * OVF_MAX_F, err)) return rc;
-                if (int rc = d_kmers.alloc(total * W, err)) return rc;
-                HIPCHK(hipMemcpyAsync(d_items.p, items.data(), (size_t)n_ovf * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
-                hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(n_ovf), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
-                HIPCHK(hipGetLastError());
-                std::vector<uint32_t> fill((size_t)n_ovf * OVF_MAX_F);
-                HIPCHK(hipMemcpyAsync(fill.data(), d_fill.p, fill.size() * 4, hipMemcpyDeviceToHost, stream_));
-                HIPCHK(hipStreamSynchronize(stream_));
-                // items with a bucket region that overflowed are re-run by residue classes instead
-                std::vector<OvfItem> good; std::vector<uint32_t> good_fill, bad;
-                for (uint32_t i = 0; i < n_ovf; i++) {
-                    bool okb = true;
-                    for (uint32_t b = 0; b < items[i].F; b++) okb = okb && fill[(size_t)i * OVF_MAX_F + b] <= items[i].cap;
-                    if (okb) { good.push_back(items[i]); good_fill.insert(good_fill.end(), fill.begin() + (size_t)i * OVF_MAX_F, fill.begin() + (size_t)(i + 1) * OVF_MAX_F); }
-                    else bad.push_back(items[i].p);
-                }
-                if (!good.empty()) {
-                    HIPCHK(hipMemcpyAsync(d_items.p, good.data(), good.size() * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
-                    HIPCHK(hipMemcpyAsync(d_fill.p, good_fill.data(), good_fill.size() * 4, hipMemcpyHostToDevice, stream_));
-                    hipLaunchKernelGGL(k_count_buckets<W>, dim3(OVF_MAX_F, (unsigned)good.size()), dim3(COUNT_THREADS), 0, stream_,
-                                       d_items.p, d_kmers.p, d_fill.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
-                                       ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2));
+                // scatter + count; an item whose bucket region overflows (a Poisson tail of heavy k-mers in one
+                // bucket) is scattered again with twice the room, at most three times, then re-run by residue classes
+                std::vector<uint32_t> bad;
+                size_t n_good_total = 0;
+                const int max_passes = (int)env_u64("SHK_OVF_MAX_PASSES", 4);
+                for (int pass = 0; pass < max_passes && !items.empty(); pass++) {
+                    const uint32_t ni = (uint32_t)items.size();
+                    unsigned long long tot = 0;
+                    for (auto &it : items) { it.base = tot; tot += (unsigned long long)it.F * it.cap; }
+                    if (int rc = d_items.alloc(ni, err)) return rc;
+                    if (int rc = d_fill.alloc((size_t)ni * OVF_MAX_F, err)) return rc;
+                    if (int rc = d_kmers.alloc(tot * W, err)) return rc;
+                    HIPCHK(hipMemcpyAsync(d_items.p, items.data(), (size_t)ni * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
+                    hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
                     HIPCHK(hipGetLastError());
+                    std::vector<uint32_t> fill((size_t)ni * OVF_MAX_F);
+                    HIPCHK(hipMemcpyAsync(fill.data(), d_fill.p, fill.size() * 4, hipMemcpyDeviceToHost, stream_));
+                    HIPCHK(hipStreamSynchronize(stream_));
+                    std::vector<OvfItem> good, again; std::vector<uint32_t> good_fill;
+                    for (uint32_t i = 0; i < ni; i++) {
+                        uint32_t mx = 0;
+                        for (uint32_t b = 0; b < items[i].F; b++) mx = std::max(mx, fill[(size_t)i * OVF_MAX_F + b]);
+                        if (mx <= items[i].cap) {
+                            good.push_back(items[i]);
+                            good_fill.insert(good_fill.end(), fill.begin() + (size_t)i * OVF_MAX_F, fill.begin() + (size_t)(i + 1) * OVF_MAX_F);
+                        } else if (pass + 1 < max_passes && (unsigned long long)mx + 256 < 0xFFFFFFF0ull) {
+                            OvfItem it = items[i]; it.cap = mx + 256; again.push_back(it);       // the exact need is known now
+                        } else bad.push_back(items[i].p);
+                    }
+                    if (!good.empty()) {
+                        HIPCHK(hipMemcpyAsync(d_items.p, good.data(), good.size() * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
+                        HIPCHK(hipMemcpyAsync(d_fill.p, good_fill.data(), good_fill.size() * 4, hipMemcpyHostToDevice, stream_));
+                        hipLaunchKernelGGL(k_count_buckets<W>, dim3(OVF_MAX_F, (unsigned)good.size()), dim3(COUNT_THREADS), 0, stream_,
+                                           d_items.p, d_kmers.p, d_fill.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2));
+                        HIPCHK(hipGetLastError());
+                        HIPCHK(hipStreamSynchronize(stream_));      // d_items / d_kmers are reused by the next pass
+                        n_good_total += good.size();
+                    }
+                    items.swap(again);
                 }
                 if (!bad.empty()) {
                     if (int rc = d_list.alloc(bad.size(), err)) return rc;
@@ -1473,9 +1490,7 @@ public:
                     HIPCHK(hipGetLastError());
                 }
                 ms_out += t2.stop();
-                times_.add("count_repartitioned_x1", (double)good.size());
-                { double sf = 0, se = 0, si = 0; for (auto &it : items) sf += it.F; for (auto &o : ov) { se += o.est_distinct; si += (double)o.instances; }
-                  times_.add("count_repart_mean_F", sf / n_ovf); times_.add("count_repart_mean_est", se / n_ovf); times_.add("count_repart_mean_inst", si / n_ovf); }
+                times_.add("count_repartitioned_x1", (double)n_good_total);
                 times_.add("count_residue_rerun_x1", (double)bad.size());
                 HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipStreamSynchronize(stream_));

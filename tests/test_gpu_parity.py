@@ -290,7 +290,7 @@ def test_counting_modes_agree():
 
 
 @pytest.mark.parametrize("k,mode", [(31, "repartition"), (51, "repartition"), (89, "repartition"), (127, "repartition"),
-                                    (31, "residue"), (51, "residue"), (31, "tiny_buckets")])
+                                    (31, "residue"), (51, "residue"), (31, "tiny_buckets"), (51, "rescatter")])
 def test_partitions_that_exceed_the_lds_table(k, mode):
     """Few partitions + many distinct k-mers: each partition exceeds the LDS table.  It is then
     repartitioned at k-mer level (k_ovf_scatter / k_count_buckets); with that switched off, or when a
@@ -302,6 +302,9 @@ def test_partitions_that_exceed_the_lds_table(k, mode):
         env["SHK_NO_REPARTITION"] = 1
     if mode == "tiny_buckets":
         env["SHK_OVF_CAP_PCT"] = 60                      # bucket regions overflow -> residue-class fallback per partition
+        env["SHK_OVF_MAX_PASSES"] = 1
+    if mode == "rescatter":
+        env["SHK_OVF_CAP_PCT"] = 60                      # bucket regions overflow -> scattered again with the exact room
     def both():
         hh = product(fq, k=k, min_count=0, min_qual=0, assemble=False)
         tt = hh.timings()                                # of the preprocess run (distinct() counts again)
@@ -318,6 +321,8 @@ def test_partitions_that_exceed_the_lds_table(k, mode):
         assert "count_repartitioned_x1" not in t
     if mode == "tiny_buckets":
         assert t.get("count_residue_rerun_x1", 0) > 0
+    if mode == "rescatter":
+        assert t.get("count_residue_rerun_x1", 0) == 0 and t.get("count_repartitioned_x1", 0) > 0
 
 
 def test_partition_slice_overflow_retry():
