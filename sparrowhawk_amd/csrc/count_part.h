@@ -20,6 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "kmer.h"
 
 namespace shk {
@@ -34,6 +35,7 @@ struct PartParams {
     uint32_t P, G, slice_cap;
     int k, m;
     uint32_t max_n;
+    uint32_t dbg_nostore;        // timing experiments only (SHK_DEBUG_NOSTORE): 1 = every record to slot 0 of its slice, 2 = no flush
 };
 
 template <int RW> struct Rec { uint64_t w[RW]; };
@@ -49,36 +51,38 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 // One 1024-thread workgroup per CU, one lane per read segment.  A tile of segments is staged in LDS
 // by coalesced dword loads; every lane then walks its segment base by base: rolling canonical
 // ntHash (32-bit state, kmer.h) of the m-mers, sliding-window minimum in registers, run detection.
-// Finished runs go to a WAVE-PRIVATE descriptor list in LDS (ballot + popcount, no atomics); a
-// wave turns its descriptors into records by itself whenever the list fills up and at the end of
-// the tile, so the walk needs no workgroup barrier (the first version shared one list and paid two
-// 16-wave barriers per 16 bases: 68 % of the wave cycles were waits, profiles/r01_s2_start).
+// Finished runs go to a LANE-PRIVATE descriptor list in LDS (slot i of lane l at [i][l]: conflict
+// free, no ballot, no atomics); a wave turns its descriptors into records by itself whenever a lane's
+// list fills up and at the end of the tile, so the walk needs no workgroup barrier (the first
+// version shared one list and paid two 16-wave barriers per 16 bases: 68 % of the wave cycles were
+// waits, profiles/r01_s2_start).
 static constexpr int PART_WAVES = PART_THREADS / 64;
-static constexpr uint32_t WDESC_CAP = 1024;          // descriptors per wave
-static constexpr int DESC_CHECK = 4;                 // steps between room checks (64 new per step at most)
+static constexpr uint32_t LDESC_CAP = 8;             // descriptors per lane
+static constexpr int DESC_CHECK = 2;                 // steps between room checks (one new per lane and step at most)
+static constexpr int STAGE_PF = (STAGE_WORDS + 8 + PART_THREADS - 1) / PART_THREADS;   // prefetch registers per thread
 
 struct PartShared {
-    uint32_t stage[STAGE_WORDS + 24];
-    uint32_t desc_a[PART_WAVES][WDESC_CAP];   // tile-relative base offset (18 bits) | (n-1) << 18
-    uint16_t desc_p[PART_WAVES][WDESC_CAP];
+    uint32_t stage[2][STAGE_WORDS + 24];      // double buffer: the next tile is fetched while this one is walked
+    uint32_t desc_a[PART_WAVES][LDESC_CAP][64];   // tile-relative base offset (18 bits) | (n-1) << 18
+    uint16_t desc_p[PART_WAVES][LDESC_CAP][64];
     uint32_t cursor[PART_MAX_P];
     uint2 nt_lut[16];                 // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1)
     uint32_t red[PART_WAVES];
 };
 
-// build one record from the staged tile and store it
+// build one record from the staged tile
 template <int RW>
-__device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t off, uint32_t n, int k,
-                                                  uint64_t *__restrict__ dst) {
+__device__ __forceinline__ void part_build_record(const uint32_t *stage, uint32_t off, uint32_t n, int k, uint64_t (&out)[RW]) {
     const uint32_t bit0 = 2u * off;
     const uint32_t wi = bit0 >> 5, s = bit0 & 31u;
     const uint32_t nbits = 2u * (n + (uint32_t)k - 1u);
-    uint64_t out[RW];
+    uint32_t w[2 * RW + 1];
+#pragma unroll
+    for (int o = 0; o < 2 * RW + 1; o++) w[o] = stage[wi + o];
 #pragma unroll
     for (int o = 0; o < RW; o++) {
-        const uint32_t a = sh.stage[wi + 2 * o], b = sh.stage[wi + 2 * o + 1], c = sh.stage[wi + 2 * o + 2];
-        const uint32_t lo = __builtin_amdgcn_alignbit(b, a, s);
-        const uint32_t hi = __builtin_amdgcn_alignbit(c, b, s);
+        const uint32_t lo = __builtin_amdgcn_alignbit(w[2 * o + 1], w[2 * o], s);
+        const uint32_t hi = __builtin_amdgcn_alignbit(w[2 * o + 2], w[2 * o + 1], s);
         uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
         const int rem = (int)nbits - 64 * o;            // bits of this word that belong to the run
         if (rem <= 0) v = 0;
@@ -86,6 +90,9 @@ __device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t
         out[o] = v;
     }
     out[RW - 1] |= (uint64_t)(n - 1u) << 58;
+}
+template <int RW>
+__device__ __forceinline__ void part_store_record(const uint64_t (&out)[RW], uint64_t *__restrict__ dst) {
 #pragma unroll
     for (int o = 0; o < RW; o += 2) {
         ulonglong2 v2; v2.x = out[o]; v2.y = out[o + 1];
@@ -93,23 +100,32 @@ __device__ __forceinline__ void part_write_record(const PartShared &sh, uint32_t
     }
 }
 
-// a wave writes the records of its own descriptor list (no workgroup barrier: the stage is read-only
-// while a tile is walked, the slice cursors are LDS atomics)
+// (LDS pointers keep their address space across the call: with generic pointers the compiler falls
+// back to flat loads with 64-bit address arithmetic for every stage / descriptor access)
+#define SHK_LDS __attribute__((address_space(3)))
 template <int RW>
-__device__ __noinline__ void wave_flush(PartShared *sh, uint32_t wave, uint32_t wn, int k, uint32_t G,
-                                        uint32_t slice_cap, uint32_t g, uint64_t *__restrict__ recs) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t d = threadIdx.x & 63u; d < wn; d += 64) {
-        const uint32_t a = sh->desc_a[wave][d];
-        const uint32_t p = sh->desc_p[wave][d];
-        const uint32_t idx = atomicAdd(&sh->cursor[p], 1u);          // LDS cursor of slice [p][g]
-        if (idx < slice_cap) {
-            uint64_t *dst = recs + (((uint64_t)p * G + g) * slice_cap + idx) * RW;
-            part_write_record<RW>(*sh, a & 0x3FFFFu, (a >> 18) + 1u, k, dst);
+__device__ __noinline__ void wave_flush(SHK_LDS PartShared *sh_l, const SHK_LDS uint32_t *stage_l, uint32_t wave, uint32_t cnt,
+                                        int k, uint32_t G, uint32_t slice_cap, uint32_t g, uint64_t *__restrict__ recs,
+                                        uint32_t dbg = 0) {
+    PartShared *sh = (PartShared *)sh_l;                 // address space is inferred from the cast
+    const uint32_t *stage = (const uint32_t *)stage_l;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (dbg == 2) return;                                // timing experiment: the walk alone
+    uint32_t mx = 0;                                     // longest list in the wave (cnt <= LDESC_CAP): ballots, no shuffles
+#pragma unroll
+    for (uint32_t c = 1; c <= LDESC_CAP; c++) if (__ballot(cnt >= c)) mx = c;
+    for (uint32_t d = 0; d < mx; d++) {
+        if (d < cnt) {
+            const uint32_t a = sh->desc_a[wave][d][lane];
+            const uint32_t p = sh->desc_p[wave][d][lane];
+            const uint32_t idx = atomicAdd(&sh->cursor[p], 1u);          // LDS cursor of slice [p][g]
+            if (idx < slice_cap) {
+                uint64_t r[RW];
+                part_build_record<RW>(stage, a & 0x3FFFFu, (a >> 18) + 1u, k, r);
+                part_store_record<RW>(r, recs + (((uint64_t)p * G + g) * slice_cap + (dbg == 1 ? 0u : idx)) * RW);
+            }
         }
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
 // W: key words (records have RW = 2W words); WBLK: k-mers per minimiser window block (= w)
@@ -129,7 +145,6 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     const int k = pp.k, m = pp.m;
     const uint32_t pmask = pp.P - 1u;
     const uint32_t max_n = pp.max_n;
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     // cursors continue where an earlier batch left this workgroup's slices
     for (uint32_t p = threadIdx.x; p < pp.P; p += PART_THREADS) sh.cursor[p] = fill[(uint64_t)p * pp.G + g];
     // ntHash roll terms (SPEC S3) for every (outgoing, incoming) base pair: 16 x 8 B in LDS, one
@@ -143,41 +158,72 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     }
     __syncthreads();
 
-    for (uint32_t st = g * PART_THREADS; st < n_seg; st += gridDim.x * PART_THREADS) {
-        const uint32_t st_end = min(st + (uint32_t)PART_THREADS, n_seg);
-        uint32_t first = st;
-        while (first < st_end) {
-            // largest tile of segments [first, first+cnt) whose packed words fit the LDS stage
-            uint32_t cnt = st_end - first;
-            const uint32_t w0 = seg_off[first] >> 4;
-            while (cnt > 1 && ((seg_off[first + cnt] + 15u) >> 4) - w0 > (uint32_t)STAGE_WORDS) cnt >>= 1;
-            const uint32_t nwords = ((seg_off[first + cnt] + 15u) >> 4) - w0;
+    // ---- tiles: [first, first+cnt) segments whose packed words [w0, w0+nwords) fit one LDS stage.  The
+    // iterator is wave-uniform; tile i+1 is fetched into registers before tile i is walked and stored
+    // to the other stage afterwards: one workgroup barrier per tile, HBM latency behind the walk.
+    struct Tile { uint32_t first, cnt, w0, nwords; };
+    uint32_t it_st = g * PART_THREADS, it_first = it_st;
+    auto next_tile = [&](Tile &t) -> bool {
+        for (;;) {
+            if (it_st >= n_seg) return false;
+            const uint32_t st_end = min(it_st + (uint32_t)PART_THREADS, n_seg);
+            if (it_first >= st_end) { it_st += gridDim.x * PART_THREADS; it_first = it_st; continue; }
+            uint32_t cnt = st_end - it_first;
+            const uint32_t w0 = seg_off[it_first] >> 4;
+            while (cnt > 1 && ((seg_off[it_first + cnt] + 15u) >> 4) - w0 > (uint32_t)STAGE_WORDS) cnt >>= 1;
+            const uint32_t nwords = ((seg_off[it_first + cnt] + 15u) >> 4) - w0;
+            const uint32_t f = it_first;
+            it_first += cnt;
             if (nwords > (uint32_t)STAGE_WORDS) {            // a single segment longer than the stage
                 if (threadIdx.x == 0) flags[1] = 1;
-                first += cnt;
                 continue;
             }
-            __syncthreads();                                 // every wave is done with the previous tile
-            // coalesced load of the tile's words into LDS (one dword per lane per pass)
-            for (uint32_t i = threadIdx.x; i < nwords + 8; i += PART_THREADS)
-                sh.stage[i] = (i < nwords + 1) ? bases[w0 + i] : 0u;     // +1: the spare word
-            uint32_t L = 0, rel = 0;
-            if (threadIdx.x < cnt) {
-                const uint32_t s0 = seg_off[first + threadIdx.x], s1 = seg_off[first + threadIdx.x + 1];
-                L = s1 - s0; rel = s0 - (w0 << 4);
+            t.first = f; t.cnt = cnt; t.w0 = w0; t.nwords = nwords;
+            return true;
+        }
+    };
+    Tile cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
+    bool have_cur = next_tile(cur);
+    uint32_t buf = 0;
+    uint32_t L = 0, rel = 0;
+    if (have_cur) {
+        for (uint32_t i = threadIdx.x; i < cur.nwords + 8; i += PART_THREADS)
+            sh.stage[0][i] = (i < cur.nwords + 1) ? bases[cur.w0 + i] : 0u;     // +1: the spare word
+        if (threadIdx.x < cur.cnt) {
+            const uint32_t s0 = seg_off[cur.first + threadIdx.x], s1 = seg_off[cur.first + threadIdx.x + 1];
+            L = s1 - s0; rel = s0 - (cur.w0 << 4);
+        }
+    }
+    __syncthreads();
+    while (have_cur) {
+        {
+            const uint32_t *stage = sh.stage[buf];
+            // ---- prefetch of the next tile (registers)
+            const bool have_nxt = next_tile(nxt);
+            uint32_t pf[STAGE_PF];
+            uint32_t Ln = 0, reln = 0;
+            if (have_nxt) {
+#pragma unroll
+                for (int i = 0; i < STAGE_PF; i++) {
+                    const uint32_t idx = threadIdx.x + (uint32_t)i * PART_THREADS;
+                    pf[i] = idx < nxt.nwords + 1 ? bases[nxt.w0 + idx] : 0u;
+                }
+                if (threadIdx.x < nxt.cnt) {
+                    const uint32_t s0 = seg_off[nxt.first + threadIdx.x], s1 = seg_off[nxt.first + threadIdx.x + 1];
+                    Ln = s1 - s0; reln = s0 - (nxt.w0 << 4);
+                }
             }
             uint32_t maxL = L;                               // over the wave
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, o));
             maxL = __builtin_amdgcn_readfirstlane(maxL);
-            __syncthreads();
 
             // ---- per-lane walk; every lane of the wave runs the same (block, t) schedule ----------
             // Bases come from 64-bit windows loaded once per block (a block of WBLK <= 16 bases spans
             // at most two packed words), never from per-lane reloads inside the step loop.
             auto window32 = [&](uint32_t pos) -> uint32_t {  // the 16 bases from stream position pos
                 const uint32_t wi = min(pos >> 4, (uint32_t)(STAGE_WORDS + 14));
-                return __builtin_amdgcn_alignbit(sh.stage[wi + 1], sh.stage[wi], 2u * (pos & 15u));
+                return __builtin_amdgcn_alignbit(stage[wi + 1], stage[wi], 2u * (pos & 15u));
             };
             Nt32State nt{0, 0};
             // prologue: the first m-mer (bases 0 .. m-1)
@@ -189,11 +235,29 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             uint32_t hreg[WBLK], sreg[WBLK];
 #pragma unroll
             for (int t = 0; t < WBLK; t++) { hreg[t] = 0xFFFFFFFFu; sreg[t] = 0xFFFFFFFFu; }
-            uint32_t run_start = 0, run_len = 0, run_p = 0;
-            uint32_t wn = 0;                                 // descriptors in this wave's list (wave-uniform)
+            // the current run: [run_start, i) of partition run_p; NO_RUN before the first k-mer.  The k-mer
+            // index i of a step is the same in every lane, so run lengths are scalar-minus-vector.
+            constexpr uint32_t NO_RUN = 0xFFFFFFFFu;
+            uint32_t run_start = 0, run_p = NO_RUN;
+            uint32_t dcnt = 0;                               // this lane's descriptors
+            // the waves of one SIMD flush at different fill levels: a flush is a chain of LDS round trips,
+            // it overlaps with the VALU-bound walk of the others only if they do not all flush together
+            const uint32_t flush_at = LDESC_CAP - DESC_CHECK - (wave >> 2);
+            uint32_t minL = L;                               // over the wave
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) minL = min(minL, (uint32_t)__shfl_xor((int)minL, o));
+            minL = __builtin_amdgcn_readfirstlane(minL);
             const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
             const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
-            for (uint32_t bq = 0; bq < n_blocks; bq++) {
+            // blocks whose WBLK m-mers exist in every lane of the wave (and are not the first): no bounds logic
+            const uint32_t n_full = minL >= (uint32_t)m ? (minL - (uint32_t)m + 1u) / WBLK : 0u;
+            auto emit = [&](uint32_t i_end) {                // close [run_start, i_end) of this lane
+                sh.desc_a[wave][dcnt][lane] = (rel + run_start) | ((i_end - run_start - 1u) << 18);
+                sh.desc_p[wave][dcnt][lane] = (uint16_t)run_p;
+                dcnt++;
+            };
+            auto do_block = [&](auto full_tag, uint32_t bq) {
+                constexpr bool FULL = decltype(full_tag)::value;
                 const uint32_t q0 = bq * WBLK;                             // first m-mer of the block
                 // the state holds m-mer q; after using it, base q leaves and base q+m enters.
                 // zo/ze: nibble j = (outgoing << 2 | incoming) of step t = 2j+1 / 2j  -> LUT index
@@ -204,20 +268,21 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 #pragma unroll
                 for (int t = 0; t < WBLK; t++) {
                     if (t % DESC_CHECK == 0) {
-                        if (wn > WDESC_CAP - 64u * DESC_CHECK) {            // wave-uniform
-                            wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs);
-                            wn = 0;
+                        if (__ballot(dcnt > flush_at)) {                    // wave-uniform
+                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore);
+                            dcnt = 0;
                         }
                     }
                     const uint32_t q = q0 + (uint32_t)t;
-                    const uint32_t j = q + (uint32_t)m - 1u;               // last base of m-mer q
-                    const bool have = j < L;
-                    const uint32_t h = have ? nt32_canonical(nt) : 0xFFFFFFFFu;
+                    const uint32_t j = q + (uint32_t)m - 1u;               // last base of m-mer q (wave-uniform)
+                    const uint32_t i = j - (uint32_t)k + 1u;               // k-mer completed by m-mer q (wave-uniform)
+                    bool have = true;
+                    uint32_t h = nt32_canonical(nt);
+                    if (!FULL) { have = j < L; h = have ? h : 0xFFFFFFFFu; }
                     // roll to m-mer q+1 (unconditionally: a state past the segment end is never used)
                     {
                         const uint32_t z = (t & 1) ? zo : ze;
-                        const uint32_t idx = (z >> (4 * (t >> 1))) & 15u;
-                        const uint2 term = sh.nt_lut[idx];
+                        const uint2 term = sh.nt_lut[(z >> (4 * (t >> 1))) & 15u];
                         nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ term.x;   // rol 1
                         nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ term.y;    // ror 1
                     }
@@ -225,44 +290,38 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                     pm = min(pm, h);
                     // k-mer i = q - w + 1 completes here; its window is suffix(prev block, t+1) + prefix(this block, t)
                     const uint32_t kmin = (t < WBLK - 1) ? min(sreg[(t + 1) % WBLK], pm) : pm;
-                    const bool valid = have && (bq > 0 || t == WBLK - 1);
-                    const uint32_t i = j - (uint32_t)k + 1u;
+                    const bool valid = FULL ? true : (have && (bq > 0 || t == WBLK - 1));
                     const uint32_t p = kmin & pmask;
-                    const bool cut = valid && run_len > 0 && (p != run_p || run_len >= max_n);
-                    const unsigned long long em = __ballot(cut);
-                    if (em) {
-                        if (cut) {
-                            const uint32_t d = wn + (uint32_t)__popcll(em & lt_mask);
-                            sh.desc_a[wave][d] = (rel + run_start) | ((run_len - 1u) << 18);
-                            sh.desc_p[wave][d] = (uint16_t)run_p;
-                            run_len = 0;
-                        }
-                        wn += (uint32_t)__popcll(em);
-                    }
-                    if (valid) {
-                        if (run_len == 0) { run_start = i; run_p = p; }
-                        run_len++;
+                    // a new run starts here if the partition changes or the current run is full
+                    if (valid && (p != run_p || run_start + max_n <= i)) {
+                        if (run_p != NO_RUN) emit(i);
+                        run_start = i; run_p = p;
                     }
                 }
                 // suffix minima of this block for the next one
                 sreg[WBLK - 1] = hreg[WBLK - 1];
 #pragma unroll
                 for (int t = WBLK - 2; t >= 0; t--) sreg[t] = min(hreg[t], sreg[t + 1]);
+            };
+            for (uint32_t bq = 0; bq < n_blocks; bq++) {
+                if (bq > 0 && bq < n_full) do_block(std::true_type{}, bq);
+                else do_block(std::false_type{}, bq);
             }
-            // close the last run of every segment
-            {
-                if (wn > WDESC_CAP - 64u) { wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs); wn = 0; }
-                const bool cut = run_len > 0;
-                const unsigned long long em = __ballot(cut);
-                if (cut) {
-                    const uint32_t d = wn + (uint32_t)__popcll(em & lt_mask);
-                    sh.desc_a[wave][d] = (rel + run_start) | ((run_len - 1u) << 18);
-                    sh.desc_p[wave][d] = (uint16_t)run_p;
+            // close the last run of every segment (it ends with the segment's last k-mer)
+            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore); dcnt = 0; }
+            if (run_p != NO_RUN) emit(L - (uint32_t)k + 1u);
+            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore);
+            // ---- the next tile goes to the other stage (its previous reader, tile i-1, ended before the last barrier)
+            if (have_nxt) {
+                uint32_t *dst = sh.stage[buf ^ 1u];
+#pragma unroll
+                for (int i = 0; i < STAGE_PF; i++) {
+                    const uint32_t idx = threadIdx.x + (uint32_t)i * PART_THREADS;
+                    if (idx < nxt.nwords + 8) dst[idx] = pf[i];
                 }
-                wn += (uint32_t)__popcll(em);
             }
-            if (wn) wave_flush<RW>(&sh, wave, wn, k, pp.G, pp.slice_cap, g, recs);
-            first += cnt;
+            __syncthreads();
+            cur = nxt; have_cur = have_nxt; buf ^= 1u; L = Ln; rel = reln;
         }
     }
     __syncthreads();

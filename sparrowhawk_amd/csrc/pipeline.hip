@@ -1344,7 +1344,7 @@ public:
         int cus = 256;
         { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
         const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
-        pp_.k = k_; pp_.m = k_ - wblk + 1;
+        pp_.k = k_; pp_.m = k_ - wblk + 1; pp_.dbg_nostore = (uint32_t)env_u64("SHK_DEBUG_NOSTORE", 0);
         pp_.max_n = std::min<uint32_t>(32u * RW - 3u - (uint32_t)(k_ - 1), 63u);
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
