@@ -103,11 +103,13 @@ __device__ __forceinline__ void part_store_record(const uint64_t (&out)[RW], uin
 // (LDS pointers keep their address space across the call: with generic pointers the compiler falls
 // back to flat loads with 64-bit address arithmetic for every stage / descriptor access)
 #define SHK_LDS __attribute__((address_space(3)))
+#define SHK_GLOBAL __attribute__((address_space(1)))
 template <int RW>
 __device__ __noinline__ void wave_flush(SHK_LDS PartShared *sh_l, const SHK_LDS uint32_t *stage_l, uint32_t wave, uint32_t cnt,
-                                        int k, uint32_t G, uint32_t slice_cap, uint32_t g, uint64_t *__restrict__ recs,
+                                        int k, uint32_t G, uint32_t slice_cap, uint32_t g, SHK_GLOBAL uint64_t *recs_g,
                                         uint32_t dbg = 0) {
     PartShared *sh = (PartShared *)sh_l;                 // address space is inferred from the cast
+    uint64_t *recs = (uint64_t *)recs_g;
     const uint32_t *stage = (const uint32_t *)stage_l;
     const uint32_t lane = threadIdx.x & 63u;
     if (dbg == 2) return;                                // timing experiment: the walk alone
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 for (int t = 0; t < WBLK; t++) {
                     if (t % DESC_CHECK == 0) {
                         if (__ballot(dcnt > flush_at)) {                    // wave-uniform
-                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore);
+                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore);
                             dcnt = 0;
                         }
                     }
@@ -308,9 +310,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 else do_block(std::false_type{}, bq);
             }
             // close the last run of every segment (it ends with the segment's last k-mer)
-            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore); dcnt = 0; }
+            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore); dcnt = 0; }
             if (run_p != NO_RUN) emit(L - (uint32_t)k + 1u);
-            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, recs, pp.dbg_nostore);
+            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore);
             // ---- the next tile goes to the other stage (its previous reader, tile i-1, ended before the last barrier)
             if (have_nxt) {
                 uint32_t *dst = sh.stage[buf ^ 1u];
