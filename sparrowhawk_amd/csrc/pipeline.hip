@@ -301,8 +301,15 @@ __device__ __forceinline__ void nt32_fill_lut(uint2 *lut, unsigned gm) {      //
 }
 template <int W> __device__ __forceinline__ MinScan km_min_scan_lut(const Kmer<W> &x, int k, int gm, const uint2 *lut) {
     MinScan r;
-    Nt32State nt{0, 0};
-    for (int j = 0; j < gm; j++) nt32_init_step(nt, km_base<W>(x, k, j), (unsigned)j);
+    // the first gm-mer: gm rolls from the all-A window (A leaves, base j enters) — the same LUT path as the scan
+    Nt32State nt;
+    nt.fh = 0; nt.rh = 0;
+    for (int j = 0; j < gm; j++) { nt.fh ^= rol32(nt32_seed(0), (unsigned)j); nt.rh ^= rol32(nt32_seed(3), (unsigned)j); }   // wave-uniform
+    for (int j = 0; j < gm; j++) {
+        const uint2 t = lut[km_base<W>(x, k, j)];          // out = A: index (0 << 2) | in
+        nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t.x;
+        nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t.y;
+    }
     r.first = nt; r.h_first = nt32_canonical(nt);
     r.min_wo_first = 0xFFFFFFFFu; r.min_wo_last = r.h_first;
     const int w = k - gm + 1;
@@ -328,6 +335,21 @@ __device__ __forceinline__ uint32_t nt32_prev_hash(const Nt32State &s, uint32_t 
     // inverse of nt32_roll: s is the state of (x0 .. x_{gm-1}); result: state of (b, x0 .. x_{gm-2})
     const uint32_t fh = ror32(s.fh ^ rol32(nt32_seed(new_first), gm) ^ nt32_seed(old_last), 1);
     const uint32_t rh = rol32(s.rh ^ ror32(nt32_seed(3u - new_first), 1) ^ rol32(nt32_seed(3u - old_last), gm - 1), 1);
+    return fh < rh ? fh : rh;
+}
+// the same two with the roll terms from the LDS table: lut[out<<2|in] holds exactly the terms of the
+// forward roll (out leaves, in enters) and of its inverse (new_first = out, old_last = in)
+__device__ __forceinline__ uint32_t nt32_next_hash_lut(const Nt32State &s, uint32_t out, uint32_t in, const uint2 *lut) {
+    const uint2 t = lut[(out << 2) | in];
+    const uint32_t fh = __builtin_amdgcn_alignbit(s.fh, s.fh, 31) ^ t.x;
+    const uint32_t rh = __builtin_amdgcn_alignbit(s.rh, s.rh, 1) ^ t.y;
+    return fh < rh ? fh : rh;
+}
+__device__ __forceinline__ uint32_t nt32_prev_hash_lut(const Nt32State &s, uint32_t new_first, uint32_t old_last, const uint2 *lut) {
+    const uint2 t = lut[(new_first << 2) | old_last];
+    const uint32_t a = s.fh ^ t.x, b = s.rh ^ t.y;
+    const uint32_t fh = __builtin_amdgcn_alignbit(a, a, 1);            // ror 1
+    const uint32_t rh = __builtin_amdgcn_alignbit(b, b, 31);           // rol 1
     return fh < rh ? fh : rh;
 }
 // Placement inside a mini table: its keys share a minimiser but are otherwise unrelated; an
@@ -465,7 +487,7 @@ __device__ __forceinline__ uint32_t gt_lookup(const GraphTable &gt, const KeyArr
 // the stored tables with all lanes busy.  A neighbour's partition follows from this node's gm-mer
 // hashes and ONE more hash: appending a base drops the first gm-mer and adds one at the end,
 // prepending drops the last and adds one in front.
-static constexpr uint32_t ADJ_LDS_SLOTS = 4096;        // 32 KB; larger (skewed) partitions work in global memory
+static constexpr uint32_t ADJ_LDS_SLOTS = 2048;        // 16 KB (8 workgroups per CU); larger (skewed) partitions work in global memory
 static constexpr uint32_t NB_MULTI = 0xFFFFFFFEu;
 
 // candidate j of node x: j < 4 successor by appended base j, else predecessor by prepended base j-4
@@ -540,8 +562,8 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         for (uint32_t j = 0; j < 8; j++) {
             bool remote = false; uint32_t p = 0;
             if (act) {
-                p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash(ms.last, out_b, j, gm))
-                           : min(ms.min_wo_last, nt32_prev_hash(ms.first, j - 4u, last_b, gm))) & gt.gp_mask;
+                p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash_lut(ms.last, out_b, j, lut))
+                           : min(ms.min_wo_last, nt32_prev_hash_lut(ms.first, j - 4u, last_b, lut))) & gt.gp_mask;
                 remote = p != P || !in_lds;
                 if (!remote) {
                     bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
@@ -1741,10 +1763,10 @@ public:
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr;
-        // graph partitions: ~1024 rows each; the minimiser length is the counting pass's, so rows that
+        // graph partitions: 256-512 rows each (mini tables of <= 2048 slots fit 16 KB of LDS); the minimiser length is the counting pass's, so rows that
         // arrive grouped by counting partition are grouped by graph partition too
         gp_ = 64;
-        while (gp_ < 65536u && (uint64_t)gp_ * 1024u < n) gp_ <<= 1;
+        while (gp_ < 131072u && (uint64_t)gp_ * 512u < n) gp_ <<= 1;
         gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
