@@ -6,9 +6,8 @@
 // on one core, 300x slower than the kernels behind it.  Here the text is uploaded as it is and
 // parsed by byte-streaming kernels (all HBM-bound):
 //   k_nl_count / k_nl_fill   newline positions (line index)
-//   k_read_scan              per record: framing checks (SPEC S1), valid-base runs (SPEC S2) -> counts
-//   k_read_emit              segment table: stream offset + text position of every kept run
-//   k_pack_words             one lane per 16-base output word: gather + encode
+//   k_read_wave<0>           one wave per record: framing checks (SPEC S1), valid-base runs (SPEC S2) -> counts
+//   k_read_wave<1>           the same walk again: segment table + the 2-bit stream (gather + encode per output word)
 // Only REGULAR input is handled (fixed 4-line framing, no blank lines between records); anything
 // else — and every malformed record — is left to the host parser, which owns the error messages.
 // The result is the same packed layout bit for bit (tests/test_gpu_parity.py compares both).
@@ -95,6 +94,13 @@ static int exclusive_scan(unsigned long long *a, uint64_t n, unsigned long long 
     return 0;
 }
 
+// 0x80 in every byte of w that equals '\n' (exact: no carry between bytes)
+__device__ __forceinline__ uint32_t nl_mask(uint32_t w) {
+    const uint32_t x = w ^ 0x0A0A0A0Au;
+    const uint32_t t = ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x;
+    return ~t & 0x80808080u;
+}
+
 // ---- newline index ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ text, uint64_t n,
                                                   unsigned long long *__restrict__ cnt) {
@@ -106,11 +112,7 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ te
         if (p + 16 <= n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x = w[j] ^ 0x0A0A0A0Au;                    // zero byte where '\n'
-                c += ((x & 0xFFu) == 0) + ((x & 0xFF00u) == 0) + ((x & 0xFF0000u) == 0) + ((x & 0xFF000000u) == 0);
-            }
+            c += __popc(nl_mask(w[0])) + __popc(nl_mask(w[1])) + __popc(nl_mask(w[2])) + __popc(nl_mask(w[3]));
         } else {
             for (uint64_t q = p; q < n && q < p + 16; q++) c += text[q] == '\n';
         }
@@ -122,42 +124,43 @@ __global__ __launch_bounds__(256) void k_nl_count(const uint8_t *__restrict__ te
     if (threadIdx.x == 0) cnt[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
 }
 
-// line_end[j] = position of the j-th '\n' (in text order).  One workgroup per chunk; inside a chunk the
-// order is kept by scanning 64-byte pieces wave by wave.
+// line_end[j] = position of the j-th '\n' (in text order).  One workgroup per 16 KB chunk, 16 bytes per
+// lane and step: newline masks by word arithmetic, an exclusive scan of the per-lane counts keeps the order.
 __global__ __launch_bounds__(256) void k_nl_fill(const uint8_t *__restrict__ text, uint64_t n,
                                                  const unsigned long long *__restrict__ chunk_off,
                                                  unsigned long long *__restrict__ line_end) {
-    __shared__ uint32_t piece_cnt[NL_CHUNK / 64];          // newlines per 64-byte piece
-    __shared__ uint32_t piece_off[NL_CHUNK / 64];
+    __shared__ uint32_t wtot[4];
     const uint64_t b0 = (uint64_t)blockIdx.x * NL_CHUNK;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    // pass 1: one wave per 64-byte piece (lane = byte)
-    for (uint32_t pc = wid; pc < NL_CHUNK / 64; pc += 4) {
-        const uint64_t p = b0 + (uint64_t)pc * 64 + lane;
-        const bool nl = p < n && text[p] == '\n';
-        const unsigned long long m = __ballot(nl);
-        if (lane == 0) piece_cnt[pc] = (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    // exclusive scan of the 256 piece counts (one per thread)
-    {
-        const uint32_t v = piece_cnt[threadIdx.x];
-        uint32_t incl = v;
+    unsigned long long base = chunk_off[blockIdx.x];
+    for (uint32_t sub = 0; sub < NL_CHUNK; sub += 256u * 16u) {
+        const uint64_t p = b0 + sub + (uint64_t)threadIdx.x * 16u;
+        uint32_t m[4] = {0, 0, 0, 0};
+        if (p + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
+            m[0] = nl_mask(v.x); m[1] = nl_mask(v.y); m[2] = nl_mask(v.z); m[3] = nl_mask(v.w);
+        } else if (p < n) {
+            for (uint32_t q = 0; q < 16 && p + q < n; q++) if (text[p + q] == '\n') m[q >> 2] |= 0x80u << (8 * (q & 3));
+        }
+        const uint32_t c = __popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]);
+        uint32_t incl = c;
         for (int o = 1; o < 64; o <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += u; }
-        __shared__ uint32_t wtot[4];
         if (lane == 63) wtot[wid] = incl;
         __syncthreads();
-        uint32_t off = 0;
-        for (int w = 0; w < wid; w++) off += wtot[w];
-        piece_off[threadIdx.x] = off + incl - v;
-    }
-    __syncthreads();
-    const unsigned long long base = chunk_off[blockIdx.x];
-    for (uint32_t pc = wid; pc < NL_CHUNK / 64; pc += 4) {
-        const uint64_t p = b0 + (uint64_t)pc * 64 + lane;
-        const bool nl = p < n && text[p] == '\n';
-        const unsigned long long m = __ballot(nl);
-        if (nl) line_end[base + piece_off[pc] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = p;
+        uint32_t off = 0, tot = 0;
+        for (int w = 0; w < 4; w++) { if (w < wid) off += wtot[w]; tot += wtot[w]; }
+        unsigned long long o = base + off + incl - c;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t mm = m[j];
+            while (mm) {
+                const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
+                line_end[o++] = p + 4u * j + (bit >> 3);
+                mm &= mm - 1u;
+            }
+        }
+        base += tot;
+        __syncthreads();
     }
 }
 
@@ -187,68 +190,105 @@ __device__ __forceinline__ void line_span(const uint8_t *text, const unsigned lo
     if (e > s && text[e - 1] == '\r') e--;
 }
 
-// mode 0: counts (segments, kept bases) per record + validation; mode 1: write the segment table
+// 2-bit code of A/C/G/T (either case) and the validity test of SPEC S2 without a table
+__device__ __forceinline__ uint32_t acgt_code(uint32_t c) { return ((c >> 1) ^ (c >> 2)) & 3u; }
+__device__ __forceinline__ bool acgt_valid(uint32_t c) {
+    const uint32_t u = (c | 0x20u) - 'a';                  // a=0 c=2 g=6 t=19
+    return u < 26u && ((0x80045u >> u) & 1u);
+}
+
+// One WAVE per record (lane = byte of the 64-byte piece being looked at: coalesced line loads, the
+// valid-base mask of a piece is one ballot, runs are found with bit scans on it).
+// mode 0: framing checks + counts (segments, kept bases) per record
+// mode 1: segment table + the packed stream itself: lane w gathers the 16 bases of output word w of the
+//         run; words shared with a neighbouring run are merged with atomicOr (the stream starts zeroed)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_read_scan(const uint8_t *__restrict__ text,
+__global__ __launch_bounds__(256) void k_read_wave(const uint8_t *__restrict__ text,
                                                    const unsigned long long *__restrict__ line_end, FqParams fp,
                                                    uint64_t n_reads, unsigned long long *__restrict__ seg_cnt,
                                                    unsigned long long *__restrict__ base_cnt,
                                                    unsigned long long *__restrict__ stats /* [0]=bad flag [1]=input bases */,
-                                                   uint32_t *__restrict__ seg_off, unsigned long long *__restrict__ seg_src) {
+                                                   uint32_t *__restrict__ seg_off, uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     unsigned long long my_in = 0;
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t s0, e0, s1, e1, s2, e2, s3, e3;
-        line_span(text, line_end, fp, 4 * r + 1, s1, e1);
-        line_span(text, line_end, fp, 4 * r + 3, s3, e3);
-        if (MODE == 0) {
-            line_span(text, line_end, fp, 4 * r, s0, e0);
-            line_span(text, line_end, fp, 4 * r + 2, s2, e2);
-            const bool ok = e0 > s0 && text[s0] == '@' && e2 > s2 && text[s2] == '+' && (e1 - s1) == (e3 - s3);
-            if (!ok) { stats[0] = 1; seg_cnt[r] = 0; base_cnt[r] = 0; continue; }
-            my_in += e1 - s1;
+    for (uint64_t r = wave0; r < n_reads; r += n_waves) {
+        // line ends 4r-1 .. 4r+3 -> lanes 0..4
+        unsigned long long le = 0;
+        if (lane < 5) {
+            const uint64_t j = 4 * r + (uint64_t)lane;           // line index + 1
+            le = j == 0 ? ~0ull : (j - 1 < fp.n_nl ? line_end[j - 1] : fp.n);
         }
-        const uint64_t L = e1 - s1;
-        uint64_t run = 0, nseg = 0, nb = 0;
-        uint64_t so = MODE == 1 ? seg_cnt[r] : 0, bo = MODE == 1 ? base_cnt[r] : 0;
-        for (uint64_t i = 0; i <= L; i++) {
-            bool valid = false;
-            if (i < L) valid = base_code(text[s1 + i]) < 4 && (int)text[s3 + i] - 33 >= (int)fp.min_qual;
-            if (valid) { run++; continue; }
+        uint64_t ls[4], e_[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ls[i] = __shfl(le, i) + 1ull;                        // (~0 + 1 = 0 for the first line)
+            e_[i] = __shfl(le, i + 1);
+        }
+        // trailing '\r' of each line
+        uint32_t cr = 0;
+        if (lane < 4) { const uint64_t e = e_[lane], s0 = ls[lane]; cr = (e > s0 && text[e - 1] == '\r') ? 1u : 0u; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) e_[i] -= (uint64_t)__shfl((int)cr, i);
+        const uint64_t s1 = ls[1], s3 = ls[3];
+        const uint64_t L = e_[1] - s1;
+        if (MODE == 0) {
+            uint32_t h = 0;
+            if (lane == 0) h = (e_[0] > ls[0] && text[ls[0]] == '@') ? 1u : 0u;
+            if (lane == 2) h = (e_[2] > ls[2] && text[ls[2]] == '+') ? 1u : 0u;
+            const bool ok = __shfl((int)h, 0) && __shfl((int)h, 2) && L == e_[3] - s3;
+            if (!ok) { if (lane == 0) { stats[0] = 1; seg_cnt[r] = 0; base_cnt[r] = 0; } continue; }
+            if (lane == 0) my_in += L;
+        }
+        uint64_t so = 0, bo = 0;
+        if (MODE == 1) { so = seg_cnt[r]; bo = base_cnt[r]; }
+        uint64_t run = 0, nseg = 0, nb = 0;                      // wave-uniform
+        auto close_run = [&](uint64_t end_pos /* text position one past the run */) {
             if (run >= fp.k) {
-                if (MODE == 1) { seg_off[so + nseg] = (uint32_t)(bo + nb); seg_src[so + nseg] = s1 + i - run; }
+                if (MODE == 1) {
+                    const uint64_t src = end_pos - run, b0 = bo + nb;
+                    if (lane == 0) seg_off[so + nseg] = (uint32_t)b0;
+                    // output words [b0/16, (b0+run-1)/16]
+                    const uint64_t w_first = b0 >> 4, w_last = (b0 + run - 1) >> 4;
+                    for (uint64_t w = w_first + (uint64_t)lane; w <= w_last; w += 64) {
+                        const uint64_t lo = w << 4;                               // first stream base of the word
+                        const uint64_t from = lo < b0 ? b0 : lo, to = (lo + 16 < b0 + run) ? lo + 16 : b0 + run;
+                        uint32_t word = 0;
+                        for (uint64_t b = from; b < to; b++) word |= acgt_code(text[src + (b - b0)]) << (2 * (uint32_t)(b - lo));
+                        if (from == lo && to == lo + 16) out[w] = word; else atomicOr(&out[w], word);
+                    }
+                }
                 nseg++; nb += run;
             }
             run = 0;
-        }
-        if (MODE == 0) { seg_cnt[r] = nseg; base_cnt[r] = nb; }
-    }
-    if (MODE == 0) {
-        for (int o = 32; o > 0; o >>= 1) my_in += __shfl_down(my_in, o);
-        if ((threadIdx.x & 63) == 0 && my_in) atomicAdd(&stats[1], my_in);
-    }
-}
-
-// one lane per output word: bases [16w, 16w+16) of the stream, gathered from the text
-__global__ __launch_bounds__(256) void k_pack_words(const uint8_t *__restrict__ text, const uint32_t *__restrict__ seg_off,
-                                                    const unsigned long long *__restrict__ seg_src, uint64_t n_seg,
-                                                    uint64_t n_bases, uint64_t n_words, uint32_t *__restrict__ out) {
-    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t b0 = w * 16;
-        uint32_t word = 0;
-        if (b0 < n_bases) {
-            // segment holding base b0: last s with seg_off[s] <= b0
-            uint64_t lo = 0, hi = n_seg;
-            while (hi - lo > 1) { const uint64_t mid = (lo + hi) >> 1; if ((uint64_t)seg_off[mid] <= b0) lo = mid; else hi = mid; }
-            uint64_t s = lo;
-            uint64_t seg_end = s + 1 < n_seg ? seg_off[s + 1] : n_bases;       // seg_off[n_seg] == n_bases is written later
-            uint64_t src = seg_src[s] + (b0 - seg_off[s]);
-            for (uint32_t i = 0; i < 16 && b0 + i < n_bases; i++) {
-                if (b0 + i >= seg_end) { s++; seg_end = s + 1 < n_seg ? seg_off[s + 1] : n_bases; src = seg_src[s]; }
-                word |= base_code(text[src++]) << (2 * i);
+        };
+        for (uint64_t p0 = 0; p0 < L; p0 += 64) {
+            const uint64_t i = p0 + (uint64_t)lane;
+            bool valid = false;
+            if (i < L) valid = acgt_valid(text[s1 + i]) && (int)text[s3 + i] - 33 >= (int)fp.min_qual;
+            unsigned long long m = __ballot(valid);
+            const uint32_t len = (uint32_t)((L - p0) < 64 ? (L - p0) : 64);
+            uint32_t pos = 0;
+            while (pos < len) {
+                const unsigned long long rest = m >> pos;
+                if (rest & 1ull) {                               // a stretch of valid bases
+                    uint32_t ones = (~rest) ? (uint32_t)__ffsll((long long)~rest) - 1u : 64u;
+                    if (ones > len - pos) ones = len - pos;
+                    run += ones; pos += ones;
+                    if (pos < len) close_run(s1 + p0 + pos);     // it ended inside this piece
+                } else {
+                    close_run(s1 + p0 + pos);                    // (a run that ended exactly at the piece boundary)
+                    uint32_t zeros = rest ? (uint32_t)__ffsll((long long)rest) - 1u : 64u;
+                    if (zeros > len - pos) zeros = len - pos;
+                    pos += zeros;
+                }
             }
         }
-        out[w] = word;
+        close_run(s1 + L);
+        if (MODE == 0 && lane == 0) { seg_cnt[r] = nseg; base_cnt[r] = nb; }
     }
+    if (MODE == 0 && lane == 0 && my_in) atomicAdd(&stats[1], my_in);
 }
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
@@ -348,8 +388,8 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     unsigned long long *seg_cnt = sc.get<unsigned long long>(n_reads, err);
     unsigned long long *base_cnt = sc.get<unsigned long long>(n_reads, err);
     if (!seg_cnt || !base_cnt) return -4;
-    hipLaunchKernelGGL(k_read_scan<0>, dim3(grid1(n_reads)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
-                       d_tot + 2, (uint32_t *)nullptr, (unsigned long long *)nullptr);
+    hipLaunchKernelGGL(k_read_wave<0>, dim3(grid1(n_reads * 64)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
+                       d_tot + 2, (uint32_t *)nullptr, (uint32_t *)nullptr);
     if (int rc = exclusive_scan(seg_cnt, n_reads, d_tot + 4, st, sc, err)) return rc;
     if (int rc = exclusive_scan(base_cnt, n_reads, d_tot + 5, st, sc, err)) return rc;
     unsigned long long h[8];
@@ -360,17 +400,12 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     if (n_bases >= 0xFFFFFFF0ull) { err = "input exceeds 2^32 bases per batch"; return -1; }
     const uint64_t n_words = (n_bases >> 4) + 2;          // partial word + one spare word (as PackedReads::finish)
     uint32_t *seg_off = sc.get<uint32_t>(n_seg + 1, err);
-    unsigned long long *seg_src = sc.get<unsigned long long>(n_seg + 1, err);
     uint32_t *bases = sc.get<uint32_t>(n_words, err);
-    if (!seg_off || !seg_src || !bases) return -4;
-    if (n_seg) {
-        hipLaunchKernelGGL(k_read_scan<1>, dim3(grid1(n_reads)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
-                           d_tot + 2, seg_off, seg_src);
-        hipLaunchKernelGGL(k_pack_words, dim3(grid1(n_words)), dim3(256), 0, st, text, seg_off, seg_src, n_seg, n_bases, n_words,
-                           bases);
-    } else {
-        FQCHK(hipMemsetAsync(bases, 0, n_words * 4, st));
-    }
+    if (!seg_off || !bases) return -4;
+    FQCHK(hipMemsetAsync(bases, 0, n_words * 4, st));
+    if (n_seg)
+        hipLaunchKernelGGL(k_read_wave<1>, dim3(grid1(n_reads * 64)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
+                           d_tot + 2, seg_off, bases);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, seg_off + n_seg, (uint32_t)n_bases);
     FQCHK(hipGetLastError());
     // progress marks
