@@ -377,6 +377,7 @@ template <int W> struct CountShared {
 
 struct CountCtl {
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
+    unsigned long long roff[256];                       // first record of every run (copied once: no dependent global load per fetch)
     uint32_t histo[500];
     uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor, rec_used, n_recs;
     // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
@@ -573,6 +574,7 @@ struct RunView {
     const uint32_t *run_cnt;
     uint32_t S;            // runs per partition (<= 256)
     int k;
+    uint32_t dbg;          // timing experiments only (SHK_DEBUG_P2)
 };
 
 // run table of the local layout recs[p][g][slice_cap]
@@ -657,6 +659,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
             const uint32_t g = g0 + threadIdx.x;
             uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
+            if (g < S_runs) ctl.roff[g] = rvw.run_off[(uint64_t)p * S_runs + g];
             uint32_t incl = f;
             for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
             if (g < S_runs) ctl.pre[g] = run + incl - f;
@@ -669,6 +672,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     }
     __syncthreads();
     const uint32_t R = ctl.pre[S_runs];
+    if (rvw.dbg == 5) return;                            // timing experiment: launch + run prefix only
 
     while (true) {
         __syncthreads();
@@ -686,11 +690,22 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         unsigned long long mine = 0;
         // the record of the NEXT batch is requested before the current one is expanded, so its
         // HBM/L2 latency hides behind ~n*60 instructions of work
-        auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
-            if (r >= R) return 0u;
-            uint32_t lo = 0, hi = S_runs;                   // run with pre[lo] <= r < pre[lo+1]
+        // Every wave takes a contiguous share of the partition's records and its lanes consecutive records,
+        // so a lane's run index only ever moves forward by a step or two: no binary search per record
+        // (eight dependent LDS reads — the longest link of the per-record latency chain).
+        const uint32_t per_wave = (((R + (COUNT_THREADS / 64) - 1) / (COUNT_THREADS / 64)) + 63u) & ~63u;
+        const uint32_t w_begin = min(R, (threadIdx.x >> 6) * per_wave), w_end = min(R, w_begin + per_wave);
+        uint32_t run_lo = 0, run_next = 0;                  // run of the lane's last record, first record of the next run
+        {
+            uint32_t lo = 0, hi = S_runs;                   // run with pre[lo] <= r < pre[lo+1], once per round
+            const uint32_t r = min(w_begin + (uint32_t)lane, R ? R - 1u : 0u);
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
-            const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
+            run_lo = lo; run_next = ctl.pre[lo + 1];
+        }
+        auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
+            if (r >= w_end) return 0u;
+            while (r >= run_next) { run_lo++; run_next = ctl.pre[run_lo + 1]; }
+            const uint64_t *src = rvw.recs + (ctl.roff[run_lo] + (r - ctl.pre[run_lo])) * RW;
 #pragma unroll
             for (int o = 0; o < RW; o += 2) {
                 const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
@@ -728,21 +743,26 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 }
             }
         };
-        Rec<RW> nxt;
+        // records are requested two batches ahead of their use (one workgroup per CU: nothing else hides HBM latency)
+        Rec<RW> nxt, nxt2;
 #pragma unroll
-        for (int o = 0; o < RW; o++) nxt.w[o] = 0;
-        uint32_t have_nxt = fetch(threadIdx.x, nxt);
+        for (int o = 0; o < RW; o++) { nxt.w[o] = 0; nxt2.w[o] = 0; }
+        uint32_t have_nxt = fetch(w_begin + (uint32_t)lane, nxt);
+        uint32_t have_nxt2 = fetch(w_begin + 64u + (uint32_t)lane, nxt2);
         if (threadIdx.x == 0) ctl.prog_den = R ? R : 1u;
-        for (uint32_t r0 = 0; r0 < R; r0 += COUNT_THREADS) {
+        for (uint32_t r0 = w_begin; r0 < (rvw.dbg == 6 ? w_begin : w_end); r0 += 64) {
             // the table filled up: stop early (every insert into a full table walks a long probe chain);
-            // how far this round got sizes the split
-            if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, r0 + 1u); break; }
+            // how far this round got (all waves advance alike) sizes the split
+            if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, min(R, (r0 - w_begin) * (COUNT_THREADS / 64) + 1u)); break; }
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
-            have_nxt = fetch(r0 + COUNT_THREADS + threadIdx.x, nxt);
+            nxt = nxt2; have_nxt = have_nxt2;
+            have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
             // phase A: identical records (the same genomic run seen in many reads) are counted
             // once here and expanded once, with their multiplicity, in phase B
-            if (n && !rec_insert<W>(tb.rt, ctl, rec)) expand(rec, n, 1u);
+            if (rvw.dbg == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
+            else if (rvw.dbg == 2) { if (n) expand(rec, n, 1u); }
+            else if (n && !rec_insert<W>(tb.rt, ctl, rec)) expand(rec, n, 1u);
         }
         {
             // phase B: every distinct record once, weighted.  The occupied slots are first listed in
@@ -752,6 +772,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             auto &rt = tb.rt;
             if (threadIdx.x < 64) rt.nhist[threadIdx.x] = 0;
             __syncthreads();
+            if (rvw.dbg != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
                 if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u);
             __syncthreads();
@@ -763,20 +784,23 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 if (threadIdx.x == 63) ctl.n_recs = incl;
             }
             __syncthreads();
+            if (rvw.dbg != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
                 if (rt.rst[s] >= 3u) rt.order[atomicAdd(&rt.nbase[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u)] = (uint16_t)s;
             __syncthreads();
-            const uint32_t n_recs = ctl.n_recs;
+            uint32_t n_recs = ctl.n_recs;
+            if (rvw.dbg == 3) n_recs = SRc;                 // timing experiment: slot order instead of length order
             // (a table that filled up in phase A keeps its progress mark; phase B then stops at once)
             if (threadIdx.x == 0 && ctl.prog_num == 0) ctl.prog_den = n_recs ? n_recs : 1u;
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_recs; i += COUNT_THREADS) {
                 if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i - threadIdx.x + 1u); break; }
-                const uint32_t s = rt.order[i];
+                const uint32_t s = rvw.dbg == 3 ? i : rt.order[i];
+                if (rvw.dbg == 3 && rt.rst[s] < 3u) continue;
                 Rec<RW> rec;
 #pragma unroll
                 for (int o = 0; o < RW; o++) rec.w[o] = rt.w[o][s];
-                expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
+                if (rvw.dbg != 1) expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
             }
         }
         __syncthreads();

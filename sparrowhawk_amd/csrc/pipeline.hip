@@ -1408,7 +1408,7 @@ public:
                                    run_cnt_.p);
                 HIPCHK(hipGetLastError());
                 run_view_.recs = recs_.p; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
-                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P;
+                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = (uint32_t)env_u64("SHK_DEBUG_P2", 0);
                 return 0;
             }
             times_.add("partition_retry", ms);
@@ -1704,7 +1704,7 @@ public:
         }
         shard_recv_ = d_recv;
         run_view_.recs = (const uint64_t *)d_recv; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
-        run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned;
+        run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned; run_view_.dbg = 0;
         uint64_t total_recs = 0;
         for (uint64_t i = 0; i < n_runs; i++) total_recs += run_cnt[i];
         memset(histo, 0, 500 * 8);
