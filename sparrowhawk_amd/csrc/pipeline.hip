@@ -702,10 +702,11 @@ __global__ __launch_bounds__(256) void k_tip_candidates(Graph<W> g, const uint8_
 
 template <int W>
 __global__ __launch_bounds__(256) void k_tip_walk(Graph<W> g, const uint32_t *__restrict__ cand,
-                                                  uint32_t n_cand, TipRec *__restrict__ tips,
+                                                  const unsigned int *__restrict__ n_cand_p, TipRec *__restrict__ tips,
                                                   unsigned int *__restrict__ n_tips,
                                                   uint32_t *__restrict__ tip_head) {
     const uint32_t T_TIP = 2u * (uint32_t)g.k;
+    const uint32_t n_cand = *n_cand_p;                     // counts stay on the device: one host round trip per round
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
         const uint32_t v = cand[c];
         uint32_t cur = v, len = 1, J = NIL;
@@ -729,9 +730,10 @@ __global__ __launch_bounds__(256) void k_tip_walk(Graph<W> g, const uint32_t *__
 // decide on the snapshot: per junction, at most 4 tips hang off tip_head[J]
 template <int W>
 __global__ __launch_bounds__(256) void k_tip_decide(Graph<W> g, const TipRec *__restrict__ tips,
-                                                    uint32_t n_tips,
+                                                    const unsigned int *__restrict__ n_tips_p,
                                                     const uint32_t *__restrict__ tip_head,
                                                     uint8_t *__restrict__ kill) {
+    const uint32_t n_tips = *n_tips_p;
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x) {
         const TipRec me = tips[a];
         const uint32_t d = g.indeg(me.junction);
@@ -754,9 +756,10 @@ __global__ __launch_bounds__(256) void k_tip_decide(Graph<W> g, const TipRec *__
 // mark the nodes of killed tips dead and append them to the removed list
 template <int W>
 __global__ __launch_bounds__(256) void k_tip_remove(Graph<W> g, const TipRec *__restrict__ tips,
-                                                    uint32_t n_tips, const uint8_t *__restrict__ kill,
+                                                    const unsigned int *__restrict__ n_tips_p, const uint8_t *__restrict__ kill,
                                                     uint32_t *__restrict__ tip_head,
                                                     uint8_t *__restrict__ mark) {
+    const uint32_t n_tips = *n_tips_p;
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x) {
         const TipRec me = tips[a];
         if (kill[a]) {
@@ -769,8 +772,9 @@ __global__ __launch_bounds__(256) void k_tip_remove(Graph<W> g, const TipRec *__
     }
 }
 
-__global__ __launch_bounds__(256) void k_tip_reset_heads(const TipRec *__restrict__ tips, uint32_t n_tips,
+__global__ __launch_bounds__(256) void k_tip_reset_heads(const TipRec *__restrict__ tips, const unsigned int *__restrict__ n_tips_p,
                                                          uint32_t *__restrict__ tip_head) {
+    const uint32_t n_tips = *n_tips_p;
     for (uint32_t a = blockIdx.x * blockDim.x + threadIdx.x; a < n_tips; a += gridDim.x * blockDim.x)
         tip_head[tips[a].junction] = NIL;
 }
@@ -800,8 +804,9 @@ __global__ __launch_bounds__(256) void k_fork_candidates(Graph<W> g, const uint8
 
 template <int W>
 __global__ __launch_bounds__(256) void k_bubble(Graph<W> g, const uint32_t *__restrict__ cand,
-                                                uint32_t n_cand, uint8_t *__restrict__ mark) {
+                                                const unsigned int *__restrict__ n_cand_p, uint8_t *__restrict__ mark) {
     const uint32_t T_BUB = 2u * (uint32_t)g.k;
+    const uint32_t n_cand = *n_cand_p;
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_cand; c += gridDim.x * blockDim.x) {
         const uint32_t S = cand[c];
         const uint32_t om = g.outmask(S);
@@ -893,7 +898,8 @@ __device__ __forceinline__ void adj_clear_bit(uint8_t *adj, uint32_t idx, uint32
 // for every removed node: clear the reciprocal edge bit in each neighbour, then its own byte
 template <int W>
 __global__ __launch_bounds__(256) void k_apply_removed(Graph<W> g, const uint32_t *__restrict__ removed,
-                                                       uint32_t n_removed) {
+                                                       const unsigned int *__restrict__ n_removed_p) {
+    const uint32_t n_removed = *n_removed_p;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n_removed; t += gridDim.x * blockDim.x) {
         const uint32_t r = removed[t];
         const uint32_t a = g.adj[r];
@@ -1823,19 +1829,14 @@ public:
         return 0;
     }
 
-    int apply_marks(Graph<W> &g, DevBuf<uint8_t> &mark, DevBuf<uint32_t> &removed, unsigned int &n_removed,
-                    std::string &err) {
+    // marked alive nodes -> removed list (count at ctl_[slot]) -> their edges cleared in the neighbours
+    int apply_marks(Graph<W> &g, DevBuf<uint8_t> &mark, DevBuf<uint32_t> &removed, int slot, std::string &err) {
         const uint32_t n = (uint32_t)n_solid_;
-        HIPCHK(hipMemsetAsync(ctl_.p + 2, 0, 8, stream_));
         hipLaunchKernelGGL(k_collect_marked, dim3(grid_for(n)), dim3(256), 0, stream_, n, mark.p, alive_.p,
-                           removed.p, (unsigned int *)(ctl_.p + 2));
+                           removed.p, (unsigned int *)(ctl_.p + slot));
+        hipLaunchKernelGGL(k_apply_removed<W>, dim3(1024), dim3(256), 0, stream_, g, removed.p,
+                           (const unsigned int *)(ctl_.p + slot));
         HIPCHK(hipGetLastError());
-        if (int rc = read_ctl(n_removed, 2, err)) return rc;
-        if (n_removed) {
-            hipLaunchKernelGGL(k_apply_removed<W>, dim3(grid_for(n_removed)), dim3(256), 0, stream_, g, removed.p,
-                               n_removed);
-            HIPCHK(hipGetLastError());
-        }
         return 0;
     }
 
@@ -1853,51 +1854,43 @@ public:
         if (int rc = mark.alloc(n, err)) return rc;
         HIPCHK(hipMemsetAsync(mark.p, 0, n, stream_));
         if (tips) {
+            // every candidate may turn out to be a tip: sized for all oriented nodes, so that no count has to
+            // come back to the host inside a round (the counters live in ctl_: 3 candidates, 4 tips, 5/6 removed)
             if (int rc = tip_head.alloc(2ull * n, err)) return rc;
+            if (int rc = tiprec.alloc(2ull * n, err)) return rc;
+            if (int rc = kill.alloc(2ull * n, err)) return rc;
             HIPCHK(hipMemsetAsync(tip_head.p, 0xFF, 2ull * n * 4, stream_));
         }
         EvTimer t(stream_);
+        const dim3 G(1024), B(256);
         for (int round = 0; round < 32; round++) {
-            unsigned int n1 = 0, n2 = 0;
+            HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
             if (tips) {
-                unsigned int nc = 0, nt = 0;
-                HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 16, stream_));
-                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, alive_.p,
+                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(2ull * n)), B, 0, stream_, g, alive_.p,
                                    cand.p, (unsigned int *)(ctl_.p + 3));
+                hipLaunchKernelGGL(k_tip_walk<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3),
+                                   tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
+                hipLaunchKernelGGL(k_tip_decide<W>, G, B, 0, stream_, g, tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                                   tip_head.p, kill.p);
+                hipLaunchKernelGGL(k_tip_remove<W>, G, B, 0, stream_, g, tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                                   kill.p, tip_head.p, mark.p);
+                hipLaunchKernelGGL(k_tip_reset_heads, G, B, 0, stream_, tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                                   tip_head.p);
                 HIPCHK(hipGetLastError());
-                if (int rc = read_ctl(nc, 3, err)) return rc;
-                if (nc) {
-                    if (tiprec.n < nc) if (int rc = tiprec.alloc(nc, err)) return rc;
-                    if (kill.n < nc) if (int rc = kill.alloc(nc, err)) return rc;
-                    hipLaunchKernelGGL(k_tip_walk<W>, dim3(grid_for(nc)), dim3(256), 0, stream_, g, cand.p, nc,
-                                       tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
-                    HIPCHK(hipGetLastError());
-                    if (int rc = read_ctl(nt, 4, err)) return rc;
-                }
-                if (nt) {
-                    hipLaunchKernelGGL(k_tip_decide<W>, dim3(grid_for(nt)), dim3(256), 0, stream_, g, tiprec.p, nt,
-                                       tip_head.p, kill.p);
-                    hipLaunchKernelGGL(k_tip_remove<W>, dim3(grid_for(nt)), dim3(256), 0, stream_, g, tiprec.p, nt,
-                                       kill.p, tip_head.p, mark.p);
-                    hipLaunchKernelGGL(k_tip_reset_heads, dim3(grid_for(nt)), dim3(256), 0, stream_, tiprec.p, nt,
-                                       tip_head.p);
-                    HIPCHK(hipGetLastError());
-                    if (int rc = apply_marks(g, mark, removed, n1, err)) return rc;
-                }
+                if (int rc = apply_marks(g, mark, removed, 5, err)) return rc;
             }
             if (bubbles) {
-                unsigned int nc = 0;
                 HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
-                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, alive_.p,
+                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(2ull * n)), B, 0, stream_, g, alive_.p,
                                    cand.p, (unsigned int *)(ctl_.p + 3));
+                hipLaunchKernelGGL(k_bubble<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3), mark.p);
                 HIPCHK(hipGetLastError());
-                if (int rc = read_ctl(nc, 3, err)) return rc;
-                if (nc) {
-                    hipLaunchKernelGGL(k_bubble<W>, dim3(grid_for(nc)), dim3(256), 0, stream_, g, cand.p, nc, mark.p);
-                    HIPCHK(hipGetLastError());
-                    if (int rc = apply_marks(g, mark, removed, n2, err)) return rc;
-                }
+                if (int rc = apply_marks(g, mark, removed, 6, err)) return rc;
             }
+            unsigned long long h[2];
+            HIPCHK(hipMemcpyAsync(h, ctl_.p + 5, sizeof h, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipStreamSynchronize(stream_));
+            const unsigned int n1 = (unsigned int)h[0], n2 = (unsigned int)h[1];
             tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
             if (n1 + n2 == 0) break;
         }
