@@ -60,10 +60,10 @@ def make_reads_on_device(torch, dev, genome_len, coverage, read_len, seed, read_
 
 def cpu_baseline(k, min_count, read_len, coverage):
     """The oracle (CPU restatement, single thread) timed on a bounded sample of the same
-    workload: a 10x smaller isolate at the same coverage / read length / k."""
+    workload: a 5x smaller isolate at the same coverage / read length / k."""
     from oracle import Oracle
     from sparrowhawk_amd import synth
-    genome_len = 500_000
+    genome_len = 1_000_000
     g = synth.random_genome(genome_len, 0xEC02)
     codes, quals = synth.sample_reads(g, genome_len * coverage // read_len, read_len, 0xEC02 + 1)
     fq = synth.to_fastq(codes, quals)
@@ -76,7 +76,7 @@ def cpu_baseline(k, min_count, read_len, coverage):
     nb = codes.size
     return {"value": nb / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
             "sample": f"{genome_len} bp isolate, {coverage}x, {read_len} bp reads, k={k} "
-                      f"({nb / 1e6:.0f} Mbases; 1/10 of the GPU workload's genome), oracle count+assemble "
+                      f"({nb / 1e6:.0f} Mbases; 1/5 of the GPU workload's genome), oracle count+assemble "
                       f"{dt:.1f} s; build's CPU restatement, not upstream sparrowhawk-asm"}
 
 
@@ -232,7 +232,7 @@ def main():
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                      "count_step_ms": c_ms + p_ms,
                      "count_step_frac": (alg_bytes / ((c_ms + p_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if c_ms + p_ms > 0 else 0.0,
-                     "note": "path is VALU-bound, not HBM-bound: see DESIGN.md section 4"},
+                     "note": "integer/hash path bound by instruction issue and LDS round trips, not by HBM: see DESIGN.md section 4"},
         "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
     }
     if rank == 0:

@@ -1156,18 +1156,20 @@ __global__ __launch_bounds__(256) void k_max_u32(const uint32_t *__restrict__ a,
 // gives them back to the driver.
 struct DevPool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;     // (device, bytes) -> block
     bool enabled = true;
     DevPool() { const char *v = getenv("SHK_NO_POOL"); enabled = !(v && *v == '1'); }
+    static int cur_dev() { int d = 0; (void)hipGetDevice(&d); return d; }
     void *get(size_t &bytes, hipError_t &e) {
         bytes = (bytes + 4095) & ~(size_t)4095;
         // big scratch buffers vary a little from handle to handle: round them up so the cached block fits again
         if (bytes > ((size_t)256 << 20)) bytes = (bytes + ((size_t)256 << 20) - 1) & ~(((size_t)256 << 20) - 1);
+        const int dev = cur_dev();
         if (enabled) {
             std::lock_guard<std::mutex> lk(mu);
-            auto it = free_blocks.lower_bound(bytes);
-            if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + (1u << 20)) {
-                void *p = it->second; bytes = it->first; free_blocks.erase(it); e = hipSuccess; return p;
+            auto it = free_blocks.lower_bound(std::make_pair(dev, bytes));
+            if (it != free_blocks.end() && it->first.first == dev && it->first.second <= bytes + bytes / 2 + (1u << 20)) {
+                void *p = it->second; bytes = it->first.second; free_blocks.erase(it); e = hipSuccess; return p;
             }
         }
         void *p = nullptr;
@@ -1178,11 +1180,11 @@ struct DevPool {
         }
         return e == hipSuccess ? p : nullptr;
     }
-    void put(void *p, size_t bytes) {
+    void put(void *p, size_t bytes) {                  // called with the owning handle's device current
         if (!p) return;
         if (!enabled) { (void)hipFree(p); return; }
         std::lock_guard<std::mutex> lk(mu);
-        free_blocks.emplace(bytes, p);
+        free_blocks.emplace(std::make_pair(cur_dev(), bytes), p);
     }
     void trim() {
         std::lock_guard<std::mutex> lk(mu);
