@@ -100,17 +100,26 @@ const char *shk_last_error(shk_handle *h) { return h ? h->err.c_str() : "null ha
 void shk_set_progress_cb(shk_handle *h, shk_progress_cb cb, void *user) { if (h) { h->cb = cb; h->cb_user = user; } }
 
 // common tail of every preprocess entry point: packed segments are in HBM
-static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
-                        uint64_t n_bases) {
+// one batch of packed segments in HBM -> pass 1 (several batches per handle are allowed)
+static int count_one_batch(shk_handle *h, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                           uint64_t n_bases) {
     std::string err;
     const double t0 = now_ms();
     int rc = h->pipe->count_batch(d_bases, d_seg_off, n_seg, n_bases, err);
+    h->pipe->times().add("preprocess_device_total_host_clock", now_ms() - t0);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    return SHK_OK;
+}
+
+// common tail of every preprocess entry point: all batches are in -> histogram, fit, filter
+static int finish_counting(shk_handle *h) {
+    std::string err;
+    const double t0 = now_ms();
     h->post_mode("loop:end");
     if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
     // the fit never returns less than 1 and falls back to min_count (SPEC S6)
     const uint32_t emit_thr = h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
-    rc = h->pipe->histogram(h->histo, emit_thr, err);
+    int rc = h->pipe->histogram(h->histo, emit_thr, err);
     if (rc) return fail(h, SHK_E_DEVICE, err);
     h->used_min_count = h->min_count; h->fit_ok = false;
     if (h->do_fit) {
@@ -129,7 +138,22 @@ static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *
     return SHK_OK;
 }
 
-static int count_packed_host(shk_handle *h, PackedReads &pr) {
+static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
+                        uint64_t n_bases) {
+    if (int rc = count_one_batch(h, d_bases, d_seg_off, n_seg, n_bases)) return rc;
+    return finish_counting(h);
+}
+
+// bases per batch of the host-parsed paths (a batch is limited to 2^32 packed bases by its 32-bit offsets)
+static uint64_t batch_bases() {
+    const char *v = getenv("SHK_BATCH_BASES");
+    const uint64_t b = (v && *v) ? strtoull(v, nullptr, 10) : (1ull << 31);
+    return b < 1024 ? 1024 : (b > (3ull << 30) ? (3ull << 30) : b);
+}
+
+// hand the packed stream on as one batch (upload + pass 1) and empty it; read counters are kept
+static int flush_host_batch(shk_handle *h, PackedReads &pr) {
+    if (pr.n_seg() == 0) { pr.reset_stream(); return SHK_OK; }
     pr.finish();
     std::string err;
     void *d_bases = nullptr, *d_off = nullptr;
@@ -138,10 +162,14 @@ static int count_packed_host(shk_handle *h, PackedReads &pr) {
     if (!rc) rc = device_upload(pr.seg_off.data(), pr.seg_off.size() * 4, &d_off, err);
     if (rc) { device_free(d_bases); device_free(d_off); return fail(h, SHK_E_OOM, err); }
     h->pipe->times().add("h2d_upload_host_clock", now_ms() - t0);
-    rc = run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_off, pr.n_seg(), pr.n_bases);
+    rc = count_one_batch(h, (const uint32_t *)d_bases, (const uint32_t *)d_off, pr.n_seg(), pr.n_bases);
     device_free(d_bases); device_free(d_off);
+    pr.reset_stream();
     return rc;
 }
+
+// chunked mode hands a batch on every chunk_size reads (docs/src/assembly.md:17: "reads per batch")
+static uint64_t flush_every_reads(const shk_handle *h) { return (!h->do_bloom && h->chunk_size > 0) ? h->chunk_size : 0; }
 
 int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
     if (!h) return SHK_E_PARAM;
@@ -157,7 +185,7 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
     // packed by streaming kernels; gzip members are inflated on the host first.  Irregular input and
     // every malformed record go to the host parser below, which owns the error messages.
     const char *force_host = getenv("SHK_HOST_PARSER");
-    if (!(force_host && *force_host == '1')) {
+    if (!(force_host && *force_host == '1') && total / 2 <= batch_bases()) {
         std::vector<uint8_t> st1, st2;
         const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
         int rc = maybe_inflate(fq1, n1, st1, t1, l1, err);
@@ -192,12 +220,20 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
         const uint64_t pct = total ? (100 * (done_before + bytes)) / total : 100;
         h->post_mode(("loop:" + std::to_string(reads) + ":" + std::to_string(pct)).c_str());
     };
-    int rc = pack_fastq(fq1, n1, h->k, h->min_qual, pr, err, h->progress_every(), prog);
-    if (!rc && fq2) { done_before = n1; rc = pack_fastq(fq2, n2, h->k, h->min_qual, pr, err, h->progress_every(), prog); }
+    int flush_rc = SHK_OK;
+    auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
+    if (flush_every_reads(h) || (n1 + n2) / 2 > batch_bases()) h->pipe->expect_more_batches();
+    int rc = pack_fastq(fq1, n1, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
+    if (!rc && fq2) {
+        done_before = n1;
+        rc = pack_fastq(fq2, n2, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
+    }
+    if (rc == -7) return flush_rc;                       // the batch hand-over failed: its error is set
     if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
     h->n_reads = pr.n_reads;
     h->pipe->times().add("fastq_parse_pack_host_clock", now_ms() - t0);
-    return count_packed_host(h, pr);
+    if (int rc2 = flush_host_batch(h, pr)) return rc2;
+    return finish_counting(h);
 }
 
 int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
@@ -209,7 +245,12 @@ int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
     }
     std::string err;
     auto prog = [&](uint64_t reads, uint64_t, uint64_t) { h->post_mode(("loop:" + std::to_string(reads)).c_str()); };
-    int rc = pack_fastq(chunk, n, h->k, h->min_qual, h->stream_reads, err, h->progress_every(), prog);
+    int flush_rc = SHK_OK;
+    auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
+    h->pipe->expect_more_batches();                      // the total is unknown while chunks keep coming
+    int rc = pack_fastq(chunk, n, h->k, h->min_qual, h->stream_reads, err, h->progress_every(), prog,
+                        flush_every_reads(h), batch_bases(), flush);
+    if (rc == -7) return flush_rc;
     if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
     return SHK_OK;
 }
@@ -218,9 +259,10 @@ int shk_finish_reads(shk_handle *h) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Streaming) return fail(h, SHK_E_STATE, "finish_reads: no reads pushed");
     h->n_reads = h->stream_reads.n_reads;
-    int rc = count_packed_host(h, h->stream_reads);
+    int rc = flush_host_batch(h, h->stream_reads);
     h->stream_reads.clear();
-    return rc;
+    if (rc) return rc;
+    return finish_counting(h);
 }
 
 int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,

@@ -377,7 +377,7 @@ template <int W> struct CountShared {
 
 struct CountCtl {
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
-    unsigned long long roff[256];                       // first record of every run (copied once: no dependent global load per fetch)
+    unsigned long long roff[256];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
     uint32_t histo[500];
     uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor, rec_used, n_recs;
     // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
@@ -567,10 +567,11 @@ struct OvfItem { uint32_t p, F, cap, pad; unsigned long long base; };
 static constexpr uint32_t OVF_MAX_F = 256;
 
 // A partition's records arrive as S runs (local: one per producer workgroup; sharded: one per
-// source rank): run j of partition p holds run_cnt[p*S+j] records starting at record run_off[p*S+j].
+// source rank; batched: one per batch): run j of partition p holds run_cnt[p*S+j] records starting at
+// device address 16 * run_addr16[p*S+j] (absolute, so the runs of one partition may live in different
+// allocations: every batch of reads keeps its own record buffer).
 struct RunView {
-    const uint64_t *recs;
-    const unsigned long long *run_off;
+    const unsigned long long *run_addr16;
     const uint32_t *run_cnt;
     uint32_t S;            // runs per partition (<= 256)
     int k;
@@ -579,11 +580,13 @@ struct RunView {
 
 // run table of the local layout recs[p][g][slice_cap]
 __global__ __launch_bounds__(256) void k_make_runs(const uint32_t *__restrict__ fill, PartParams pp,
-                                                   unsigned long long *__restrict__ run_off,
+                                                   const uint64_t *recs, uint32_t rec_words,
+                                                   unsigned long long *__restrict__ run_addr16,
                                                    uint32_t *__restrict__ run_cnt) {
     const uint64_t n = (uint64_t)pp.P * pp.G;
+    const unsigned long long base16 = (unsigned long long)recs >> 4;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        run_off[i] = i * pp.slice_cap;
+        run_addr16[i] = base16 + i * pp.slice_cap * (rec_words / 2u);
         run_cnt[i] = min(fill[i], pp.slice_cap);
     }
 }
@@ -659,7 +662,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
             const uint32_t g = g0 + threadIdx.x;
             uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
-            if (g < S_runs) ctl.roff[g] = rvw.run_off[(uint64_t)p * S_runs + g];
+            if (g < S_runs) ctl.roff[g] = rvw.run_addr16[(uint64_t)p * S_runs + g];
             uint32_t incl = f;
             for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
             if (g < S_runs) ctl.pre[g] = run + incl - f;
@@ -705,7 +708,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
             if (r >= w_end) return 0u;
             while (r >= run_next) { run_lo++; run_next = ctl.pre[run_lo + 1]; }
-            const uint64_t *src = rvw.recs + (ctl.roff[run_lo] + (r - ctl.pre[run_lo])) * RW;
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[run_lo] << 4) + (uint64_t)(r - ctl.pre[run_lo]) * RW;
 #pragma unroll
             for (int o = 0; o < RW; o += 2) {
                 const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
                 uint32_t lo = 0, hi = S_runs;
                 while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
-                const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - ctl.pre[lo])) * RW;
+                const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[lo] << 4) + (uint64_t)(r - ctl.pre[lo]) * RW;
                 inst += (src[RW - 1] >> 58) + 1ull;
             }
             for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
@@ -885,7 +888,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
     for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
         uint32_t lo = 0, hi = S_runs;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
-        const uint64_t *src = rvw.recs + (rvw.run_off[(uint64_t)p * S_runs + lo] + (r - pre[lo])) * RW;
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(rvw.run_addr16[(uint64_t)p * S_runs + lo] << 4) + (uint64_t)(r - pre[lo]) * RW;
         Rec<RW> rec;
 #pragma unroll
         for (int o = 0; o < RW; o += 2) {

@@ -10,6 +10,10 @@ void PackedReads::clear() {
     bases.clear(); seg_off.clear(); n_bases = n_reads = n_input_bases = 0; cur = 0;
 }
 
+void PackedReads::reset_stream() {
+    bases.clear(); seg_off.clear(); n_bases = 0; cur = 0;
+}
+
 void PackedReads::finish() {
     if (seg_off.empty()) seg_off.push_back(0);
     // materialise the partial word and one spare word so kernels may read one word past the end
@@ -83,7 +87,8 @@ inline void append_run(PackedReads &o, const uint8_t *codes, size_t len) {
 }  // namespace
 
 int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
-               std::string &err, uint64_t every, const ProgressFn &progress) {
+               std::string &err, uint64_t every, const ProgressFn &progress,
+               uint64_t flush_reads, uint64_t flush_bases, const FlushFn &flush) {
     std::vector<uint8_t> inflated;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
         if (int rc = inflate_all(buf, n, inflated, err)) return rc;
@@ -129,6 +134,10 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
         out.n_input_bases += L;
         out.n_reads++; rec++;
         if (every && progress && (out.n_reads % every) == 0) progress(out.n_reads, p > n ? n : p, n);
+        if (flush && ((flush_reads && (out.n_reads % flush_reads) == 0) || (flush_bases && out.n_bases >= flush_bases))) {
+            if (int rc = flush(out)) { err = "batch hand-over failed"; return rc; }
+            if (out.seg_off.empty()) out.seg_off.push_back(0);
+        }
     }
     return 0;
 }

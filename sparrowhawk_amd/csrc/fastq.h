@@ -18,6 +18,7 @@ struct PackedReads {
     uint64_t n_input_bases = 0;      // bases in the FASTQ records
     uint32_t cur = 0;                // partial word being filled
     void clear();
+    void reset_stream();             // drop the packed stream (a batch was handed on), keep the read counters
     void finish();                   // flush the partial word, pad one spare word
     uint64_t n_seg() const { return seg_off.empty() ? 0 : seg_off.size() - 1; }
 };
@@ -26,8 +27,13 @@ struct PackedReads {
 using ProgressFn = std::function<void(uint64_t, uint64_t, uint64_t)>;
 
 // Appends the reads of one FASTQ buffer (plain or gzip) to `out`.  0 or SHK_E_PARSE(-3)/-4.
+// flush(out) — optional — is called after a record when out.n_reads is a multiple of flush_reads (if non-zero)
+// or the stream holds >= flush_bases bases: the caller takes the batch (PackedReads::finish + upload) and
+// calls out.reset_stream().  Non-zero return aborts the parse with that code.
+using FlushFn = std::function<int(PackedReads &)>;
 int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
-               std::string &err, uint64_t every = 0, const ProgressFn &progress = nullptr);
+               std::string &err, uint64_t every = 0, const ProgressFn &progress = nullptr,
+               uint64_t flush_reads = 0, uint64_t flush_bases = 0, const FlushFn &flush = nullptr);
 
 // gzip sniff (1F 8B) + multi-member inflate; plain input is passed through (p/n point at buf or at `storage`)
 int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,

@@ -29,6 +29,8 @@ public:
     // counting (SPEC S4): may be called once per batch of packed segments
     virtual int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
                             uint64_t n_bases, std::string &err) = 0;
+    // more batches will follow the first one (chunked / streamed input of unknown size): partition for the worst case
+    virtual void expect_more_batches() = 0;
     // spectrum histogram (SPEC S5).  Rows with count <= emit_threshold will never be asked for
     // by filter(): the counting pass may drop them as soon as they are histogrammed.
     virtual int histogram(uint64_t histo[500], uint32_t emit_threshold, std::string &err) = 0;

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1367,7 +1368,9 @@ public:
         if (global_mode_) return count_batch_global(d_bases, d_seg_off, n_seg, n_bases, err);
         if (n_seg >= 0xFFFFFFFFull || n_bases >= 0xFFFFFFFFull) { err = "batch too large (>= 2^32 bases)"; return -1; }
         if (n_seg == 0) return 0;
-        if (have_parts_) { err = "one batch per handle in this version"; return -1; }
+        // several batches per handle (chunked / streamed / > 2^32-base inputs): the previous batch's records
+        // are packed densely into a buffer of their own; pass 2 then reads one run per batch and partition
+        if (have_parts_) if (int rc = pack_current_batch(err)) return rc;
         constexpr int RW = 2 * W;
         const int wblk = k_ >= 23 ? 16 : 8;
         const uint64_t inst_ub = n_bases - n_seg * (uint64_t)(k_ - 1);
@@ -1384,6 +1387,7 @@ public:
         while (P < (uint32_t)PART_MAX_P && (uint64_t)P * per_part < inst_ub) P <<= 1;
         if (uint64_t fp = env_u64("SHK_PART_P", 0)) P = (uint32_t)fp;
         if (forced_P_) P = forced_P_;
+        if (!batches_.empty()) P = pp_.P;                 // every batch uses the first batch's partitioning
         pp_.P = P;
         // records per slice: mean run length is ~(WBLK+1)/2 k-mers (shorter if max_n caps it); 2x slack
         const uint64_t per_rec = pp_.max_n >= 16 ? 4 : 2;
@@ -1412,10 +1416,10 @@ public:
                 // run table of the local layout: one run per (partition, producer workgroup)
                 if (int rc = run_off_.alloc(n_slices, err)) return rc;
                 if (int rc = run_cnt_.alloc(n_slices, err)) return rc;
-                hipLaunchKernelGGL(k_make_runs, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, pp_, run_off_.p,
-                                   run_cnt_.p);
+                hipLaunchKernelGGL(k_make_runs, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, pp_, recs_.p,
+                                   (uint32_t)RW, run_off_.p, run_cnt_.p);
                 HIPCHK(hipGetLastError());
-                run_view_.recs = recs_.p; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+                run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
                 run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = (uint32_t)env_u64("SHK_DEBUG_P2", 0);
                 return 0;
             }
@@ -1425,6 +1429,61 @@ public:
         err = "partition slices overflowed twice";
         return -6;
     }
+
+    // ---- batches ---------------------------------------------------------------------------------
+    struct BatchRecs { DevBuf<uint64_t> dense; std::vector<unsigned long long> part_off; /* [P+1], records */ };
+
+    // the batch that still sits in its [p][g] slices -> a dense buffer (partition-major), slices released
+    int pack_current_batch(std::string &err) {
+        constexpr int RW = 2 * W;
+        DevBuf<unsigned long long> tot, base;
+        if (int rc = tot.alloc(pp_.P, err)) return rc;
+        if (int rc = base.alloc(pp_.P, err)) return rc;
+        hipLaunchKernelGGL(k_part_totals, dim3(pp_.P), dim3(256), 0, stream_, fill_.p, pp_, tot.p);
+        HIPCHK(hipGetLastError());
+        std::vector<unsigned long long> h(pp_.P);
+        HIPCHK(hipMemcpyAsync(h.data(), tot.p, (size_t)pp_.P * 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        std::unique_ptr<BatchRecs> b(new BatchRecs());
+        b->part_off.assign(pp_.P + 1, 0);
+        for (uint32_t p = 0; p < pp_.P; p++) b->part_off[p + 1] = b->part_off[p] + h[p];
+        if (int rc = b->dense.alloc(b->part_off[pp_.P] * RW + 2, err)) return rc;
+        HIPCHK(hipMemcpyAsync(base.p, b->part_off.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
+        EvTimer t(stream_);
+        hipLaunchKernelGGL((k_pack_partition<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, recs_.p, fill_.p, pp_, base.p, b->dense.p);
+        HIPCHK(hipGetLastError());
+        times_.add("batch_pack_kernel", t.stop());
+        HIPCHK(hipStreamSynchronize(stream_));
+        batches_.push_back(std::move(b));
+        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
+        return 0;
+    }
+
+    // run tables over the packed batches: partition p, run b = batch b's records of p
+    int make_batch_run_view(std::string &err) {
+        const uint32_t nb = (uint32_t)batches_.size();
+        if (nb > 256) { err = "more than 256 batches per handle"; return -1; }
+        const uint64_t n_runs = (uint64_t)pp_.P * nb;
+        std::vector<unsigned long long> addr16(n_runs); std::vector<uint32_t> cnt(n_runs);
+        for (uint32_t p = 0; p < pp_.P; p++)
+            for (uint32_t b = 0; b < nb; b++) {
+                const BatchRecs &B = *batches_[b];
+                const unsigned long long c = B.part_off[p + 1] - B.part_off[p];
+                if (c > 0xFFFFFFFFull) { err = "partition too large in one batch"; return -1; }
+                addr16[(uint64_t)p * nb + b] = ((unsigned long long)(uintptr_t)B.dense.p >> 4) + B.part_off[p] * (unsigned long long)W;
+                cnt[(uint64_t)p * nb + b] = (uint32_t)c;
+            }
+        if (int rc = run_off_.alloc(n_runs, err)) return rc;
+        if (int rc = run_cnt_.alloc(n_runs, err)) return rc;
+        HIPCHK(hipMemcpyAsync(run_off_.p, addr16.data(), n_runs * 8, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemcpyAsync(run_cnt_.p, cnt.data(), n_runs * 4, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+        run_view_.S = nb; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = 0;
+        have_parts_ = true;
+        return 0;
+    }
+    void expect_more_batches() override { if (!forced_P_ && batches_.empty() && !have_parts_) forced_P_ = (uint32_t)PART_MAX_P; }
 
     // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying.
     // Partitions whose distinct k-mers do not fit the LDS table are listed by the first launch and
@@ -1540,6 +1599,10 @@ public:
         if (!global_mode_) {
             memset(histo, 0, 500 * 8);
             n_distinct_ = 0; n_emitted_ = 0; emit_threshold_ = emit_threshold;
+            if (!batches_.empty()) {
+                if (have_parts_ && recs_.p) if (int rc = pack_current_batch(err)) return rc;
+                if (int rc = make_batch_run_view(err)) return rc;
+            }
             if (have_parts_) {
                 const uint64_t inst_ub_rows = total_rows_hint();
                 double ms = 0; uint64_t inst = 0;
@@ -1570,8 +1633,8 @@ public:
 
     uint64_t total_rows_hint() const {
         // rows = distinct k-mers above the emit threshold; unknown before the pass, retried if short
-        uint64_t slots = 0;
-        for (uint64_t i = 0; i < 1; i++) slots = (uint64_t)pp_.P * pp_.G * pp_.slice_cap;   // records >= rows / max_n
+        uint64_t slots = (uint64_t)pp_.P * pp_.G * pp_.slice_cap;         // records >= rows / max_n
+        if (!batches_.empty()) { slots = 0; for (auto &b : batches_) slots += b->part_off[pp_.P]; }
         return std::max<uint64_t>(1u << 16, slots / 8);
     }
 
@@ -1647,7 +1710,7 @@ public:
             if (int rc = compact_into(0, n_distinct_, dk, dc, err)) return rc;
         } else if (n_distinct_) {
             // stage inspection: run the counting pass again keeping every row
-            if (!have_parts_ || !recs_.p) { err = "partition buffers already released"; return -2; }
+            if (!have_parts_ || (!recs_.p && batches_.empty())) { err = "partition buffers already released"; return -2; }
             uint64_t rows = 0, hist[500], inst = 0; double ms = 0;
             if (int rc = run_count_partitions(run_view_, n_count_parts_, 0, dk, dc, rows, hist, inst, n_distinct_, ms, err)) return rc;
             if (rows != n_distinct_) { err = "distinct row count mismatch"; return -6; }
@@ -1706,12 +1769,14 @@ public:
         const uint64_t n_runs = (uint64_t)n_owned * n_sources;
         if (int rc = run_off_.alloc(n_runs, err)) return rc;
         if (int rc = run_cnt_.alloc(n_runs, err)) return rc;
+        std::vector<unsigned long long> addr16(n_runs);
+        for (uint64_t i = 0; i < n_runs; i++) addr16[i] = ((unsigned long long)(uintptr_t)d_recv >> 4) + run_off[i] * (unsigned long long)W;   // RW/2 = W
         if (n_runs) {
-            HIPCHK(hipMemcpyAsync(run_off_.p, run_off, n_runs * 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(run_off_.p, addr16.data(), n_runs * 8, hipMemcpyHostToDevice, stream_));
             HIPCHK(hipMemcpyAsync(run_cnt_.p, run_cnt, n_runs * 4, hipMemcpyHostToDevice, stream_));
         }
         shard_recv_ = d_recv;
-        run_view_.recs = (const uint64_t *)d_recv; run_view_.run_off = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+        run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
         run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned; run_view_.dbg = 0;
         uint64_t total_recs = 0;
         for (uint64_t i = 0; i < n_runs; i++) total_recs += run_cnt[i];
@@ -1770,7 +1835,7 @@ public:
         // count table is no longer needed once the solid set exists
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
-        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr;
+        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr; batches_.clear();
         // graph partitions: 256-512 rows each (mini tables of <= 2048 slots fit 16 KB of LDS); the minimiser length is the counting pass's, so rows that
         // arrive grouped by counting partition are grouped by graph partition too
         gp_ = 64;
@@ -2100,6 +2165,7 @@ private:
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
     DevBuf<unsigned long long> run_off_; DevBuf<uint32_t> run_cnt_;
     RunView run_view_{}; uint32_t n_count_parts_ = 0; uint32_t forced_P_ = 0;
+    std::vector<std::unique_ptr<BatchRecs>> batches_;
     const void *shard_recv_ = nullptr;
     DevBuf<uint64_t> ekeys_[W]; DevBuf<uint32_t> ecnt_;
     uint64_t n_emitted_ = 0; uint32_t emit_threshold_ = 0;

@@ -400,3 +400,37 @@ def test_device_fastq_parser_equals_host_parser():
     for data in (b"", b"\n", b"\r\n\n"):
         h = product(data, k=21, min_count=0, assemble=False)
         assert h.n_distinct == 0
+
+
+def test_several_batches_per_handle():
+    """Inputs are handed to the device in batches (chunked mode: every chunk_size reads; any mode: when a
+    batch would exceed its 32-bit base offsets; streaming: per pushed chunk).  Every batch keeps its own
+    record buffer and pass 2 reads one run per batch and partition: results must not change."""
+    g, fq = make_dataset(60000, 30, err=0.01, seed=77)
+    ref = product(fq, k=31, min_count=2)
+    o = run_oracle([fq], k=31, min_count=2)
+    compare_all(ref, o)
+    # host parser, small batches by base count (7 or so batches), bulk mode
+    a = _with_env({"SHK_HOST_PARSER": 1, "SHK_BATCH_BASES": 300000}, lambda: product(fq, k=31, min_count=2))
+    assert a.timings().get("batch_pack_kernel", 0) > 0
+    assert a.get_assembly() == ref.get_assembly() and a.get_preprocessing_info() == ref.get_preprocessing_info()
+    assert a.total_instances == ref.total_instances
+    # chunked mode through the host parser: one batch per 1000 reads
+    b = _with_env({"SHK_HOST_PARSER": 1}, lambda: product(fq, k=31, min_count=2, csize=1000))
+    assert b.timings().get("batch_pack_kernel", 0) > 0
+    assert b.get_assembly() == ref.get_assembly()
+    # streaming entry point with tiny batches, two-word keys, the distinct table itself
+    recs = fq.decode().split("@r")[1:]
+    parts = [("@r" + "@r".join(recs[i::3])).encode() for i in range(3)]
+    def stream():
+        h = AssemblyHelper.new(51, True, 0, 20, 0, False, False, False, False)
+        for p in parts:
+            h.push_reads(p)
+        h.finish_reads()
+        return h, sorted_table(*h.distinct())
+    c, (ck, cc, _) = _with_env({"SHK_BATCH_BASES": 200000}, stream)
+    assert c.timings().get("batch_pack_kernel", 0) > 0
+    o2 = run_oracle(parts, k=51, min_count=0)
+    ok_, oc_ = o2.distinct()
+    assert np.array_equal(ck, ok_) and np.array_equal(cc, oc_)
+    assert c.total_instances == o2.total_instances
