@@ -104,7 +104,7 @@ const char *shk_get_assembly(shk_handle *h);
  *        -- all-gather of the solid rows --
  *   shk_shard_set_solid  installs the whole solid set; the handle is then "preprocessed" and
  *                        shk_assemble() runs as usual (identically on every rank)
- * n_partitions: a power of two <= 4096, identical on all ranks. */
+ * n_partitions: a power of two <= 16384, identical on all ranks. */
 int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
                         uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions,
                         uint64_t *part_records /* [n_partitions] out */);

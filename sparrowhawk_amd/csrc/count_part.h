@@ -16,7 +16,7 @@
 // in RW = 2W 64-bit words, n-1 in the top 6 bits.  Results never depend on the partitioning.
 //
 // No global atomics in pass 1: workgroup g owns slice [p][g] of every partition buffer and keeps
-// its 4096 write cursors in LDS; the layout is a deterministic function of the input.
+// its (up to 16384) write cursors in LDS; the layout is a deterministic function of the input.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -27,7 +27,7 @@ namespace shk {
 
 static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
 static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
-static constexpr int PART_MAX_P = 4096;
+static constexpr int PART_MAX_P = 16384;             // LDS cursors: 64 KB
 static constexpr int STAGE_WORDS = 10240;            // 163840 bases of a read tile in LDS
 static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
 
@@ -62,7 +62,7 @@ static constexpr int DESC_CHECK = 2;                 // steps between room check
 static constexpr int STAGE_PF = (STAGE_WORDS + 8 + PART_THREADS - 1) / PART_THREADS;   // prefetch registers per thread
 
 struct PartShared {
-    uint32_t stage[2][STAGE_WORDS + 24];      // double buffer: the next tile is fetched while this one is walked
+    uint32_t stage[STAGE_WORDS + 24];         // the next tile is fetched into registers while this one is walked
     uint32_t desc_a[PART_WAVES][LDESC_CAP][64];   // tile-relative base offset (18 bits) | (n-1) << 18
     uint16_t desc_p[PART_WAVES][LDESC_CAP][64];
     uint32_t cursor[PART_MAX_P];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 
     // ---- tiles: [first, first+cnt) segments whose packed words [w0, w0+nwords) fit one LDS stage.  The
     // iterator is wave-uniform; tile i+1 is fetched into registers before tile i is walked and stored
-    // to the other stage afterwards: one workgroup barrier per tile, HBM latency behind the walk.
+    // to the stage afterwards: HBM latency behind the walk.
     struct Tile { uint32_t first, cnt, w0, nwords; };
     uint32_t it_st = g * PART_THREADS, it_first = it_st;
     auto next_tile = [&](Tile &t) -> bool {
@@ -186,11 +186,10 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     };
     Tile cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
     bool have_cur = next_tile(cur);
-    uint32_t buf = 0;
     uint32_t L = 0, rel = 0;
     if (have_cur) {
         for (uint32_t i = threadIdx.x; i < cur.nwords + 8; i += PART_THREADS)
-            sh.stage[0][i] = (i < cur.nwords + 1) ? bases[cur.w0 + i] : 0u;     // +1: the spare word
+            sh.stage[i] = (i < cur.nwords + 1) ? bases[cur.w0 + i] : 0u;        // +1: the spare word
         if (threadIdx.x < cur.cnt) {
             const uint32_t s0 = seg_off[cur.first + threadIdx.x], s1 = seg_off[cur.first + threadIdx.x + 1];
             L = s1 - s0; rel = s0 - (cur.w0 << 4);
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     __syncthreads();
     while (have_cur) {
         {
-            const uint32_t *stage = sh.stage[buf];
+            const uint32_t *stage = sh.stage;
             // ---- prefetch of the next tile (registers)
             const bool have_nxt = next_tile(nxt);
             uint32_t pf[STAGE_PF];
@@ -313,17 +312,17 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore); dcnt = 0; }
             if (run_p != NO_RUN) emit(L - (uint32_t)k + 1u);
             if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore);
-            // ---- the next tile goes to the other stage (its previous reader, tile i-1, ended before the last barrier)
+            // ---- the next tile replaces this one once every wave has finished reading it
+            __syncthreads();
             if (have_nxt) {
-                uint32_t *dst = sh.stage[buf ^ 1u];
 #pragma unroll
                 for (int i = 0; i < STAGE_PF; i++) {
                     const uint32_t idx = threadIdx.x + (uint32_t)i * PART_THREADS;
-                    if (idx < nxt.nwords + 8) dst[idx] = pf[i];
+                    if (idx < nxt.nwords + 8) sh.stage[idx] = pf[i];
                 }
             }
             __syncthreads();
-            cur = nxt; have_cur = have_nxt; buf ^= 1u; L = Ln; rel = reln;
+            cur = nxt; have_cur = have_nxt; L = Ln; rel = reln;
         }
     }
     __syncthreads();

@@ -1586,7 +1586,7 @@ public:
             }
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
-            if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way splitting"; return -6; }
+            if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way residue splitting"; return -6; }
             n_rows = h[0]; inst_out = h[1];
             if (n_rows <= cap) return 0;
             cap = n_rows;                                 // exact; run again
@@ -1727,7 +1727,7 @@ public:
                         uint32_t n_partitions, std::vector<uint64_t> &part_records, std::string &err) override {
         if (global_mode_) { err = "shard layer needs the partitioned counting mode"; return -1; }
         if (n_partitions < 1 || n_partitions > (uint32_t)PART_MAX_P || (n_partitions & (n_partitions - 1))) {
-            err = "n_partitions must be a power of two <= 4096"; return -1;
+            err = "n_partitions must be a power of two <= 16384"; return -1;
         }
         forced_P_ = n_partitions;
         part_records.assign(n_partitions, 0);

@@ -24,9 +24,9 @@ from .helper import AssemblyHelper, ShkError
 
 
 def choose_partitions(total_instances_ub, world, per_part=100_000):
-    """Power of two in [64, 4096], >= world, ~per_part k-mer instances per partition."""
+    """Power of two in [64, 16384], >= world, ~per_part k-mer instances per partition."""
     P = 64
-    while P < 4096 and P * per_part < total_instances_ub:
+    while P < 16384 and P * per_part < total_instances_ub:
         P <<= 1
     while P < world:
         P <<= 1

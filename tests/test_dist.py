@@ -42,7 +42,7 @@ def test_plan_exchange_is_consistent_single_process():
         for p in order:
             assert int(pl["base"][p]) == off
             off += int(allp[r, p])
-    assert choose_partitions(10, 8) == 64 and choose_partitions(4 * 10 ** 9, 8) == 4096
+    assert choose_partitions(10, 8) == 64 and choose_partitions(4 * 10 ** 9, 8) == 16384
     assert choose_partitions(100_000 * 1000, 2) == 1024
 
 
