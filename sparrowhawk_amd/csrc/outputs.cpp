@@ -19,7 +19,6 @@ static std::string revcomp(const char *s, size_t n) {
     for (size_t i = 0; i < n; i++) r[i] = comp(s[n - 1 - i]);
     return r;
 }
-static std::string revcomp(const std::string &s) { return revcomp(s.data(), s.size()); }
 
 // is revcomp(s) < s ?  decided at the first differing position, without materialising it
 static bool revcomp_is_smaller(const char *s, size_t n) {
@@ -97,29 +96,74 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     const size_t nc = contigs.size();
     out.ncontigs = nc;
 
-    // links: first k-mer of every (contig, orientation) -> id; '+' entries win over '-'
-    std::unordered_map<std::string, uint64_t> head;
-    head.reserve(nc * 2 + 1);
-    std::vector<std::string> tail_plus(nc), tail_minus(nc);
-    for (size_t i = 0; i < nc; i++) head.emplace(std::string(contigs[i].data(), k), i * 2);
+    // links: first k-mer of every (contig, orientation) -> id; '+' entries win over '-'.  K-mers are handled
+    // 2-bit packed (4 words hold k <= 127): a fragmented assembly has 10^4..10^6 contigs and this map is
+    // the whole cost of the writer then.
+    struct Key {
+        uint64_t w[4];
+        bool operator==(const Key &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+    };
+    struct KeyHash {
+        size_t operator()(const Key &x) const {
+            uint64_t h = 0x9e3779b97f4a7c15ull;
+            for (int i = 0; i < 4; i++) { h ^= x.w[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+            return (size_t)h;
+        }
+    };
+    auto code = [](char c) -> uint64_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
+    auto shl2 = [](Key &x, uint64_t b) {                       // x = x * 4 + b
+        x.w[3] = (x.w[3] << 2) | (x.w[2] >> 62); x.w[2] = (x.w[2] << 2) | (x.w[1] >> 62);
+        x.w[1] = (x.w[1] << 2) | (x.w[0] >> 62); x.w[0] = (x.w[0] << 2) | b;
+    };
+    auto mask_k = [&](Key &x) {                                // keep the low 2k bits
+        const uint32_t used = 2 * k;
+        for (uint32_t i = 0; i < 4; i++) {
+            if (64 * i >= used) x.w[i] = 0;
+            else if (used - 64 * i < 64) x.w[i] &= (1ull << (used - 64 * i)) - 1ull;
+        }
+    };
+    auto pack = [&](const char *p) {                           // first base in the top 2 bits of the 2k-bit value
+        Key x{{0, 0, 0, 0}};
+        for (uint32_t i = 0; i < k; i++) { const uint32_t pos = 2 * (k - 1 - i); x.w[pos >> 6] |= code(p[i]) << (pos & 63); }
+        return x;
+    };
+    auto pack_rc = [&](const char *p) {                        // reverse complement of p[0..k)
+        Key x{{0, 0, 0, 0}};
+        for (uint32_t i = 0; i < k; i++) { const uint32_t pos = 2 * i; x.w[pos >> 6] |= (3 - code(p[i])) << (pos & 63); }
+        return x;
+    };
+    // flat open-addressing table (the first entry of a key wins, like unordered_map::emplace)
+    size_t cap = 16; while (cap < 4 * nc + 4) cap <<= 1;
+    std::vector<Key> hk(cap); std::vector<uint64_t> hv(cap, ~0ull);
+    const KeyHash hasher;
+    auto put = [&](const Key &x, uint64_t v) {
+        size_t s = hasher(x) & (cap - 1);
+        while (hv[s] != ~0ull) { if (hk[s] == x) return; s = (s + 1) & (cap - 1); }
+        hk[s] = x; hv[s] = v;
+    };
+    auto get = [&](const Key &x) -> uint64_t {
+        size_t s = hasher(x) & (cap - 1);
+        while (hv[s] != ~0ull) { if (hk[s] == x) return hv[s]; s = (s + 1) & (cap - 1); }
+        return ~0ull;
+    };
+    std::vector<Key> tail_plus(nc), tail_minus(nc);
+    for (size_t i = 0; i < nc; i++) put(pack(contigs[i].data()), i * 2);
     for (size_t i = 0; i < nc; i++) {
-        std::string last(contigs[i].data() + contigs[i].size() - k, k);
-        std::string first(contigs[i].data(), k);
-        head.emplace(revcomp(last), i * 2 + 1);       // first k-mer of the '-' orientation
-        tail_plus[i] = std::move(last);               // last k-mer of '+'
-        tail_minus[i] = revcomp(first);               // last k-mer of '-'
+        const char *first = contigs[i].data(), *last = contigs[i].data() + contigs[i].size() - k;
+        put(pack_rc(last), i * 2 + 1);                  // first k-mer of the '-' orientation
+        tail_plus[i] = pack(last);                      // last k-mer of '+'
+        tail_minus[i] = pack_rc(first);                 // last k-mer of '-'
     }
     typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> Link;
     std::vector<Link> links;
-    const char B[4] = {'A', 'C', 'G', 'T'};
     for (size_t i = 0; i < nc; i++) for (uint32_t o = 0; o < 2; o++) {
-        const std::string &t = o ? tail_minus[i] : tail_plus[i];
-        std::string cand = t.substr(1) + "A";
-        for (int b = 0; b < 4; b++) {
-            cand[k - 1] = B[b];
-            auto it = head.find(cand);
-            if (it == head.end()) continue;
-            const uint32_t cj = (uint32_t)(it->second >> 1), oj = (uint32_t)(it->second & 1);
+        Key cand = o ? tail_minus[i] : tail_plus[i];
+        shl2(cand, 0); mask_k(cand);                    // drop the first base, append A
+        for (uint64_t b = 0; b < 4; b++) {
+            cand.w[0] = (cand.w[0] & ~3ull) | b;
+            const uint64_t hit = get(cand);
+            if (hit == ~0ull) continue;
+            const uint32_t cj = (uint32_t)(hit >> 1), oj = (uint32_t)(hit & 1);
             Link L((uint32_t)i + 1, o, cj + 1, oj), M(cj + 1, !oj, (uint32_t)i + 1, !o);
             links.push_back(M < L ? M : L);
         }
