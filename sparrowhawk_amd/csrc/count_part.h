@@ -467,7 +467,10 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * 
         h = mix32(h ^ lo ^ __builtin_amdgcn_alignbit(hi, hi, 9 + 3 * o));
     }
     uint32_t slot = (uint32_t)(((uint64_t)h * SR) >> 32);
-    for (uint32_t probes = 0; probes < 64;) {
+    // once the table is saturated (error-rich reads: most records are unique) only a short look for an
+    // existing copy is worth it: walking 64 slots of a 7/8 full table per record cost 4.5 ms per launch
+    const uint32_t max_probes = ctl.rec_used >= (SR / 8) * 7 ? 6u : 64u;
+    for (uint32_t probes = 0; probes < max_probes;) {
         uint32_t st = __hip_atomic_load(&rt.rst[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (st == 0) {
             if (ctl.rec_used >= (SR / 8) * 7) return false;             // keep the probe chains short
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         auto expand = [&](Rec<RW> rec, uint32_t n, uint32_t weight) {
             Kmer<W> f = km_zero<W>();
             for (uint32_t s = 0; s < n; s++) {
-                if (ctl.overflow) return;                   // the round is lost: do not walk full-table probe chains
+                if (ctl.overflow || ctl.n_used > (S / 10) * 9) return;   // the round is lost: do not walk full-table probe chains
                 if (s) {
 #pragma unroll
                     for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
@@ -764,7 +767,13 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             // once here and expanded once, with their multiplicity, in phase B
             if (rvw.dbg == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
             else if (rvw.dbg == 2) { if (n) expand(rec, n, 1u); }
-            else if (n && !rec_insert<W>(tb.rt, ctl, rec)) expand(rec, n, 1u);
+            else if (n && !rec_insert<W>(tb.rt, ctl, rec)) {
+                // the record table is saturated.  If that happens in the first half of the records, most of
+                // them are unique (error-rich reads): their k-mers cannot fit the k-mer table either, so the
+                // round is given up at once when the k-mer-level repartition can take over (always correct)
+                if (ovf && mod == 1 && (r0 - w_begin) * 2u < (w_end - w_begin)) ctl.overflow = 1;
+                else expand(rec, n, 1u);
+            }
         }
         {
             // phase B: every distinct record once, weighted.  The occupied slots are first listed in
@@ -923,6 +932,19 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) bucket_fill[(uint64_t)blockIdx.x * OVF_MAX_F + b] = cursor[b];
+}
+
+// per item: the fullest bucket; an item whose bucket region overflowed is switched off (F = 0) so that
+// k_count_buckets skips it (the host scatters it again with the room it needs)
+__global__ __launch_bounds__(256) void k_ovf_check(OvfItem *__restrict__ items, const uint32_t *__restrict__ bucket_fill,
+                                                   uint32_t n_items, uint32_t *__restrict__ max_fill) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        uint32_t mx = 0;
+        const uint32_t F = items[i].F;
+        for (uint32_t b = 0; b < F; b++) mx = max(mx, bucket_fill[(uint64_t)i * OVF_MAX_F + b]);
+        max_fill[i] = mx;
+        if (mx > items[i].cap) items[i].F = 0;
+    }
 }
 
 // counts one bucket of canonical k-mers (blockIdx.x = bucket, blockIdx.y = item); the same table, the

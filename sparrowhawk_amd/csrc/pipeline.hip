@@ -1496,7 +1496,7 @@ public:
         constexpr uint32_t S = CountShared<W>::S;
         const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0;
         DevBuf<unsigned long long> dh;
-        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list; DevBuf<uint64_t> d_kmers;
+        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill; DevBuf<uint64_t> d_kmers;
         if (int rc = dh.alloc(500, err)) return rc;
         if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
         uint64_t cap = cap_hint;
@@ -1523,8 +1523,12 @@ public:
                 HIPCHK(hipMemcpy(ov.data(), d_ovf.p, (size_t)n_ovf * sizeof(OvfRec), hipMemcpyDeviceToHost));
                 std::vector<OvfItem> items(n_ovf);
                 for (uint32_t i = 0; i < n_ovf; i++) {
+                    // buckets sized by INSTANCES (1.5 table sizes each): the distinct/instance estimate of the
+                    // aborted round is biased high (repeats show up late), and a bucket that turns out to hold
+                    // too many distinct k-mers only costs itself a second pass over its own k-mer list
                     uint32_t F = 2;
-                    while ((double)F * (0.45 * S) < (double)ov[i].est_distinct && F < OVF_MAX_F) F <<= 1;
+                    while ((double)F * (1.5 * S) < (double)ov[i].instances && F < OVF_MAX_F) F <<= 1;
+                    (void)ov[i].est_distinct;
                     const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 150) / (100ull * F) + 256;   // 50 % slack
                     items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
                     items[i].pad = 0; items[i].base = 0;
@@ -1544,29 +1548,27 @@ public:
                     HIPCHK(hipMemcpyAsync(d_items.p, items.data(), (size_t)ni * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
                     hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
                     HIPCHK(hipGetLastError());
-                    std::vector<uint32_t> fill((size_t)ni * OVF_MAX_F);
-                    HIPCHK(hipMemcpyAsync(fill.data(), d_fill.p, fill.size() * 4, hipMemcpyDeviceToHost, stream_));
+                    if (int rc = d_maxfill.alloc(ni, err)) return rc;
+                    hipLaunchKernelGGL(k_ovf_check, dim3(grid_for(ni)), dim3(256), 0, stream_, d_items.p, d_fill.p, ni, d_maxfill.p);
+                    HIPCHK(hipGetLastError());
+                    std::vector<uint32_t> mxf(ni);
+                    HIPCHK(hipMemcpyAsync(mxf.data(), d_maxfill.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipStreamSynchronize(stream_));
-                    std::vector<OvfItem> good, again; std::vector<uint32_t> good_fill;
+                    std::vector<OvfItem> again;
+                    uint32_t n_good = 0, max_f = 2;
                     for (uint32_t i = 0; i < ni; i++) {
-                        uint32_t mx = 0;
-                        for (uint32_t b = 0; b < items[i].F; b++) mx = std::max(mx, fill[(size_t)i * OVF_MAX_F + b]);
-                        if (mx <= items[i].cap) {
-                            good.push_back(items[i]);
-                            good_fill.insert(good_fill.end(), fill.begin() + (size_t)i * OVF_MAX_F, fill.begin() + (size_t)(i + 1) * OVF_MAX_F);
-                        } else if (pass + 1 < max_passes && (unsigned long long)mx + 256 < 0xFFFFFFF0ull) {
-                            OvfItem it = items[i]; it.cap = mx + 256; again.push_back(it);       // the exact need is known now
+                        if (mxf[i] <= items[i].cap) { n_good++; max_f = std::max(max_f, items[i].F); }
+                        else if (pass + 1 < max_passes && (unsigned long long)mxf[i] + 256 < 0xFFFFFFF0ull) {
+                            OvfItem it = items[i]; it.cap = mxf[i] + 256; again.push_back(it);       // the exact need is known now
                         } else bad.push_back(items[i].p);
                     }
-                    if (!good.empty()) {
-                        HIPCHK(hipMemcpyAsync(d_items.p, good.data(), good.size() * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
-                        HIPCHK(hipMemcpyAsync(d_fill.p, good_fill.data(), good_fill.size() * 4, hipMemcpyHostToDevice, stream_));
-                        hipLaunchKernelGGL(k_count_buckets<W>, dim3(OVF_MAX_F, (unsigned)good.size()), dim3(COUNT_THREADS), 0, stream_,
+                    if (n_good) {                                    // (overflowed items were switched off on the device)
+                        hipLaunchKernelGGL(k_count_buckets<W>, dim3(max_f, ni), dim3(COUNT_THREADS), 0, stream_,
                                            d_items.p, d_kmers.p, d_fill.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
                                            ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2));
                         HIPCHK(hipGetLastError());
                         HIPCHK(hipStreamSynchronize(stream_));      // d_items / d_kmers are reused by the next pass
-                        n_good_total += good.size();
+                        n_good_total += n_good;
                     }
                     items.swap(again);
                 }
