@@ -767,6 +767,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             // once here and expanded once, with their multiplicity, in phase B
             if (rvw.dbg == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
             else if (rvw.dbg == 2) { if (n) expand(rec, n, 1u); }
+            else if (rvw.dbg == 7) { if (n) (void)rec_insert<W>(tb.rt, ctl, rec); }      // timing experiment: dedupe only
             else if (n && !rec_insert<W>(tb.rt, ctl, rec)) {
                 // the record table is saturated.  If that happens in the first half of the records, most of
                 // them are unique (error-rich reads): their k-mers cannot fit the k-mer table either, so the
