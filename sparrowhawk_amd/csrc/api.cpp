@@ -182,19 +182,22 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
     const double t0 = now_ms();
     const size_t total = n1 + (fq2 ? n2 : 0);
     // ---- device-side parsing (fastq_gpu.hip): regular 4-line FASTQ is parsed, masked, segmented and
-    // packed by streaming kernels; gzip members are inflated on the host first.  Irregular input and
-    // every malformed record go to the host parser below, which owns the error messages.
-    const char *force_host = getenv("SHK_HOST_PARSER");
-    if (!(force_host && *force_host == '1') && total / 2 <= batch_bases()) {
-        std::vector<uint8_t> st1, st2;
-        const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
-        int rc = maybe_inflate(fq1, n1, st1, t1, l1, err);
-        if (!rc && fq2) rc = maybe_inflate(fq2, n2, st2, t2, l2, err);
+    // packed by streaming kernels.  Irregular input and every malformed record go to the host parser
+    // below, which owns the error messages.
+    // gzip (plain members: one thread per file; BGZF: block-parallel) is inflated once, for either parser
+    std::vector<uint8_t> st1, st2;
+    const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
+    {
+        int rc = maybe_inflate_pair(fq1, n1, fq2, n2, st1, st2, t1, l1, t2, l2, err);
         if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : SHK_E_OOM, err);
         h->pipe->times().add("gunzip_host_clock", now_ms() - t0);
+    }
+    const size_t text_total = l1 + (fq2 ? l2 : 0);
+    const char *force_host = getenv("SHK_HOST_PARSER");
+    if (!(force_host && *force_host == '1') && text_total / 2 <= batch_bases()) {
         const double t1c = now_ms();
         GpuPacked gp;
-        rc = gpu_pack_fastq(t1, l1, fq2 ? t2 : nullptr, l2, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err);
+        int rc = gpu_pack_fastq(t1, l1, fq2 ? t2 : nullptr, l2, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err);
         if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
         if (rc == 0) {
             h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t1c);
@@ -214,6 +217,7 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
         }
         gpu_packed_free(gp);                            // rc == 1: not regular -> host parser
     }
+    // ---- host parser (irregular framing, malformed records, inputs of several batches)
     PackedReads pr;
     size_t done_before = 0;
     auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
@@ -222,11 +226,11 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
     };
     int flush_rc = SHK_OK;
     auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
-    if (flush_every_reads(h) || (n1 + n2) / 2 > batch_bases()) h->pipe->expect_more_batches();
-    int rc = pack_fastq(fq1, n1, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
+    if (flush_every_reads(h) || text_total / 2 > batch_bases()) h->pipe->expect_more_batches();
+    int rc = pack_fastq(t1, l1, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
     if (!rc && fq2) {
         done_before = n1;
-        rc = pack_fastq(fq2, n2, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
+        rc = pack_fastq(t2, l2, h->k, h->min_qual, pr, err, h->progress_every(), prog, flush_every_reads(h), batch_bases(), flush);
     }
     if (rc == -7) return flush_rc;                       // the batch hand-over failed: its error is set
     if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : (rc == -4 ? SHK_E_OOM : SHK_E_PARAM), err);

@@ -3,6 +3,8 @@
 
 #include <string.h>
 #include <zlib.h>
+#include <atomic>
+#include <thread>
 
 namespace shk {
 
@@ -52,13 +54,93 @@ static int inflate_all(const uint8_t *in, size_t n, std::vector<uint8_t> &out, s
     return 0;
 }
 
+// ---- BGZF (bgzip) input: a gzip file made of independent blocks of <= 64 KiB, each announcing its
+// compressed size in a 'BC' extra subfield (SAM spec section 4.1).  The blocks are inflated in parallel.
+static bool bgzf_block(const uint8_t *b, size_t n, size_t &bsize) {
+    if (n < 18 || b[0] != 0x1F || b[1] != 0x8B || b[2] != 8 || !(b[3] & 4)) return false;
+    const size_t xlen = b[10] | ((size_t)b[11] << 8);
+    if (12 + xlen > n) return false;
+    for (size_t o = 12; o + 4 <= 12 + xlen;) {
+        const size_t slen = b[o + 2] | ((size_t)b[o + 3] << 8);
+        if (b[o] == 'B' && b[o + 1] == 'C' && slen == 2 && o + 6 <= 12 + xlen) {
+            bsize = (size_t)(b[o + 4] | ((size_t)b[o + 5] << 8)) + 1;
+            return bsize >= 12 + xlen + 8 && bsize <= n;
+        }
+        o += 4 + slen;
+    }
+    return false;
+}
+
+static int inflate_bgzf(const uint8_t *in, size_t n, std::vector<uint8_t> &out, std::string &err, bool &is_bgzf) {
+    struct Blk { size_t in_off, in_len, out_off, out_len, hdr; };
+    std::vector<Blk> blocks;
+    size_t p = 0, total = 0;
+    is_bgzf = false;
+    while (p < n) {
+        size_t bs = 0;
+        if (!bgzf_block(in + p, n - p, bs)) { if (blocks.empty()) return 0; err = "BGZF block chain broken"; is_bgzf = true; return -3; }
+        const size_t xlen = in[p + 10] | ((size_t)in[p + 11] << 8);
+        const uint8_t *t = in + p + bs - 4;
+        const size_t isize = t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+        blocks.push_back({p, bs, total, isize, 12 + xlen});
+        total += isize; p += bs;
+    }
+    is_bgzf = true;
+    out.resize(total);
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt < 1) nt = 1;
+    if (nt > 16) nt = 16;
+    if (nt > blocks.size()) nt = (unsigned)blocks.size();
+    std::atomic<size_t> next(0);
+    std::atomic<int> bad(0);
+    auto work = [&]() {
+        z_stream zs;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= blocks.size() || bad.load()) break;
+            const Blk &b = blocks[i];
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
+            zs.next_in = (Bytef *)(in + b.in_off + b.hdr); zs.avail_in = (uInt)(b.in_len - b.hdr - 8);
+            zs.next_out = out.data() + b.out_off; zs.avail_out = (uInt)b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            const bool ok = (rc == Z_STREAM_END) && zs.avail_out == 0;
+            inflateEnd(&zs);
+            if (!ok) { bad = 1; break; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned i = 1; i < nt; i++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (bad.load()) { err = "gzip stream corrupt"; return -3; }
+    return 0;
+}
+
 int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,
                   std::string &err) {
     p = buf; pn = n;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
-        if (int rc = inflate_all(buf, n, storage, err)) return rc;
+        bool is_bgzf = false;
+        if (int rc = inflate_bgzf(buf, n, storage, err, is_bgzf)) return rc;
+        if (!is_bgzf) if (int rc = inflate_all(buf, n, storage, err)) return rc;
         p = storage.data(); pn = storage.size();
     }
+    return 0;
+}
+
+// both files of a pair at once (a plain gzip member cannot be split, two files can)
+int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, std::vector<uint8_t> &s1,
+                       std::vector<uint8_t> &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
+                       std::string &err) {
+    p2 = nullptr; l2 = 0;
+    if (!b2) return maybe_inflate(b1, n1, s1, p1, l1, err);
+    int rc2 = 0; std::string err2;
+    std::thread t([&]() { rc2 = maybe_inflate(b2, n2, s2, p2, l2, err2); });
+    const int rc1 = maybe_inflate(b1, n1, s1, p1, l1, err);
+    t.join();
+    if (rc1) return rc1;
+    if (rc2) { err = err2; return rc2; }
     return 0;
 }
 
@@ -91,8 +173,9 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
                uint64_t flush_reads, uint64_t flush_bases, const FlushFn &flush) {
     std::vector<uint8_t> inflated;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
-        if (int rc = inflate_all(buf, n, inflated, err)) return rc;
-        buf = inflated.data(); n = inflated.size();
+        const uint8_t *q = nullptr; size_t qn = 0;
+        if (int rc = maybe_inflate(buf, n, inflated, q, qn, err)) return rc;
+        buf = q; n = qn;
     }
     if (out.seg_off.empty()) out.seg_off.push_back(0);
     std::vector<uint8_t> run;

@@ -38,5 +38,9 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
 // gzip sniff (1F 8B) + multi-member inflate; plain input is passed through (p/n point at buf or at `storage`)
 int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,
                   std::string &err);
+// the two files of a pair in two threads (b2 may be null); BGZF input is inflated block-parallel either way
+int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, std::vector<uint8_t> &s1,
+                       std::vector<uint8_t> &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
+                       std::string &err);
 
 }  // namespace shk

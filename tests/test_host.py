@@ -11,7 +11,7 @@ import pytest
 
 import sparrowhawk_amd
 from oracle import oracle_fit
-from sparrowhawk_amd import _lib, pack_fastq, ShkError
+from sparrowhawk_amd import _lib, pack_fastq, ShkError, synth
 from util import canonical_int, int_to_words, kmer_int, make_dataset, py_nthash, revcomp
 import cases
 
@@ -133,3 +133,35 @@ def test_product_does_not_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "shk_oracle" not in txt and "shko_" not in txt and "import oracle" not in txt \
                     and "from oracle" not in txt, f"{f} references the oracle"
+
+
+def _bgzf(data: bytes, block=30000) -> bytes:
+    """BGZF (bgzip) container: independent gzip members with a 'BC' extra subfield (SAM spec 4.1)."""
+    import struct, zlib
+    out = bytearray()
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]               # the empty EOF block last
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out += b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6)
+        out += b"BC" + struct.pack("<HH", 2, bsize - 1)
+        out += body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk))
+    return bytes(out)
+
+
+def test_packer_bgzf_blocks_are_inflated_in_parallel():
+    import gzip
+    g = synth.random_genome(3000, 5)
+    codes, quals = synth.sample_reads(g, 2000, 100, 6, err=0.01)
+    fq = synth.to_fastq(codes, quals)
+    assert gzip.decompress(_bgzf(fq)) == fq                 # the container is valid gzip
+    a = pack_fastq(fq, 21, 20)
+    b = pack_fastq(_bgzf(fq), 21, 20)
+    c = pack_fastq(gzip.compress(fq), 21, 20)
+    for x, y in ((a, b), (a, c)):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2:] == y[2:]
+    broken = bytearray(_bgzf(fq)); broken[40] ^= 0xFF
+    with pytest.raises(ShkError) as ei:
+        pack_fastq(bytes(broken), 21, 20)
+    assert ei.value.code == -3
