@@ -2,6 +2,7 @@
 #include "fastq.h"
 
 #include <string.h>
+#include <algorithm>
 #include <zlib.h>
 #include <atomic>
 #include <thread>
@@ -209,8 +210,13 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
             }
             if (c < 4) { run.push_back(c); continue; }
             if (run.size() >= k) {
-                if (out.n_bases + run.size() >= 0xFFFFFFF0ull) { err = "input exceeds 2^32 bases per batch"; return -1; }
-                append_run(out, run.data(), run.size());
+                if (out.n_bases + run.size() + run.size() / 256 >= 0xFFFFFFF0ull) { err = "input exceeds 2^32 bases per batch"; return -1; }
+                // the kernels take segments of at most 32768 bases: a longer run goes in as pieces that
+                // overlap by k-1 bases, so that every k-mer window lies in exactly one piece
+                const size_t kPiece = 16384;
+                if (run.size() <= kPiece + k - 1) append_run(out, run.data(), run.size());
+                else for (size_t p0 = 0; p0 + k - 1 < run.size(); p0 += kPiece)
+                    append_run(out, run.data() + p0, std::min(run.size() - p0, kPiece + k - 1));
             }
             run.clear();
         }

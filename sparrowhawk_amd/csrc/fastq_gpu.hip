@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256) void k_read_wave(const uint8_t *__restrict__ t
         if (MODE == 1) { so = seg_cnt[r]; bo = base_cnt[r]; }
         uint64_t run = 0, nseg = 0, nb = 0;                      // wave-uniform
         auto close_run = [&](uint64_t end_pos /* text position one past the run */) {
+            if (MODE == 0 && run > 16384 && lane == 0) stats[0] = 1;       // very long runs are split by the host parser
             if (run >= fp.k) {
                 if (MODE == 1) {
                     const uint64_t src = end_pos - run, b0 = bo + nb;

@@ -434,3 +434,17 @@ def test_several_batches_per_handle():
     ok_, oc_ = o2.distinct()
     assert np.array_equal(ck, ok_) and np.array_equal(cc, oc_)
     assert c.total_instances == o2.total_instances
+
+
+def test_long_reads_are_split_into_overlapping_segments():
+    """A 60 kbp read (longer than a kernel segment) goes through the host packer, which cuts it into
+    pieces overlapping by k-1 bases: every k-mer is counted exactly once."""
+    g = synth.random_genome(60000, 123)
+    seq = synth.codes_to_str(g)
+    fq = ("@long\n" + seq + "\n+\n" + "I" * len(seq) + "\n").encode()
+    fq = fq + fq.replace(b"@long", b"@again")                      # twice: every k-mer has count 2
+    for k in (31, 51):
+        h = product(fq, k=k, min_count=1)
+        o = run_oracle([fq], k=k, min_count=1)
+        compare_all(h, o)
+        assert h.total_instances == 2 * (len(seq) - k + 1)
