@@ -350,7 +350,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
 // rst: 0 empty, 1 being written, >= 3 ready with multiplicity rst-2
 template <int W, uint32_t SR_> struct RecTable {
     static constexpr uint32_t SR = SR_;
-    uint64_t w[2 * W][SR];
+    __attribute__((aligned(16))) uint64_t w[SR][2 * W];   // one record = adjacent words: 16-byte LDS reads
     uint32_t rst[SR];
     uint16_t order[SR];                                 // occupied record slots, sorted by record length
     uint32_t nhist[64], nbase[64];
@@ -477,7 +477,7 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * 
             st = atomicCAS(&rt.rst[slot], 0u, 1u);
             if (st == 0) {
 #pragma unroll
-                for (int o = 0; o < 2 * W; o++) rt.w[o][slot] = rec.w[o];
+                for (int o = 0; o < 2 * W; o++) rt.w[slot][o] = rec.w[o];
                 __hip_atomic_fetch_add(&rt.rst[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 3
                 atomicAdd(&ctl.rec_used, 1u);
                 return true;
@@ -486,7 +486,7 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * 
         if (st == 1) continue;                                          // owner is mid-write
         bool eq = true;
 #pragma unroll
-        for (int o = 0; o < 2 * W; o++) eq = eq && rt.w[o][slot] == rec.w[o];
+        for (int o = 0; o < 2 * W; o++) eq = eq && rt.w[slot][o] == rec.w[o];
         if (eq) { atomicAdd(&rt.rst[slot], 1u); return true; }
         slot = slot + 1 == SR ? 0 : slot + 1;
         probes++;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             __syncthreads();
             if (rvw.dbg != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
-                if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u);
+                if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u);
             __syncthreads();
             if (threadIdx.x < 64) {
                 const uint32_t v = rt.nhist[threadIdx.x];
@@ -798,7 +798,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             __syncthreads();
             if (rvw.dbg != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
-                if (rt.rst[s] >= 3u) rt.order[atomicAdd(&rt.nbase[(uint32_t)(rt.w[RW - 1][s] >> 58)], 1u)] = (uint16_t)s;
+                if (rt.rst[s] >= 3u) rt.order[atomicAdd(&rt.nbase[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u)] = (uint16_t)s;
             __syncthreads();
             uint32_t n_recs = ctl.n_recs;
             if (rvw.dbg == 3) n_recs = SRc;                 // timing experiment: slot order instead of length order
@@ -811,7 +811,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 if (rvw.dbg == 3 && rt.rst[s] < 3u) continue;
                 Rec<RW> rec;
 #pragma unroll
-                for (int o = 0; o < RW; o++) rec.w[o] = rt.w[o][s];
+                for (int o = 0; o < RW; o++) rec.w[o] = rt.w[s][o];
                 if (rvw.dbg != 1) expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
             }
         }
