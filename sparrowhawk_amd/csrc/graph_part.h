@@ -49,12 +49,17 @@ __device__ __forceinline__ void nt32_fill_lut(uint2 *lut, unsigned gm) {      //
         lut[threadIdx.x] = v;
     }
 }
-template <int W> __device__ __forceinline__ MinScan km_min_scan_lut(const Kmer<W> &x, int k, int gm, const uint2 *lut) {
+// hash state of the all-A gm-mer (wave-uniform: computed once per kernel, not per node)
+__device__ __forceinline__ Nt32State nt32_all_a(int gm) {
+    Nt32State nt; nt.fh = 0; nt.rh = 0;
+    for (int j = 0; j < gm; j++) { nt.fh ^= rol32(nt32_seed(0), (unsigned)j); nt.rh ^= rol32(nt32_seed(3), (unsigned)j); }
+    return nt;
+}
+template <int W> __device__ __forceinline__ MinScan km_min_scan_lut(const Kmer<W> &x, int k, int gm, const uint2 *lut,
+                                                                    const Nt32State &all_a) {
     MinScan r;
     // the first gm-mer: gm rolls from the all-A window (A leaves, base j enters) — the same LUT path as the scan
-    Nt32State nt;
-    nt.fh = 0; nt.rh = 0;
-    for (int j = 0; j < gm; j++) { nt.fh ^= rol32(nt32_seed(0), (unsigned)j); nt.rh ^= rol32(nt32_seed(3), (unsigned)j); }   // wave-uniform
+    Nt32State nt = all_a;
     for (int j = 0; j < gm; j++) {
         const uint2 t = lut[km_base<W>(x, k, j)];          // out = A: index (0 << 2) | in
         nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t.x;
@@ -125,12 +130,13 @@ __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, in
                                                   uint32_t *__restrict__ gp_of, uint32_t *__restrict__ gp_cnt) {
     __shared__ uint2 lut[16];
     nt32_fill_lut(lut, (unsigned)gt.gm);
+    const Nt32State all_a = nt32_all_a(gt.gm);
     __syncthreads();
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_round = (n + stride - 1) / stride * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         uint32_t p = 0xFFFFFFFFu;
-        if (i < n) { p = km_min_scan_lut<W>(keys.load(i), k, gt.gm, lut).min_all() & gt.gp_mask; gp_of[i] = p; }
+        if (i < n) { p = km_min_scan_lut<W>(keys.load(i), k, gt.gm, lut, all_a).min_all() & gt.gp_mask; gp_of[i] = p; }
         unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
@@ -269,6 +275,7 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
     const bool in_lds = pmask < ADJ_LDS_SLOTS;
     uint64_t *gtab = gt.e + gt.off[P];
     nt32_fill_lut(lut, gm);
+    const Nt32State all_a = nt32_all_a(gt.gm);
     if (threadIdx.x == 0) q_fill = 0;
     // ---- build the mini table (keys are distinct: claim the first empty slot)
     if (in_lds) { for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) tab[t] = EMPTY64; }
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         if (act) {
             x = keys.load(i);
             rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
-            ms = km_min_scan_lut<W>(x, k, gt.gm, lut);
+            ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);
             out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer
             last_b = km_base<W>(x, k, (int)gm - 1);                // last base of the first gm-mer
         }
