@@ -58,25 +58,44 @@ __device__ __forceinline__ Nt32State nt32_all_a(int gm) {
 template <int W> __device__ __forceinline__ MinScan km_min_scan_lut(const Kmer<W> &x, int k, int gm, const uint2 *lut,
                                                                     const Nt32State &all_a) {
     MinScan r;
+    // The roll terms depend on the bases only, not on the hash: they are fetched eight steps at a time
+    // (eight LDS reads in flight) and then folded in — 31 dependent LDS round trips per node otherwise.
+    constexpr int CH = 8;
     // the first gm-mer: gm rolls from the all-A window (A leaves, base j enters) — the same LUT path as the scan
     Nt32State nt = all_a;
-    for (int j = 0; j < gm; j++) {
-        const uint2 t = lut[km_base<W>(x, k, j)];          // out = A: index (0 << 2) | in
-        nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t.x;
-        nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t.y;
+    for (int j0 = 0; j0 < gm; j0 += CH) {
+        uint2 t[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) t[u] = lut[j0 + u < gm ? km_base<W>(x, k, j0 + u) : 0u];    // out = A: index (0 << 2) | in
+#pragma unroll
+        for (int u = 0; u < CH; u++)
+            if (j0 + u < gm) {
+                nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t[u].x;
+                nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t[u].y;
+            }
     }
     r.first = nt; r.h_first = nt32_canonical(nt);
     r.min_wo_first = 0xFFFFFFFFu; r.min_wo_last = r.h_first;
     const int w = k - gm + 1;
     uint32_t h = r.h_first;
-    for (int q = 1; q < w; q++) {
-        const uint32_t idx = (km_base<W>(x, k, q - 1) << 2) | km_base<W>(x, k, q + gm - 1);
-        const uint2 t = lut[idx];
-        nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t.x;
-        nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t.y;
-        h = nt32_canonical(nt);
-        r.min_wo_first = min(r.min_wo_first, h);
-        if (q < w - 1) r.min_wo_last = min(r.min_wo_last, h);
+    for (int q0 = 1; q0 < w; q0 += CH) {
+        uint2 t[CH];
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int q = q0 + u;
+            t[u] = lut[q < w ? ((km_base<W>(x, k, q - 1) << 2) | km_base<W>(x, k, q + gm - 1)) : 0u];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; u++) {
+            const int q = q0 + u;
+            if (q < w) {
+                nt.fh = __builtin_amdgcn_alignbit(nt.fh, nt.fh, 31) ^ t[u].x;
+                nt.rh = __builtin_amdgcn_alignbit(nt.rh, nt.rh, 1) ^ t[u].y;
+                h = nt32_canonical(nt);
+                r.min_wo_first = min(r.min_wo_first, h);
+                if (q < w - 1) r.min_wo_last = min(r.min_wo_last, h);
+            }
+        }
     }
     r.last = nt; r.h_last = h;
     return r;
