@@ -286,7 +286,10 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
                                                      uint32_t *__restrict__ overflow) {
     const unsigned gm = (unsigned)gt.gm;
     __shared__ uint2 lut[16];
-    __shared__ uint64_t tab[ADJ_LDS_SLOTS];
+    // LDS copy of the mini table.  One-word keys (k <= 31): the key itself plus the node id (12 B per slot),
+    // so a local probe never leaves the CU; wider keys: fingerprint | id, verified against the key array.
+    __shared__ uint64_t tab[ADJ_LDS_SLOTS];                // W == 1: keys; else fingerprint << 32 | id
+    __shared__ uint32_t tabi[W == 1 ? ADJ_LDS_SLOTS : 1];  // W == 1: node ids
     __shared__ uint32_t q_fill;
     const uint32_t P = blockIdx.x;
     const uint32_t r0 = roff[P], r1 = roff[P + 1];
@@ -296,25 +299,37 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
     nt32_fill_lut(lut, gm);
     const Nt32State all_a = nt32_all_a(gt.gm);
     if (threadIdx.x == 0) q_fill = 0;
-    // ---- build the mini table (keys are distinct: claim the first empty slot)
-    if (in_lds) { for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) tab[t] = EMPTY64; }
-    else { for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = EMPTY64; }
+    // ---- build the mini table (keys are distinct: claim the first empty slot).  A canonical k-mer is never
+    // all ones (k odd: at most 2k < 64W bits... or its reverse complement, all zeros, would be smaller)
+    constexpr bool KEYS_IN_LDS = W == 1;
+    for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) {
+        if (in_lds) tab[t] = EMPTY64;
+        if (!in_lds || KEYS_IN_LDS) gtab[t] = EMPTY64;
+    }
     __syncthreads();
     for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
         const uint32_t i = rows[r];
-        const uint64_t h = gt_hash<W>(keys.load(i));
+        const Kmer<W> key = keys.load(i);
+        const uint64_t h = gt_hash<W>(key);
         const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
         uint32_t slot = (uint32_t)h & pmask;
         bool done = false;
         for (uint32_t t = 0; t <= pmask; t++) {
-            unsigned long long *cell = in_lds ? (unsigned long long *)&tab[slot] : (unsigned long long *)&gtab[slot];
-            if (atomicCAS(cell, (unsigned long long)EMPTY64, (unsigned long long)entry) == EMPTY64) { done = true; break; }
+            if (in_lds && KEYS_IN_LDS) {
+                if (atomicCAS((unsigned long long *)&tab[slot], (unsigned long long)EMPTY64, (unsigned long long)key.w[0]) == EMPTY64) {
+                    tabi[slot] = i; gtab[slot] = entry; done = true; break;      // same slot in the stored table
+                }
+            } else {
+                unsigned long long *cell = in_lds ? (unsigned long long *)&tab[slot] : (unsigned long long *)&gtab[slot];
+                if (atomicCAS(cell, (unsigned long long)EMPTY64, (unsigned long long)entry) == EMPTY64) { done = true; break; }
+            }
             slot = (slot + 1) & pmask;
         }
         if (!done) *overflow = 1;
     }
     __syncthreads();
-    if (in_lds) for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = tab[t];
+    if (in_lds && !KEYS_IN_LDS) for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = tab[t];
+    if (gt.dbg == 1) { if (threadIdx.x == 0) qcnt[P] = 0; return; }     // timing experiment: table build only
     // ---- neighbours
     unsigned long long *myq = queries + 8ull * r0;
     const int lane = threadIdx.x & 63;
@@ -329,7 +344,7 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         if (act) {
             x = keys.load(i);
             rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
-            ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);
+            if (gt.dbg != 2) ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);      // (2: timing experiment without the scan)
             out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer
             last_b = km_base<W>(x, k, (int)gm - 1);                // last base of the first gm-mer
         }
@@ -341,7 +356,9 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
                 p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash_lut(ms.last, out_b, j, lut))
                            : min(ms.min_wo_last, nt32_prev_hash_lut(ms.first, j - 4u, last_b, lut))) & gt.gp_mask;
                 remote = p != P || !in_lds;
-                if (!remote) {
+                if (gt.dbg == 3) remote = false;                       // timing experiment: scan + candidates only
+                if (gt.dbg == 4 && remote) { remote = false; }         // timing experiment: no remote queue
+                else if (!remote && gt.dbg != 3) {
                     bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
                     const uint64_t h = gt_hash<W>(c);
                     const uint32_t fp = (uint32_t)(h >> 32);
@@ -349,9 +366,11 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
                     for (uint32_t t = 0; t <= pmask; t++) {
                         const uint64_t e = tab[slot];
                         if (e == EMPTY64) break;
-                        if ((uint32_t)(e >> 32) == fp && km_eq<W>(keys.load((uint32_t)e), c)) { idx = (uint32_t)e; break; }
+                        if constexpr (KEYS_IN_LDS) { if (e == c.w[0]) { idx = tabi[slot]; break; } }
+                        else if ((uint32_t)(e >> 32) == fp && km_eq<W>(keys.load((uint32_t)e), c)) { idx = (uint32_t)e; break; }
                         slot = (slot + 1) & pmask;
                     }
+                    (void)fp;
                     if (idx != NIL) {
                         a |= 1u << j;
                         // a predecessor q -> (x,0) is the edge (x,1) -> rc(q)

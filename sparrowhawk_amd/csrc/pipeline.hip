@@ -78,6 +78,7 @@ struct GraphTable {                            // entry = fingerprint<<32 | node
     const uint32_t *msk;                       // [GP] its size - 1 (power of two)
     uint32_t gp_mask;                          // GP - 1
     int gm;                                    // minimiser length of the graph partition function
+    uint32_t dbg;                              // timing experiments only (SHK_DEBUG_G)
 };
 
 }  // namespace shk
@@ -767,7 +768,7 @@ public:
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
         g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
-        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_);
+        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = (uint32_t)env_u64("SHK_DEBUG_G", 0);
         g.n = (uint32_t)n_solid_;
         return g;
     }
