@@ -776,6 +776,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 else expand(rec, n, 1u);
             }
         }
+        if (rvw.dbg == 10) return;                          // timing experiment: phase A only, no phase B
         {
             // phase B: every distinct record once, weighted.  The occupied slots are first listed in
             // order of record length (counting sort in LDS) so that the 64 records a wave expands
@@ -817,9 +818,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
         __syncthreads();
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
+        if (rvw.dbg == 8) return;                           // timing experiment: no defer / emit work at all
         if (over && ovf && mod == 1) {
             // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets):
             // report the estimated number of distinct k-mers and the exact number of instances
+            if (rvw.dbg == 9) return;                       // timing experiment: overflow detected, nothing reported
             // distinct / instance ratio of what was inserted before the table filled up, times all instances
             if (threadIdx.x == 0) ctl.tried = 0;
             __syncthreads();
