@@ -1,0 +1,90 @@
+"""Randomised differential test: the HIP path against the oracle on many small random datasets
+(k, coverage, error rate, repeats, min_count, min_qual, flags, one or two files, gzip, chunking drawn at
+random).  Not part of the pytest suite: run on a GPU box, e.g.  python tools/fuzz_parity.py 300 1"""
+import gzip
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401
+from sparrowhawk_amd import AssemblyHelper, synth
+from util import compare_all, run_oracle
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+for case in range(n_cases):
+    k = int(rng.choice([15, 21, 27, 31, 33, 41, 51, 63, 65, 77, 89, 95, 101, 127]))
+    glen = int(rng.integers(300, 30000))
+    g = synth.random_genome(glen, int(rng.integers(1 << 30)))
+    if rng.random() < 0.4:                                   # planted repeats -> branching graph
+        L = int(rng.integers(k + 5, 4 * k))
+        src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
+        g[dst:dst + L] = g[src:src + L]
+    if rng.random() < 0.2:                                   # inverted repeat / hairpin material
+        L = int(rng.integers(k, 3 * k)); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
+        g[dst:dst + L] = (3 - g[src:src + L])[::-1]
+    rl = int(rng.choice([max(k + 3, 60), 100, 150, 250]))
+    rl = max(rl, k + 1)
+    cov = float(rng.choice([3, 8, 20, 40]))
+    err = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
+    circular = bool(rng.random() < 0.15)
+    n_reads = max(1, int(glen * cov / rl))
+    codes, quals = synth.sample_reads(g, n_reads, rl, int(rng.integers(1 << 30)), err=err, circular=circular)
+    if rng.random() < 0.3:                                   # N bases
+        m = rng.random(codes.shape) < 0.003
+        fq = synth.to_fastq(codes, quals).decode()
+        # put Ns into the text form
+        lines = fq.split("\n")
+        for i in range(1, len(lines), 4):
+            row = m[(i - 1) // 4]
+            if row.any():
+                s = list(lines[i])
+                for j in np.flatnonzero(row): s[j] = "N"
+                lines[i] = "".join(s)
+        fq = "\n".join(lines).encode()
+    else:
+        fq = synth.to_fastq(codes, quals)
+    min_count = int(rng.choice([0, 1, 2, 3, 5]))
+    min_qual = int(rng.choice([0, 11, 20, 33]))
+    do_fit = bool(rng.random() < 0.25)
+    do_bloom = bool(rng.random() < 0.1 and min_count >= 3)
+    csize = int(rng.choice([0, 0, 500, 150000]))
+    nb, nd = bool(rng.random() < 0.15), bool(rng.random() < 0.15)
+    files = [fq]
+    if rng.random() < 0.3:
+        recs = fq.split(b"\n@r")
+        half = max(1, len(recs) // 2)
+        f1 = b"\n@r".join(recs[:half]) + b"\n"
+        f2 = b"@r" + b"\n@r".join(recs[half:]) if len(recs) > half else None
+        files = [f1] + ([f2] if f2 else [])
+    sent = [gzip.compress(f) if rng.random() < 0.3 else f for f in files]
+    env = {}
+    if rng.random() < 0.3: env["SHK_HOST_PARSER"] = "1"
+    if rng.random() < 0.2: env["SHK_BATCH_BASES"] = str(int(rng.integers(2000, 200000)))
+    if rng.random() < 0.2: env["SHK_PART_P"] = str(int(rng.choice([64, 256, 16384])))
+    old = {e: os.environ.get(e) for e in env}
+    os.environ.update(env)
+    desc = dict(case=case, k=k, glen=glen, rl=rl, cov=cov, err=err, circ=circular, mc=min_count, mq=min_qual, fit=do_fit,
+                bloom=do_bloom, csize=csize, nb=nb, nd=nd, nfiles=len(files), env=env)
+    try:
+        h = AssemblyHelper.new(k, True, min_count, min_qual, csize, do_bloom, do_fit, nb, nd)
+        h.preprocess(sent[0], sent[1] if len(sent) > 1 else None)
+        h.assemble()
+        o = run_oracle(files, k=k, min_count=min_count, min_qual=min_qual, do_fit=do_fit, no_bubble_collapse=nb,
+                       no_dead_end_removal=nd)
+        compare_all(h, o)
+        h.free()
+    except Exception as e:                                   # report and stop: a failing case is a bug
+        print("FAIL", desc, repr(e), flush=True)
+        raise
+    finally:
+        for e, v in old.items():
+            if v is None: os.environ.pop(e, None)
+            else: os.environ[e] = v
+    if case % 20 == 0:
+        print("case", case, "ok  %.0f s" % (time.time() - t0), desc, flush=True)
+print("all", n_cases, "cases identical to the oracle in %.0f s" % (time.time() - t0))
