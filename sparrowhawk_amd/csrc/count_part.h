@@ -356,22 +356,24 @@ template <int W, uint32_t SR_> struct RecTable {
     uint32_t nhist[64], nbase[64];
 };
 
-template <int W> struct CountShared;
-template <> struct CountShared<1> {
+// the k-mer table alone (k_count_buckets needs nothing else: two workgroups share a CU's LDS there)
+template <int W> struct KmerTable;
+template <> struct KmerTable<1> {
     static constexpr uint32_t S = 5376;                 // k-mer table: 12 B / slot -> 63 KB
     static constexpr uint32_t NB = S / 4;               // buckets of 4 keys = two ds_read_b128
     __attribute__((aligned(16))) uint64_t key0[S];
     uint32_t cnt[S];
-    RecTable<1, 4096> rt;                               // 22 B / slot -> 88 KB
 };
-// W >= 2: one key array per word, a state word per slot (0 empty, 1 being written, 2 ready); the
-// LDS is split between the k-mer table (72 KB) and the record table (~70 KB)
-template <int W> struct CountShared {
+// W >= 2: one key array per word, a state word per slot (0 empty, 1 being written, 2 ready)
+template <int W> struct KmerTable {
     static constexpr uint32_t S = (73728u / (8u * W + 8u)) & ~63u;            // 3072 / 2304 / 1792 slots for W = 2 / 3 / 4
     uint64_t key[W][S];
     uint32_t cnt[S];
     uint32_t state[S];
-    RecTable<W, ((71680u / (16u * W + 6u)) & ~63u)> rt;                       // 1856 / 1280 / 1024 records
+};
+// pass 2 proper: the LDS is split between the k-mer table (63-72 KB) and the record table (70-88 KB)
+template <int W> struct CountShared : KmerTable<W> {
+    RecTable<W, (W == 1 ? 4096u : ((71680u / (16u * W + 6u)) & ~63u))> rt;   // 4096 / 1856 / 1280 / 1024 records
 };
 
 struct CountCtl {
@@ -402,16 +404,17 @@ template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) 
 }
 
 // insert into the LDS table; returns false when the probe sequence is exhausted
-template <int W>
-__device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h,
-                                           uint32_t weight) {
-    constexpr uint32_t S = CountShared<W>::S;
+// (COUNT_USED = false: the caller keeps ctl.n_used itself from the return value 2 = "new key")
+template <int W, bool COUNT_USED = true>
+__device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h,
+                                          uint32_t weight) {
+    constexpr uint32_t S = KmerTable<W>::S;
     if constexpr (W == 1) {
         // 4-way buckets: the whole bucket comes back from one pair of 16-byte LDS reads, so a hit
         // (the common case at >1x coverage) costs one LDS round trip instead of a serial probe chain.
         // A key lives in the first bucket of its probe sequence that had a free slot when it arrived;
         // slots never change once written, so "bucket has a free slot and no match" proves absence.
-        constexpr uint32_t NB = CountShared<1>::NB;
+        constexpr uint32_t NB = KmerTable<1>::NB;
         uint32_t b = (uint32_t)(((uint64_t)h * NB) >> 32);
         const unsigned long long kk = key.w[0];
         for (uint32_t probes = 0; probes < 64u;) {          // a longer chain means the table is (locally) full: split
@@ -422,14 +425,18 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
                 const int e = a.x == ~0ull ? 0 : a.y == ~0ull ? 1 : c.x == ~0ull ? 2 : c.y == ~0ull ? 3 : -1;
                 if (e < 0) { b = b + 1 == NB ? 0 : b + 1; probes++; continue; }      // bucket full
                 const unsigned long long old = atomicCAS((unsigned long long *)&tb.key0[4 * b + e], ~0ull, kk);
-                if (old == ~0ull) { atomicAdd(&ctl.n_used, 1u); j = e; }
+                if (old == ~0ull) {
+                    if constexpr (COUNT_USED) atomicAdd(&ctl.n_used, 1u);
+                    atomicAdd(&tb.cnt[4 * b + e], weight);
+                    return 2;
+                }
                 else if (old == kk) j = e;
                 else continue;                              // lost the slot to another key: look again
             }
             atomicAdd(&tb.cnt[4 * b + j], weight);
-            return true;
+            return 1;
         }
-        return false;
+        return 0;
     } else {
         uint32_t slot = (uint32_t)(((uint64_t)h * S) >> 32);
         uint32_t probes = 0;
@@ -441,17 +448,17 @@ __device__ __forceinline__ bool lds_insert(CountShared<W> &tb, CountCtl &ctl, co
 #pragma unroll
                 for (int j = 0; j < W; j++) tb.key[j][slot] = key.w[j];
                 __hip_atomic_store(&tb.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                atomicAdd(&ctl.n_used, 1u);
+                if constexpr (COUNT_USED) atomicAdd(&ctl.n_used, 1u);
                 atomicAdd(&tb.cnt[slot], weight);
-                return true;
+                return 2;
             }
             if (st == 1) continue;                          // owner is mid-write
             bool eq = true;
 #pragma unroll
             for (int j = 0; j < W; j++) eq = eq && tb.key[j][slot] == key.w[j];
-            if (eq) { atomicAdd(&tb.cnt[slot], weight); return true; }
+            if (eq) { atomicAdd(&tb.cnt[slot], weight); return 1; }
             slot = slot + 1 == S ? 0 : slot + 1;
-            if (++probes >= 48u) return false;              // table (locally) full: the caller splits the class
+            if (++probes >= 48u) return 0;              // table (locally) full: the caller splits the class
         }
     }
 }
@@ -495,69 +502,74 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * 
 }
 
 // empty table, zero round-local histogram (all threads; ends with a barrier)
-template <int W> __device__ __forceinline__ void table_reset(CountShared<W> &tb, CountCtl &ctl) {
-    constexpr uint32_t S = CountShared<W>::S;
+template <int W> __device__ __forceinline__ void kmer_table_reset(KmerTable<W> &tb, CountCtl &ctl) {
+    constexpr uint32_t S = KmerTable<W>::S;
     for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
         tb.cnt[s] = 0;
         if constexpr (W == 1) tb.key0[s] = ~0ull; else tb.state[s] = 0;
     }
-    for (uint32_t s = threadIdx.x; s < decltype(tb.rt)::SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
     for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) ctl.histo[b] = 0;
     __syncthreads();
 }
+template <int W> __device__ __forceinline__ void table_reset(CountShared<W> &tb, CountCtl &ctl) {
+    for (uint32_t s = threadIdx.x; s < decltype(tb.rt)::SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
+    kmer_table_reset<W>(tb, ctl);
+}
 
-// a finished round: histogram of the table's counts, rows with count > threshold appended to the output
-template <int W>
-__device__ __forceinline__ void table_emit(CountShared<W> &tb, CountCtl &ctl, unsigned long long mine, uint32_t threshold,
+// a finished round: histogram of the table's counts, rows with count > threshold appended to the output.
+// One scan of the table feeds the round-local histogram and lists the slots to emit in LDS (list: room
+// for S slot numbers); then one global atomic reserves the rows and they are written densely — one
+// store instruction per 64 rows and array, whatever the density of solid rows in the table.
+template <int W, typename LT>
+__device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtl &ctl, unsigned long long mine, uint32_t threshold,
                                            unsigned long long *__restrict__ histo, KeyArr<W> out_keys,
                                            uint32_t *__restrict__ out_cnt, unsigned long long out_cap,
-                                           unsigned long long *__restrict__ out_cursor) {
-    constexpr uint32_t S = CountShared<W>::S;
+                                           unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg = 0) {
+    constexpr uint32_t S = KmerTable<W>::S;
     const int lane = threadIdx.x & 63;
-    // ---- scan 1: histogram + number of rows to emit
+    if (dbg == 10) return;                                  // (timing experiments 10, 11, 4: stop after successive stages)
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
     if (lane == 0 && mine) atomicAdd(&ctl.n_inst, mine);
-    uint32_t my_emit = 0;
     for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
+        // (S is a multiple of 64: whole waves.)  Singletons — nearly every slot when the reads carry
+        // errors — go in with one LDS atomic per wave instead of 64 serialised ones on one address
         const uint32_t c = tb.cnt[s];
-        if (c) {
-            atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
-            if (c > threshold) my_emit++;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) my_emit += __shfl_down(my_emit, o);
-    if (lane == 0 && my_emit) atomicAdd(&ctl.n_emit, my_emit);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long base = ctl.n_emit ? atomicAdd(out_cursor, (unsigned long long)ctl.n_emit) : 0ull;
-        ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
-    }
-    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
-        if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
-    __syncthreads();
-    // ---- scan 2: write rows (wave-aggregated reservation inside the workgroup's range)
-    const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
-    const uint32_t s_round = (S + COUNT_THREADS - 1) / COUNT_THREADS * COUNT_THREADS;
-    for (uint32_t s = threadIdx.x; s < s_round; s += COUNT_THREADS) {
-        const uint32_t c = s < S ? tb.cnt[s] : 0u;
-        const bool e = c > threshold && c != 0;
+        const unsigned long long m1 = __ballot(c == 1u);
+        if (lane == 0 && m1) atomicAdd(&ctl.histo[0], (uint32_t)__popcll(m1));
+        if (c > 1u) atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
+        const bool e = c > threshold;                       // (c == 0: an empty slot, never above a threshold >= 0)
         const unsigned long long em = __ballot(e);
         if (!em) continue;
         uint32_t wb = 0;
-        if (lane == 0) wb = atomicAdd(&ctl.wave_cursor, (uint32_t)__popcll(em));
+        if (lane == 0) wb = atomicAdd(&ctl.n_emit, (uint32_t)__popcll(em));
         wb = __shfl(wb, 0);
-        if (e) {
-            const unsigned long long o = gbase + wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
-            if (o < out_cap) {
-                Kmer<W> x;
-                if constexpr (W == 1) x.w[0] = tb.key0[s];
-                else {
+        if (e) list[wb + (uint32_t)__popcll(em & ((1ull << lane) - 1ull))] = (LT)s;
+    }
+    if (dbg == 11) return;
+    __syncthreads();
+    const uint32_t n_emit = ctl.n_emit;
+    if (threadIdx.x == 0) {
+        unsigned long long base = (n_emit && dbg != 5) ? atomicAdd(out_cursor, (unsigned long long)n_emit) : 0ull;
+        ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
+    }
+    if (dbg != 1)                                           // (timing experiment: no global histogram flush)
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+        if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
+    if (!n_emit || dbg == 4) return;                        // (uniform)
+    __syncthreads();
+    const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
+    for (uint32_t i = threadIdx.x; i < n_emit; i += COUNT_THREADS) {
+        const uint32_t sl = list[i];
+        const unsigned long long o = gbase + i;
+        if (o < out_cap) {
+            Kmer<W> x;
+            if constexpr (W == 1) x.w[0] = tb.key0[sl];
+            else {
 #pragma unroll
-                    for (int j = 0; j < W; j++) x.w[j] = tb.key[j][s];
-                }
-                out_keys.store(o, x);
-                out_cnt[o] = c;
+                for (int j = 0; j < W; j++) x.w[j] = tb.key[j][sl];
             }
+            out_keys.store(o, x);
+            out_cnt[o] = tb.cnt[sl];
         }
     }
 }
@@ -649,7 +661,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags,
     const uint32_t *__restrict__ part_list /* nullable: partitions to process */,
     OvfRec *__restrict__ ovf /* nullable: partitions that do not fit are listed here instead of being split */,
-    uint32_t *__restrict__ ovf_n) {
+    uint32_t *__restrict__ ovf_n,
+    uint32_t probe_blocks, uint32_t defer_after /* != 0: a workgroup numbered >= probe_blocks (they start in
+                            order, so the first ones act as a sample of the partitions: partition = minimiser hash)
+                            that finds *ovf_n >= defer_after takes the input for error-rich and hands its partition
+                            to the k-mer-level repartition without trying it first.  Only the path taken depends
+                            on the timing, never the counts. */) {
     constexpr int RW = 2 * W;
     constexpr uint32_t S = CountShared<W>::S;
     __shared__ CountShared<W> tb;
@@ -672,12 +689,40 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
         if (threadIdx.x == 0) {
             ctl.pre[S_runs] = run; ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
-            ctl.n_inst = 0;
+            ctl.n_inst = 0; ctl.n_used = 0;
+            ctl.overflow = (ovf && defer_after && blockIdx.x >= probe_blocks && __hip_atomic_load(ovf_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= defer_after) ? 1u : 0u;
         }
     }
     __syncthreads();
     const uint32_t R = ctl.pre[S_runs];
     if (rvw.dbg == 5) return;                            // timing experiment: launch + run prefix only
+
+    // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets): report the
+    // estimated number of distinct k-mers (distinct / instance ratio of what was inserted before the table
+    // filled up, times all instances) and the exact number of instances
+    auto defer = [&](unsigned long long mine) {
+        if (threadIdx.x == 0) ctl.tried = 0;
+        __syncthreads();
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+        if (lane == 0 && mine) atomicAdd(&ctl.tried, mine);
+        unsigned long long inst = 0;
+        for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
+            uint32_t lo = 0, hi = S_runs;
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[lo] << 4) + (uint64_t)(r - ctl.pre[lo]) * RW;
+            inst += (src[RW - 1] >> 58) + 1ull;
+        }
+        for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+        if (lane == 0 && inst) atomicAdd(&ctl.n_inst, inst);
+        __syncthreads();
+        if (threadIdx.x == 0 && R) {
+            const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.n_inst / (double)ctl.tried : (double)ctl.n_inst;
+            const uint32_t slot = atomicAdd(ovf_n, 1u);
+            OvfRec o; o.p = p; o.est_distinct = !ctl.tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)est; o.instances = ctl.n_inst;
+            ovf[slot] = o;
+        }
+    };
+    if (ctl.overflow) { defer(0ull); return; }            // (uniform: written before the barrier above)
 
     while (true) {
         __syncthreads();
@@ -820,30 +865,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
         if (rvw.dbg == 8) return;                           // timing experiment: no defer / emit work at all
         if (over && ovf && mod == 1) {
-            // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets):
-            // report the estimated number of distinct k-mers and the exact number of instances
             if (rvw.dbg == 9) return;                       // timing experiment: overflow detected, nothing reported
-            // distinct / instance ratio of what was inserted before the table filled up, times all instances
-            if (threadIdx.x == 0) ctl.tried = 0;
-            __syncthreads();
-            for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
-            if (lane == 0 && mine) atomicAdd(&ctl.tried, mine);
-            unsigned long long inst = 0;
-            for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
-                uint32_t lo = 0, hi = S_runs;
-                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
-                const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[lo] << 4) + (uint64_t)(r - ctl.pre[lo]) * RW;
-                inst += (src[RW - 1] >> 58) + 1ull;
-            }
-            for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
-            if (lane == 0 && inst) atomicAdd(&ctl.n_inst, inst);
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.n_inst / (double)ctl.tried : (double)ctl.n_inst;
-                const uint32_t slot = atomicAdd(ovf_n, 1u);
-                OvfRec o; o.p = p; o.est_distinct = est > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)est; o.instances = ctl.n_inst;
-                ovf[slot] = o;
-            }
+            defer(mine);
             return;
         }
         if (over) {
@@ -861,7 +884,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             }
             continue;
         }
-        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor);
+        // (phase B is over: the record table's multiplicity words are free to hold the emit list)
+        static_assert(2u * decltype(tb.rt)::SR >= S, "emit list");
+        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, reinterpret_cast<uint16_t *>(tb.rt.rst));
     }
     __syncthreads();
     if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
@@ -896,7 +921,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
     for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) cursor[b] = 0;
     __syncthreads();
     const uint32_t R = pre[S_runs];
-    const uint32_t fmask = it.F - 1u;
+    const uint32_t F = it.F;
     for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS) {
         uint32_t lo = 0, hi = S_runs;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
@@ -925,7 +950,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
             Kmer<W> c;
 #pragma unroll
             for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
-            const uint32_t b = (km_mix32<W>(c) >> 12) & fmask;
+            // (any F: multiply-high of a second mix of the key hash, independent of the table slot and residue bits)
+            const uint32_t b = (uint32_t)(((uint64_t)mix32(km_mix32<W>(c) ^ 0x85EBCA6Bu) * F) >> 32);
             const uint32_t pos = atomicAdd(&cursor[b], 1u);
             if (pos < it.cap) {
                 uint64_t *dst = kmers + (it.base + (unsigned long long)b * it.cap + pos) * W;
@@ -938,35 +964,47 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
     for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) bucket_fill[(uint64_t)blockIdx.x * OVF_MAX_F + b] = cursor[b];
 }
 
-// per item: the fullest bucket; an item whose bucket region overflowed is switched off (F = 0) so that
-// k_count_buckets skips it (the host scatters it again with the room it needs)
-__global__ __launch_bounds__(256) void k_ovf_check(OvfItem *__restrict__ items, const uint32_t *__restrict__ bucket_fill,
-                                                   uint32_t n_items, uint32_t *__restrict__ max_fill) {
+// one non-empty bucket of a scattered partition: nb canonical k-mers from k-mer index `first`
+struct BucketRef { unsigned long long first; uint32_t nb, pad; };
+
+// per item: the fullest bucket; the non-empty buckets of the items that fit go on the work list of
+// k_count_buckets (an item whose bucket region overflowed is scattered again by the host with the room it needs)
+__global__ __launch_bounds__(256) void k_ovf_check(const OvfItem *__restrict__ items, const uint32_t *__restrict__ bucket_fill,
+                                                   uint32_t n_items, uint32_t *__restrict__ max_fill,
+                                                   BucketRef *__restrict__ list, uint32_t *__restrict__ list_n) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
-        uint32_t mx = 0;
-        const uint32_t F = items[i].F;
-        for (uint32_t b = 0; b < F; b++) mx = max(mx, bucket_fill[(uint64_t)i * OVF_MAX_F + b]);
+        uint32_t mx = 0, ne = 0;
+        const OvfItem it = items[i];
+        for (uint32_t b = 0; b < it.F; b++) {
+            const uint32_t f = bucket_fill[(uint64_t)i * OVF_MAX_F + b];
+            mx = max(mx, f); ne += f != 0;
+        }
         max_fill[i] = mx;
-        if (mx > items[i].cap) items[i].F = 0;
+        if (mx > it.cap || !ne) continue;
+        uint32_t at = atomicAdd(list_n, ne);
+        for (uint32_t b = 0; b < it.F; b++) {
+            const uint32_t f = bucket_fill[(uint64_t)i * OVF_MAX_F + b];
+            if (f) { BucketRef r; r.first = it.base + (unsigned long long)b * it.cap; r.nb = f; r.pad = 0; list[at++] = r; }
+        }
     }
 }
 
-// counts one bucket of canonical k-mers (blockIdx.x = bucket, blockIdx.y = item); the same table, the
+// counts one bucket of canonical k-mers (one entry of the work list per workgroup); the same table, the
 // same emit and — should a bucket still not fit — the same residue-class splitting as k_count_partitions
 template <int W>
 __global__ __launch_bounds__(COUNT_THREADS) void k_count_buckets(
-    const OvfItem *__restrict__ items, const uint64_t *__restrict__ kmers, const uint32_t *__restrict__ bucket_fill,
+    const BucketRef *__restrict__ list, const uint64_t *__restrict__ kmers,
     uint32_t threshold, unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
-    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags) {
-    constexpr uint32_t S = CountShared<W>::S;
-    __shared__ CountShared<W> tb;
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg /* timing experiments (SHK_DEBUG_B) */) {
+    constexpr uint32_t S = KmerTable<W>::S;
+    __shared__ KmerTable<W> tb;                         // ~half the LDS: two workgroups per CU overlap their fixed latencies
     __shared__ CountCtl ctl;
-    const OvfItem it = items[blockIdx.y];
-    if (blockIdx.x >= it.F) return;
-    const uint32_t nb = min(bucket_fill[(uint64_t)blockIdx.y * OVF_MAX_F + blockIdx.x], it.cap);
-    if (nb == 0) return;
-    const uint64_t *src = kmers + (it.base + (unsigned long long)blockIdx.x * it.cap) * W;
+    constexpr uint32_t ELIST = W == 1 ? S : 64;         // emit list: W >= 2 reuses the state words
+    __shared__ uint16_t elist[ELIST];
+    const BucketRef ref = list[blockIdx.x];
+    const uint32_t nb = ref.nb;
+    const uint64_t *src = kmers + ref.first * W;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x == 0) {
         ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0; ctl.n_inst = 0;
@@ -982,25 +1020,42 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_buckets(
             ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
             ctl.prog_num = 0; ctl.prog_den = nb;
         }
-        table_reset<W>(tb, ctl);
+        kmer_table_reset<W>(tb, ctl);
         unsigned long long mine = 0;
+        // the k-mer of the next iteration is requested before the current one is inserted
+        auto fetch = [&](uint32_t i, Kmer<W> &c) {
+            if (i < nb) {
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = src[(uint64_t)i * W + j];
+            }
+        };
+        Kmer<W> nxt = km_zero<W>();
+        fetch(threadIdx.x, nxt);
         for (uint32_t i0 = 0; i0 < nb; i0 += COUNT_THREADS) {
             if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i0 + 1u); break; }
             const uint32_t i = i0 + threadIdx.x;
-            if (i < nb) {
-                Kmer<W> c;
-#pragma unroll
-                for (int j = 0; j < W; j++) c.w[j] = src[(uint64_t)i * W + j];
+            const Kmer<W> c = nxt;
+            fetch(i + COUNT_THREADS, nxt);
+            bool fresh = false;
+            if (i < nb && dbg != 3) {
                 const uint32_t h = km_mix32<W>(c);
                 if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {
-                    if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u)) ctl.overflow = 1;
+                    const int r = lds_insert<W, false>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u);
+                    if (!r) ctl.overflow = 1;
+                    fresh = r == 2;
                     mine++;
                 }
             }
+            if (dbg == 3 && i < nb && c.w[0] == 0x123456789ull) ctl.overflow = 1;
+            // most k-mers of an error-rich bucket are new keys: one LDS atomic per wave for the fill level
+            const unsigned long long fm = __ballot(fresh);
+            if (lane == 0 && fm) atomicAdd(&ctl.n_used, (uint32_t)__popcll(fm));
         }
+        if (dbg == 2 || dbg == 3) return;                   // timing experiments: no emit
         __syncthreads();
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
         if (over) {
+            if (threadIdx.x == 0) atomicAdd(&flags[1], 1u);      // (statistic: buckets split by residue class)
             if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -1013,11 +1068,11 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_buckets(
             }
             continue;
         }
-        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor);
+        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, dbg);
+        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, dbg);   // (the state words are not read after counting)
     }
     __syncthreads();
-    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
-    (void)lane;
+    if (threadIdx.x == 0 && ctl.n_inst && dbg != 8) atomicAdd(n_inst, ctl.n_inst);
 }
 
 }  // namespace shk

@@ -437,7 +437,7 @@ public:
         constexpr uint32_t S = CountShared<W>::S;
         const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0;
         DevBuf<unsigned long long> dh;
-        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill; DevBuf<uint64_t> d_kmers;
+        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill; DevBuf<uint64_t> d_kmers; DevBuf<BucketRef> d_blist;
         if (int rc = dh.alloc(500, err)) return rc;
         if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
         uint64_t cap = cap_hint;
@@ -448,10 +448,16 @@ public:
             HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             EvTimer t(stream_);
+            // The first workgroups of the launch act as a sample of the partitions.  When most of them do
+            // not fit the LDS table the reads are error-rich, and the later workgroups hand their partitions
+            // to the k-mer-level repartition at once instead of finding out one by one (that cost 6 ms of 23
+            // on configs[2] with the errors left in).  Decided on the device, inside the one launch.
+            const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
+            const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
             hipLaunchKernelGGL(k_count_partitions<W>, dim3(n_parts), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
-                               (uint32_t *)(ctl_.p + 3));
+                               (uint32_t *)(ctl_.p + 3), n_probe + n_probe / 2, n_probe / 2);
             HIPCHK(hipGetLastError());
             ms_out = t.stop();
             unsigned long long h[4];
@@ -463,13 +469,16 @@ public:
                 std::vector<OvfRec> ov(n_ovf);
                 HIPCHK(hipMemcpy(ov.data(), d_ovf.p, (size_t)n_ovf * sizeof(OvfRec), hipMemcpyDeviceToHost));
                 std::vector<OvfItem> items(n_ovf);
+                uint32_t n_untried = 0;
                 for (uint32_t i = 0; i < n_ovf; i++) {
-                    // buckets sized by INSTANCES (1.5 table sizes each): the distinct/instance estimate of the
+                    // buckets sized by INSTANCES (1.1 table sizes each, any F): the distinct/instance estimate of the
                     // aborted round is biased high (repeats show up late), and a bucket that turns out to hold
                     // too many distinct k-mers only costs itself a second pass over its own k-mer list
-                    uint32_t F = 2;
-                    while ((double)F * (1.5 * S) < (double)ov[i].instances && F < OVF_MAX_F) F <<= 1;
-                    (void)ov[i].est_distinct;
+                    // (about half of an error-rich bucket's k-mers are distinct: a table at ~45 % keeps the linear
+                    // probe chains far below the 48-probe limit; at 60 % one bucket in a few hit it and re-ran by residue classes)
+                    const unsigned long long per = (unsigned long long)S * env_u64("SHK_OVF_FILL_PCT", 110) / 100;
+                    const uint32_t F = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>((ov[i].instances + per - 1) / per, 2ull), OVF_MAX_F);
+                    if (ov[i].est_distinct == 0) n_untried++;
                     const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 150) / (100ull * F) + 256;   // 50 % slack
                     items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
                     items[i].pad = 0; items[i].base = 0;
@@ -490,27 +499,34 @@ public:
                     hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
                     HIPCHK(hipGetLastError());
                     if (int rc = d_maxfill.alloc(ni, err)) return rc;
-                    hipLaunchKernelGGL(k_ovf_check, dim3(grid_for(ni)), dim3(256), 0, stream_, d_items.p, d_fill.p, ni, d_maxfill.p);
+                    unsigned long long n_buckets_ub = 0;
+                    for (auto &it : items) n_buckets_ub += it.F;
+                    if (int rc = d_blist.alloc(n_buckets_ub, err)) return rc;
+                    HIPCHK(hipMemsetAsync(ctl_.p + 4, 0, sizeof(unsigned long long), stream_));
+                    hipLaunchKernelGGL(k_ovf_check, dim3(grid_for(ni)), dim3(256), 0, stream_, d_items.p, d_fill.p, ni, d_maxfill.p,
+                                       d_blist.p, (uint32_t *)(ctl_.p + 4));
                     HIPCHK(hipGetLastError());
                     std::vector<uint32_t> mxf(ni);
+                    unsigned long long n_list = 0;
                     HIPCHK(hipMemcpyAsync(mxf.data(), d_maxfill.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
+                    HIPCHK(hipMemcpyAsync(&n_list, ctl_.p + 4, sizeof n_list, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipStreamSynchronize(stream_));
                     std::vector<OvfItem> again;
-                    uint32_t n_good = 0, max_f = 2;
+                    uint32_t n_good = 0;
                     for (uint32_t i = 0; i < ni; i++) {
-                        if (mxf[i] <= items[i].cap) { n_good++; max_f = std::max(max_f, items[i].F); }
+                        if (mxf[i] <= items[i].cap) n_good++;
                         else if (pass + 1 < max_passes && (unsigned long long)mxf[i] + 256 < 0xFFFFFFF0ull) {
                             OvfItem it = items[i]; it.cap = mxf[i] + 256; again.push_back(it);       // the exact need is known now
                         } else bad.push_back(items[i].p);
                     }
-                    if (n_good) {                                    // (overflowed items were switched off on the device)
-                        hipLaunchKernelGGL(k_count_buckets<W>, dim3(max_f, ni), dim3(COUNT_THREADS), 0, stream_,
-                                           d_items.p, d_kmers.p, d_fill.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
-                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2));
+                    if ((uint32_t)n_list) {
+                        hipLaunchKernelGGL(k_count_buckets<W>, dim3((uint32_t)n_list), dim3(COUNT_THREADS), 0, stream_,
+                                           d_blist.p, d_kmers.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), (uint32_t)env_u64("SHK_DEBUG_B", 0));
                         HIPCHK(hipGetLastError());
                         HIPCHK(hipStreamSynchronize(stream_));      // d_items / d_kmers are reused by the next pass
-                        n_good_total += n_good;
                     }
+                    n_good_total += n_good;
                     items.swap(again);
                 }
                 if (!bad.empty()) {
@@ -518,20 +534,24 @@ public:
                     HIPCHK(hipMemcpyAsync(d_list.p, bad.data(), bad.size() * 4, hipMemcpyHostToDevice, stream_));
                     hipLaunchKernelGGL(k_count_partitions<W>, dim3((unsigned)bad.size()), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
                                        dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
-                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr);
+                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
                     HIPCHK(hipGetLastError());
                 }
                 ms_out += t2.stop();
                 times_.add("count_repartitioned_x1", (double)n_good_total);
+                times_.add("count_deferred_untried_x1", (double)n_untried);
                 times_.add("count_residue_rerun_x1", (double)bad.size());
                 HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipStreamSynchronize(stream_));
+                times_.add("count_bucket_splits_x1", (double)(h[2] >> 32));
             }
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipStreamSynchronize(stream_));
             if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way residue splitting"; return -6; }
             n_rows = h[0]; inst_out = h[1];
-            if (n_rows <= cap) return 0;
+            if (n_rows <= cap) {
+                return 0;
+            }
             cap = n_rows;                                 // exact; run again
         }
         err = "row buffer overflowed twice";

@@ -290,14 +290,22 @@ def test_counting_modes_agree():
 
 
 @pytest.mark.parametrize("k,mode", [(31, "repartition"), (51, "repartition"), (89, "repartition"), (127, "repartition"),
-                                    (31, "residue"), (51, "residue"), (31, "tiny_buckets"), (51, "rescatter")])
+                                    (31, "residue"), (51, "residue"), (31, "tiny_buckets"), (51, "rescatter"),
+                                    (31, "probe"), (51, "probe")])
 def test_partitions_that_exceed_the_lds_table(k, mode):
     """Few partitions + many distinct k-mers: each partition exceeds the LDS table.  It is then
     repartitioned at k-mer level (k_ovf_scatter / k_count_buckets); with that switched off, or when a
     bucket region overflows, it is re-run per residue class of the key hash (count_part.h).  Results
-    must not change."""
-    g, fq = make_dataset(150000, 12, err=0.02, seed=92)
-    env = {"SHK_PART_P": 64}
+    must not change.  "probe": more partitions than workgroups in flight; the first ones find the
+    input error-rich and the later ones hand their partitions over without trying them."""
+    if mode == "probe":
+        g, fq = make_dataset(400000, 45, err=0.02, seed=94)
+        env = {"SHK_PART_P": 1024, "SHK_PROBE_PARTS": 128}
+        n_tables = 1024
+    else:
+        g, fq = make_dataset(150000, 12, err=0.02, seed=92)
+        env = {"SHK_PART_P": 64}
+        n_tables = 64
     if mode == "residue":
         env["SHK_NO_REPARTITION"] = 1
     if mode == "tiny_buckets":
@@ -312,9 +320,11 @@ def test_partitions_that_exceed_the_lds_table(k, mode):
     h, t, (hk, hc, _) = _with_env(env, both)
     o = run_oracle([fq], k=k, min_count=0, min_qual=0)
     ok_, oc_ = o.distinct()
-    assert len(oc_) > 64 * (6144 if k <= 63 else 3648)  # really more than the LDS tables hold
+    assert len(oc_) > n_tables * (6144 if k <= 63 else 3648)  # really more than the LDS tables hold
     assert np.array_equal(hk, ok_) and np.array_equal(hc, oc_)
     assert np.array_equal(h.histo(), o.histo()) and h.total_instances == o.total_instances
+    if mode == "probe":
+        assert t.get("count_deferred_untried_x1", 0) >= 256 and t.get("count_repartitioned_x1", 0) >= 900, t
     if mode == "repartition":
         assert t.get("count_repartitioned_x1", 0) > 0
     if mode == "residue":
