@@ -214,6 +214,12 @@ def main():
     except Exception:
         pass
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    # the second denominator SURVEY.md 8(d) asks for: what a pure streaming read of 2 GiB reaches on this box
+    stream_gbs = None
+    if rank == 0:
+        g = ctypes.c_double(0.0)
+        if L.shk_measure_stream_read(2 << 30, 5, ctypes.byref(g)) == 0:
+            stream_gbs = g.value
     line = {
         "metric": "Gbases/s assembled, k=31 150bp reads",
         "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,6 +235,7 @@ def main():
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     "achievable_peak": stream_gbs, "frac_of_achievable": (achieved / stream_gbs) if stream_gbs else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                      "count_step_ms": c_ms + p_ms,
                      "count_step_frac": (alg_bytes / ((c_ms + p_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if c_ms + p_ms > 0 else 0.0,

@@ -156,6 +156,11 @@ int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0
  * for one preprocess+assemble); this returns the cache to the driver.  SHK_NO_POOL=1 disables it. */
 void shk_release_cached_memory(void);
 
+/* Measurement helper (bench.py): best rate in GB/s of `iters` pure streaming reads of a
+ * `bytes` device buffer on the current HIP device — the achievable HBM read peak of this box, reported
+ * beside the nominal 8 TB/s.  No counterpart in the reference. */
+int shk_measure_stream_read(size_t bytes, int iters, double *gbs);
+
 const char *shk_version(void);
 
 #ifdef __cplusplus

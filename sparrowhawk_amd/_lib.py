@@ -56,6 +56,7 @@ SIGNATURES = {
     "shk_host_nthash": (_u64, [_cp, _u32]),
     "shk_host_fit": (_int, [_vp, C.POINTER(_u32)]),
     "shk_release_cached_memory": (None, []),
+    "shk_measure_stream_read": (_int, [_sz, _int, C.POINTER(C.c_double)]),
     "shk_version": (_cp, []),
 }
 

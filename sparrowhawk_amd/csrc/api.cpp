@@ -62,6 +62,11 @@ static int fail(shk_handle *h, int code, const std::string &msg) { h->err = msg;
 extern "C" {
 
 void shk_release_cached_memory(void) { device_pool_trim(); }
+int shk_measure_stream_read(size_t bytes, int iters, double *gbs) {
+    std::string err;
+    const int rc = stream_read_gbs(bytes, iters, gbs, err);
+    return rc == 0 ? SHK_OK : rc == -1 ? SHK_E_PARAM : rc == -4 ? SHK_E_OOM : SHK_E_DEVICE;
+}
 
 const char *shk_version(void) { return "sparrowhawk_amd 0.1 (gfx950)"; }
 int shk_new_error(void) { return g_new_err; }

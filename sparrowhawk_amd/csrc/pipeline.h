@@ -76,6 +76,8 @@ void device_free(void *dptr);
 void device_pool_trim();
 // the process-wide device block cache (pipeline.hip): bytes is rounded up to the block actually handed out
 void *device_pool_alloc(size_t &bytes);
+// best rate (GB/s) of `iters` pure streaming reads of a `bytes` buffer on the current device
+int stream_read_gbs(size_t bytes, int iters, double *gbs, std::string &err);
 void device_pool_release(void *p, size_t bytes);
 
 }  // namespace shk

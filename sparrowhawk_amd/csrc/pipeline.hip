@@ -1188,6 +1188,49 @@ template <int W> static int host_canon_t(const char *seq, uint32_t k, uint64_t *
     if (orient) *orient = o;
     return 0;
 }
+// ---- measurement helper: what a pure streaming read reaches on this box (SURVEY.md 8d asks for the
+// achievable HBM peak beside the nominal 8 TB/s).  16 bytes per lane and load, 8 loads in flight.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_stream_read(const u32x4_t *__restrict__ src, uint64_t n16, uint32_t *__restrict__ sink) {
+    u32x4_t acc = {0, 0, 0, 0};
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= v[u];
+    }
+    for (; i < n16; i += stride) acc ^= src[i];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = 1;      // never with the fill pattern: keeps the loads alive
+}
+int stream_read_gbs(size_t bytes, int iters, double *gbs, std::string &err) {
+    if (!gbs || bytes < (1u << 20) || iters < 1) { err = "bad arguments"; return -1; }
+    void *buf = nullptr; uint32_t *sink = nullptr;
+    if (hipMalloc(&buf, bytes) != hipSuccess || hipMalloc((void **)&sink, 4) != hipSuccess) {
+        (void)hipGetLastError(); if (buf) (void)hipFree(buf);
+        err = "out of device memory"; return -4;
+    }
+    hipStream_t st = nullptr;
+    (void)hipMemsetAsync(buf, 0x5A, bytes, st); (void)hipMemsetAsync(sink, 0, 4, st);
+    const uint64_t n16 = bytes / 16;
+    const dim3 grid(256 * 16);
+    hipLaunchKernelGGL(k_stream_read, grid, dim3(256), 0, st, (const u32x4_t *)buf, n16, sink);   // warm-up
+    double best = 0;
+    for (int it = 0; it < iters; it++) {
+        EvTimer t(st);
+        hipLaunchKernelGGL(k_stream_read, grid, dim3(256), 0, st, (const u32x4_t *)buf, n16, sink);
+        const double ms = t.stop();
+        if (ms > 0) best = std::max(best, (double)(n16 * 16) / (ms * 1e-3) / 1e9);
+    }
+    const hipError_t e = hipGetLastError();
+    (void)hipFree(buf); (void)hipFree(sink);
+    if (e != hipSuccess) { err = hipGetErrorString(e); return -5; }
+    *gbs = best;
+    return 0;
+}
+
 int host_canonical(const char *seq, uint32_t k, uint64_t *out, int *orient) {
     const int W = (2 * k + 63) / 64;
     if (W == 1) return host_canon_t<1>(seq, k, out, orient);
