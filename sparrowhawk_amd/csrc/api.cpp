@@ -176,6 +176,106 @@ static int flush_host_batch(shk_handle *h, PackedReads &pr) {
 // chunked mode hands a batch on every chunk_size reads (docs/src/assembly.md:17: "reads per batch")
 static uint64_t flush_every_reads(const shk_handle *h) { return (!h->do_bloom && h->chunk_size > 0) ? h->chunk_size : 0; }
 
+// start of the first FASTQ record at or after `from` (a line starting with '@' whose line after next starts
+// with '+': a quality line may start with '@' too, but then the line after next is a sequence); n = none,
+// SIZE_MAX = the text does not look like 4-line FASTQ here
+static size_t next_record_start(const uint8_t *t, size_t n, size_t from) {
+    size_t p = from;
+    if (p >= n) return n;
+    if (p > 0 && t[p - 1] != '\n') {
+        const void *nl = memchr(t + p, '\n', n - p);
+        if (!nl) return n;
+        p = (size_t)((const uint8_t *)nl - t) + 1;
+    }
+    for (int tries = 0; tries < 8 && p < n; tries++) {
+        const void *e0 = memchr(t + p, '\n', n - p);
+        if (!e0) return n;
+        const size_t b = (size_t)((const uint8_t *)e0 - t) + 1;
+        if (b >= n) return n;
+        const void *e1 = memchr(t + b, '\n', n - b);
+        if (!e1) return n;
+        const size_t c = (size_t)((const uint8_t *)e1 - t) + 1;
+        if (t[p] == '@' && c < n && t[c] == '+') return p;
+        p = b;
+    }
+    return SIZE_MAX;
+}
+
+// A text of more than one batch: pieces of ~2 * batch_bases() bytes, cut at record boundaries, go through
+// the device parser one after the other, each counted as its own batch (pass 1) before the next is parsed.
+// handled = false (and nothing counted) when the very first piece is not regular 4-line FASTQ: the caller
+// then runs the host parser over everything.  A later piece that is not regular is parsed on the host from
+// there to the end of its file, with the record numbers and progress of the whole file.
+static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1, const uint8_t *t2, size_t l2,
+                                    size_t n1, size_t total, bool &handled) {
+    handled = false;
+    std::string err;
+    const size_t piece_bytes = (size_t)(2 * batch_bases());
+    uint64_t reads_done = 0;
+    bool counted_any = false;
+    const double t0 = now_ms();
+    for (int f = 0; f < 2; f++) {
+        const uint8_t *t = f ? t2 : t1;
+        const size_t len = f ? l2 : l1;
+        if (!t) continue;
+        const size_t done_before = f ? n1 : 0;
+        uint64_t file_reads = 0;
+        size_t off = 0;
+        while (off < len) {
+            size_t end = len;
+            if (len - off > piece_bytes + piece_bytes / 8) {
+                end = next_record_start(t, len, off + piece_bytes);
+                if (end == SIZE_MAX) end = off;          // no record boundary found: the host parser takes it from here
+            }
+            int rc = 1;
+            GpuPacked gp;
+            if (end > off) {
+                rc = gpu_pack_fastq(t + off, end - off, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, reads_done);
+                if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+            }
+            if (rc == 1) {
+                gpu_packed_free(gp);
+                if (!counted_any) return SHK_OK;         // handled stays false
+                // the rest of this file on the host
+                PackedReads pr;
+                pr.n_reads = reads_done;
+                auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
+                    const uint64_t pct = total ? (100 * (done_before + off + bytes)) / total : 100;
+                    h->post_mode(("loop:" + std::to_string(reads) + ":" + std::to_string(pct)).c_str());
+                };
+                int flush_rc = SHK_OK;
+                auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
+                int rc2 = pack_fastq(t + off, len - off, h->k, h->min_qual, pr, err, h->progress_every(), prog, 0, batch_bases(), flush, file_reads);
+                if (rc2 == -7) return flush_rc;
+                if (rc2) return fail(h, rc2 == -3 ? SHK_E_PARSE : (rc2 == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
+                if (int rc3 = flush_host_batch(h, pr)) return rc3;
+                reads_done = pr.n_reads;
+                break;
+            }
+            if (!counted_any) h->pipe->expect_more_batches();
+            h->pipe->times().add("fastq_h2d_text", gp.h2d_ms);
+            h->pipe->times().add("fastq_device_kernels", gp.kernels_ms);
+            h->pipe->times().add("fastq_device_pieces_x1", 1.0);
+            const uint64_t every = h->progress_every();
+            for (size_t j = 0; j < gp.progress_bytes.size(); j++) {
+                const uint64_t bytes = gp.progress_bytes[j] & ~(1ull << 63);
+                const uint64_t pct = total ? (100 * (done_before + off + bytes)) / total : 100;
+                h->post_mode(("loop:" + std::to_string(every * (gp.first_mark + j + 1)) + ":" + std::to_string(pct)).c_str());
+            }
+            int rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
+            reads_done += gp.n_reads; file_reads += gp.n_reads;
+            gpu_packed_free(gp);
+            if (rc2) return rc2;
+            counted_any = true;
+            off = end;
+        }
+    }
+    handled = true;
+    h->n_reads = reads_done;
+    h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t0);
+    return finish_counting(h);
+}
+
 int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used (Assembler.ts:92: one preprocess per handle)");
@@ -221,6 +321,12 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
             return rc;
         }
         gpu_packed_free(gp);                            // rc == 1: not regular -> host parser
+    }
+    // ---- texts of several batches: pieces cut at record boundaries, each through the device parser
+    if (!(force_host && *force_host == '1') && text_total / 2 > batch_bases()) {
+        bool handled = false;
+        int rc = preprocess_device_pieces(h, t1, l1, fq2 ? t2 : nullptr, l2, n1, total, handled);
+        if (rc || handled) return rc;
     }
     // ---- host parser (irregular framing, malformed records, inputs of several batches)
     PackedReads pr;

@@ -171,7 +171,7 @@ inline void append_run(PackedReads &o, const uint8_t *codes, size_t len) {
 
 int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
                std::string &err, uint64_t every, const ProgressFn &progress,
-               uint64_t flush_reads, uint64_t flush_bases, const FlushFn &flush) {
+               uint64_t flush_reads, uint64_t flush_bases, const FlushFn &flush, uint64_t rec_base) {
     std::vector<uint8_t> inflated;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
         const uint8_t *q = nullptr; size_t qn = 0;
@@ -180,7 +180,7 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
     }
     if (out.seg_off.empty()) out.seg_off.push_back(0);
     std::vector<uint8_t> run;
-    size_t p = 0; uint64_t rec = 0;
+    size_t p = 0; uint64_t rec = rec_base;
     const int minq = (int)min_qual;
     while (p < n) {
         if (buf[p] == '\n') { p++; continue; }

@@ -33,7 +33,8 @@ using ProgressFn = std::function<void(uint64_t, uint64_t, uint64_t)>;
 using FlushFn = std::function<int(PackedReads &)>;
 int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
                std::string &err, uint64_t every = 0, const ProgressFn &progress = nullptr,
-               uint64_t flush_reads = 0, uint64_t flush_bases = 0, const FlushFn &flush = nullptr);
+               uint64_t flush_reads = 0, uint64_t flush_bases = 0, const FlushFn &flush = nullptr,
+               uint64_t rec_base = 0 /* records of this file that came before buf: numbering of the error messages */);
 
 // gzip sniff (1F 8B) + multi-member inflate; plain input is passed through (p/n point at buf or at `storage`)
 int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,

@@ -15,13 +15,16 @@ struct GpuPacked {
     uint64_t n_seg = 0, n_bases = 0, n_reads = 0, n_input_bases = 0;
     // one entry per `every` reads: bytes consumed inside the file the batch ends in; bit 63 = second file
     std::vector<unsigned long long> progress_bytes;
+    uint64_t first_mark = 0;          // entry j belongs to read number every * (first_mark + j + 1)
 };
 
 // t1/t2: plain FASTQ texts in host memory (t2 may be null).  Returns 0 = packed on the device,
 // 1 = input is not regular 4-line FASTQ (the caller runs the host parser, which owns the error
 // messages and the blank-line rules), < 0 = error (-4 memory, -5 HIP, -1 too large).
+// read_base: records that came before this text (earlier pieces of the same input) — progress marks
+// stay at global multiples of `every`.
 int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, uint32_t k, uint32_t min_qual,
-                   uint64_t every, void *stream, GpuPacked &out, std::string &err);
+                   uint64_t every, void *stream, GpuPacked &out, std::string &err, uint64_t read_base = 0);
 void gpu_packed_free(GpuPacked &p);
 
 }  // namespace shk

@@ -296,9 +296,10 @@ __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
 
 // byte offset (inside its own file) after record `every*(j+1)` for the progress strings; bit 63 = second file
 __global__ __launch_bounds__(256) void k_progress_marks(const unsigned long long *__restrict__ line_end, FqParams fp,
-                                                        uint64_t every, uint64_t n_marks, unsigned long long *__restrict__ marks) {
+                                                        uint64_t every, uint64_t n_marks, unsigned long long *__restrict__ marks,
+                                                        uint64_t first_mark, uint64_t read_base) {
     for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_marks; j += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t r = every * (j + 1) - 1;                  // last record of the batch
+        const uint64_t r = every * (first_mark + j + 1) - 1 - read_base;   // last record of the batch (read_base records came in earlier pieces)
         const uint64_t line = 4 * r + 3;
         uint64_t p = line < fp.n_nl ? line_end[line] + 1 : fp.n;
         if (r < fp.part1_reads) marks[j] = p < fp.part1_len ? p : fp.part1_len;
@@ -329,7 +330,7 @@ static size_t trimmed_len(const uint8_t *t, size_t n) {
 }
 
 int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, uint32_t k, uint32_t min_qual,
-                   uint64_t every, void *stream_v, GpuPacked &out, std::string &err) {
+                   uint64_t every, void *stream_v, GpuPacked &out, std::string &err, uint64_t read_base) {
     hipStream_t st = (hipStream_t)stream_v;
     out = GpuPacked();
     Scratch sc;
@@ -411,11 +412,13 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     FQCHK(hipGetLastError());
     // progress marks
     if (every) {
-        const uint64_t n_marks = n_reads / every;
+        const uint64_t first_mark = read_base / every;
+        const uint64_t n_marks = (read_base + n_reads) / every - first_mark;
+        out.first_mark = first_mark;
         if (n_marks) {
             unsigned long long *marks = sc.get<unsigned long long>(n_marks, err);
             if (!marks) return -4;
-            hipLaunchKernelGGL(k_progress_marks, dim3(grid1(n_marks)), dim3(256), 0, st, line_end, fp, every, n_marks, marks);
+            hipLaunchKernelGGL(k_progress_marks, dim3(grid1(n_marks)), dim3(256), 0, st, line_end, fp, every, n_marks, marks, first_mark, read_base);
             out.progress_bytes.resize(n_marks);
             FQCHK(hipMemcpyAsync(out.progress_bytes.data(), marks, n_marks * 8, hipMemcpyDeviceToHost, st));
         }

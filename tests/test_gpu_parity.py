@@ -446,6 +446,55 @@ def test_several_batches_per_handle():
     assert c.total_instances == o2.total_instances
 
 
+def test_device_parser_takes_large_texts_in_pieces():
+    """A text of more than one batch is cut at record boundaries and every piece goes through the device
+    parser as its own batch.  Counts, progress strings (read numbers at global multiples, percentages of the
+    whole input), results and error messages equal the host parser's."""
+    g, fq = make_dataset(60000, 30, err=0.01, seed=78)
+    # qualities starting with '@' now and then: a quality line must not be taken for a header at a cut
+    recs = fq.decode().split("\n")
+    for i in range(3, len(recs), 4 * 7):
+        recs[i] = "@" + recs[i][1:]
+    fq = "\n".join(recs).encode()
+    ref = product(fq, k=31, min_count=2, min_qual=0)
+    compare_all(ref, run_oracle([fq], k=31, min_count=2, min_qual=0))
+    env = {"SHK_BATCH_BASES": 150000}                    # ~300 kB of text per piece: a dozen pieces
+    a = _with_env(env, lambda: product(fq, k=31, min_count=2, min_qual=0, csize=500))
+    ta = a.timings()
+    assert ta.get("fastq_device_pieces_x1", 0) >= 8 and ta.get("batch_pack_kernel", 0) > 0
+    b = _with_env({**env, "SHK_HOST_PARSER": 1}, lambda: product(fq, k=31, min_count=2, min_qual=0, csize=500))
+    assert "fastq_device_pieces_x1" not in b.timings()
+    assert a.states == b.states
+    assert a.get_assembly() == b.get_assembly() == _with_env({}, lambda: product(fq, k=31, min_count=2, min_qual=0, csize=500)).get_assembly()
+    assert a.get_preprocessing_info() == b.get_preprocessing_info() and a.total_instances == b.total_instances
+    # two files, the second one gzip; k = 51
+    cut = fq.rfind(b"\n@r", 0, len(fq) // 3) + 1
+    f1, f2 = fq[:cut], gzip.compress(fq[cut:])
+    c = _with_env(env, lambda: product(f1, f2, k=51, min_count=1, csize=700))
+    d = _with_env({**env, "SHK_HOST_PARSER": 1}, lambda: product(f1, f2, k=51, min_count=1, csize=700))
+    assert c.timings().get("fastq_device_pieces_x1", 0) >= 8
+    assert c.states == d.states and c.get_assembly() == d.get_assembly()
+    compare_all(c, run_oracle([f1, f2], k=51, min_count=1))
+    # a malformed record deep inside: same message from both; blank lines in a later piece: host takes over there
+    lines = fq.split(b"\n")
+    bad = list(lines)
+    bad[4 * 5000 + 2] = b"-"                             # the '+' line of record 5000
+    bad = b"\n".join(bad)
+    msgs = []
+    for e in (env, {**env, "SHK_HOST_PARSER": 1}):
+        with pytest.raises(Exception) as ei:
+            _with_env(e, lambda: product(bad, k=31, min_count=2))
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1] and "5000" in msgs[0]
+    gap = list(lines)
+    gap.insert(4 * 9000, b"")                            # a blank line between two records
+    gap = b"\n".join(gap)
+    e1 = _with_env(env, lambda: product(gap, k=31, min_count=2, min_qual=0, csize=500))
+    e2 = _with_env({**env, "SHK_HOST_PARSER": 1}, lambda: product(gap, k=31, min_count=2, min_qual=0, csize=500))
+    assert e1.timings().get("fastq_device_pieces_x1", 0) >= 1 and e1.timings().get("fastq_parse_pack_host_clock", 0) == 0
+    assert e1.states == e2.states and e1.get_assembly() == e2.get_assembly() == ref.get_assembly()
+
+
 def test_long_reads_are_split_into_overlapping_segments():
     """A 60 kbp read (longer than a kernel segment) goes through the host packer, which cuts it into
     pieces overlapping by k-1 bases: every k-mer is counted exactly once."""

@@ -12,8 +12,13 @@ fq = synth.to_fastq_fixed(codes, quals)
 nb = codes.size
 print("FASTQ bytes %.2f GB, bases %.0f M" % (len(fq) / 1e9, nb / 1e6), flush=True)
 del codes, quals
-for name, env in (("device parser", "0"), ("host parser", "1")):
+for name, env, bb in (("device parser", "0", None), ("device, pieces", "0", str(1 << 27)), ("host parser", "1", None)):
+    if os.environ.get("SKIP_HOST") == "1" and env == "1":
+        continue
     os.environ["SHK_HOST_PARSER"] = env
+    os.environ.pop("SHK_BATCH_BASES", None)
+    if bb:
+        os.environ["SHK_BATCH_BASES"] = bb               # 256 MB of text per piece
     for it in range(2 if env == "0" else 1):
         h = AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
         t0 = time.perf_counter(); h.preprocess(fq); dt = time.perf_counter() - t0
