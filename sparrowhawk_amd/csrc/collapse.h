@@ -114,14 +114,21 @@ __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ se
         if (r.next_spl != NIL) { P[r.next_spl] = s; A[r.next_spl] = r.len; K[r.next_spl] = r.sum; }
     }
 }
+// one launch follows HOPS pointers (the reach grows HOPS-fold per launch instead of doubling: a launch
+// over ~300 k splitters is all latency, so ceil(log4 n) launches of four dependent reads beat
+// ceil(log2 n) launches of two); heads point to themselves with A = K = 0, so overshooting adds nothing
+static constexpr int RANK_HOPS = 4;
 __global__ __launch_bounds__(256) void k_rank_jump(uint32_t n_spl, const uint32_t *__restrict__ Pi,
                                                    const uint32_t *__restrict__ Ai,
                                                    const unsigned long long *__restrict__ Ki,
                                                    uint32_t *__restrict__ Po, uint32_t *__restrict__ Ao,
                                                    unsigned long long *__restrict__ Ko) {
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
-        const uint32_t p = Pi[s];
-        Po[s] = Pi[p]; Ao[s] = Ai[s] + Ai[p]; Ko[s] = Ki[s] + Ki[p];
+        uint32_t p = s, a = 0;
+        unsigned long long kc = 0;
+#pragma unroll
+        for (int h = 0; h < RANK_HOPS; h++) { a += Ai[p]; kc += Ki[p]; p = Pi[p]; }
+        Po[s] = p; Ao[s] = a; Ko[s] = kc;
     }
 }
 struct HeadRec { uint32_t spl, head_node, tail_node, emit; unsigned long long len, kc; };

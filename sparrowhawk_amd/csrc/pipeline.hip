@@ -215,6 +215,24 @@ struct EvTimer {
         return ms;
     }
     ~EvTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+    // stop without waiting: the pair of events goes on `pending` and is read when the timings are asked for
+    // (a hipEventSynchronize between two phases that have nothing to wait for costs a pipeline bubble)
+    struct Pending { std::string name; hipEvent_t a, b; };
+    void stop_later(const char *name, std::vector<Pending> &pending) {
+        if (!ok) return;
+        (void)hipEventRecord(b, st);
+        pending.push_back(Pending{name, a, b});
+        ok = false;                                      // the events now belong to the list
+    }
+    static void resolve(std::vector<Pending> &pending, StageTimes &times) {
+        for (auto &p : pending) {
+            (void)hipEventSynchronize(p.b);
+            float ms = 0; (void)hipEventElapsedTime(&ms, p.a, p.b);
+            times.add(p.name, ms);
+            (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
+        }
+        pending.clear();
+    }
 };
 
 static inline uint64_t env_u64(const char *name, uint64_t dflt) {
@@ -228,7 +246,7 @@ static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
 template <int W> class Pipeline : public IPipeline {
 public:
     explicit Pipeline(int k) : k_(k) {}
-    ~Pipeline() override { if (stream_) stream_pool_put(stream_dev_, stream_); }
+    ~Pipeline() override { EvTimer::resolve(pending_timers_, times_); if (stream_) stream_pool_put(stream_dev_, stream_); }
     int init(std::string &err) {
         HIPCHK(hipGetDevice(&stream_dev_));
         stream_ = stream_pool_get(stream_dev_);
@@ -236,7 +254,7 @@ public:
         HIPCHK(ctl_.alloc(16, err) ? hipErrorOutOfMemory : hipSuccess);
         return 0;
     }
-    StageTimes &times() override { return times_; }
+    StageTimes &times() override { EvTimer::resolve(pending_timers_, times_); return times_; }
     void *stream() override { return (void *)stream_; }
     uint64_t total_instances() const override { return total_instances_; }
     uint64_t n_distinct() const override { return n_distinct_; }
@@ -833,14 +851,14 @@ public:
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
             HIPCHK(hipGetLastError());
-            times_.add("graph_table_kernel", t.stop());
+            t.stop_later("graph_table_kernel", pending_timers_);
             EvTimer t2(stream_);
             hipLaunchKernelGGL(k_graph_local<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
                                adj_.p, nb_.p, queries.p, gp_cnt.p, (uint32_t *)(ctl_.p + 1));
             hipLaunchKernelGGL(k_graph_remote<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, queries.p,
                                gp_cnt.p, adj_.p, nb_.p);
             HIPCHK(hipGetLastError());
-            times_.add("adjacency_kernel", t2.stop());
+            t2.stop_later("adjacency_kernel", pending_timers_);
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
             unsigned long long h[3];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -969,7 +987,7 @@ public:
             hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
                                spl.p, n_spl, ol.p, segs.p, split_mask);
             HIPCHK(hipGetLastError());
-            times_.add("collapse_walk", t2.stop());
+            t2.stop_later("collapse_walk", pending_timers_);
         }
         // ---- rank the splitter list on the device: prefix of segment lengths by pointer jumping
         DevBuf<uint32_t> Pa, Pb, Aa, Ab, slot_of; DevBuf<unsigned long long> Ka, Kb, d_off; DevBuf<HeadRec> d_heads;
@@ -996,7 +1014,7 @@ public:
             const int gr = grid_for(n_spl);
             hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, n_spl, Pa.p, Aa.p, Ka.p);
             uint32_t *Pi = Pa.p, *Po = Pb.p, *Ai = Aa.p, *Ao = Ab.p; unsigned long long *Ki = Ka.p, *Ko = Kb.p;
-            int rounds = 1; while ((1ull << rounds) < (uint64_t)n_spl) rounds++;
+            int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl) { reach *= RANK_HOPS; rounds++; } }
             for (int r = 0; r < rounds; r++) {
                 hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, n_spl, Pi, Ai, Ki, Po, Ao, Ko);
                 std::swap(Pi, Po); std::swap(Ai, Ao); std::swap(Ki, Ko);
@@ -1114,6 +1132,7 @@ private:
     int k_;
     hipStream_t stream_ = nullptr; int stream_dev_ = 0;
     StageTimes times_;
+    std::vector<EvTimer::Pending> pending_timers_;
     DevBuf<unsigned long long> ctl_;
     // count table
     DevBuf<uint64_t> tkeys_[W]; DevBuf<uint32_t> tcnt_, tstate_; uint64_t tslots_ = 0;
