@@ -376,15 +376,17 @@ template <int W> struct CountShared : KmerTable<W> {
     RecTable<W, (W == 1 ? 4096u : ((71680u / (16u * W + 6u)) & ~63u))> rt;   // 4096 / 1856 / 1280 / 1024 records
 };
 
-struct CountCtl {
-    uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
-    unsigned long long roff[256];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
+struct CountCtlCore {                                   // what the table, the emit and the residue rounds need
     uint32_t histo[500];
     uint32_t n_used, overflow, n_emit, emit_base_lo, emit_base_hi, sp, wave_cursor, rec_used, n_recs;
     // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
     uint32_t st_res[16], st_step[16], st_factor[16], st_next[16];
     uint32_t prog_num, prog_den;                        // how far the round got when the table filled up
     unsigned long long n_inst, tried;
+};
+struct CountCtl : CountCtlCore {                        // + the run table of a partition (k_count_partitions)
+    uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
+    unsigned long long roff[256];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
 };
 
 // Table placement hash: add/shift/xor only (Jenkins one-at-a-time finaliser); integer multiplies
@@ -406,7 +408,7 @@ template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) 
 // insert into the LDS table; returns false when the probe sequence is exhausted
 // (COUNT_USED = false: the caller keeps ctl.n_used itself from the return value 2 = "new key")
 template <int W, bool COUNT_USED = true>
-__device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtl &ctl, const Kmer<W> &key, uint32_t h,
+__device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtlCore &ctl, const Kmer<W> &key, uint32_t h,
                                           uint32_t weight) {
     constexpr uint32_t S = KmerTable<W>::S;
     if constexpr (W == 1) {
@@ -465,7 +467,7 @@ __device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtl &ctl, const
 
 // phase A: count a whole record; false = table saturated (the caller then expands it directly)
 template <int W, typename RT>
-__device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * W> &rec) {
+__device__ __forceinline__ bool rec_insert(RT &rt, CountCtlCore &ctl, const Rec<2 * W> &rec) {
     constexpr uint32_t SR = RT::SR;
     uint32_t h = 0x9E3779B9u;
 #pragma unroll
@@ -502,7 +504,7 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtl &ctl, const Rec<2 * 
 }
 
 // empty table, zero round-local histogram (all threads; ends with a barrier)
-template <int W> __device__ __forceinline__ void kmer_table_reset(KmerTable<W> &tb, CountCtl &ctl) {
+template <int W> __device__ __forceinline__ void kmer_table_reset(KmerTable<W> &tb, CountCtlCore &ctl) {
     constexpr uint32_t S = KmerTable<W>::S;
     for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
         tb.cnt[s] = 0;
@@ -521,10 +523,11 @@ template <int W> __device__ __forceinline__ void table_reset(CountShared<W> &tb,
 // for S slot numbers); then one global atomic reserves the rows and they are written densely — one
 // store instruction per 64 rows and array, whatever the density of solid rows in the table.
 template <int W, typename LT>
-__device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtl &ctl, unsigned long long mine, uint32_t threshold,
+__device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtlCore &ctl, unsigned long long mine, uint32_t threshold,
                                            unsigned long long *__restrict__ histo, KeyArr<W> out_keys,
                                            uint32_t *__restrict__ out_cnt, unsigned long long out_cap,
-                                           unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg = 0) {
+                                           unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg = 0,
+                                           uint32_t *hist_accum = nullptr /* LDS: the round's histogram is added here instead of to `histo` */) {
     constexpr uint32_t S = KmerTable<W>::S;
     const int lane = threadIdx.x & 63;
     if (dbg == 10) return;                                  // (timing experiments 10, 11, 4: stop after successive stages)
@@ -552,9 +555,12 @@ __device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtl &ctl, unsi
         unsigned long long base = (n_emit && dbg != 5) ? atomicAdd(out_cursor, (unsigned long long)n_emit) : 0ull;
         ctl.emit_base_lo = (uint32_t)base; ctl.emit_base_hi = (uint32_t)(base >> 32);
     }
-    if (dbg != 1)                                           // (timing experiment: no global histogram flush)
-    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
-        if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
+    if (hist_accum) {                                       // (thread b owns bin b: no atomics)
+        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) hist_accum[b] += ctl.histo[b];
+    } else if (dbg != 1) {                                  // (dbg 1: timing experiment, no global histogram flush)
+        for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+            if (ctl.histo[b]) atomicAdd(&histo[b], (unsigned long long)ctl.histo[b]);
+    }
     if (!n_emit || dbg == 4) return;                        // (uniform)
     __syncthreads();
     const unsigned long long gbase = ((unsigned long long)ctl.emit_base_hi << 32) | ctl.emit_base_lo;
@@ -989,89 +995,168 @@ __global__ __launch_bounds__(256) void k_ovf_check(const OvfItem *__restrict__ i
     }
 }
 
-// counts one bucket of canonical k-mers (one entry of the work list per workgroup); the same table, the
-// same emit and — should a bucket still not fit — the same residue-class splitting as k_count_partitions
+// Counts the buckets of the work list: PERSISTENT workgroups (two per CU, each needs only the k-mer table),
+// workgroup g takes entries g, g + G, g + 2G, ...  A bucket is ~3-9 k-mers per thread of work between fixed
+// latencies (launch, list entry -> k-mers, barriers, the row reservation's round trip), so the loop is
+// software-pipelined: the k-mers of bucket i+1 are loaded into registers before bucket i is counted, the
+// list entry of bucket i+2 before that, and the histogram stays in LDS until the workgroup is done.  The
+// same table, the same emit and — should a bucket still not fit — the same residue-class splitting (then
+// read from memory again) as k_count_partitions.
 template <int W>
-__global__ __launch_bounds__(COUNT_THREADS) void k_count_buckets(
-    const BucketRef *__restrict__ list, const uint64_t *__restrict__ kmers,
+__global__ __launch_bounds__(COUNT_THREADS, 8) void k_count_buckets(   // 8 waves per SIMD: two workgroups per CU, <= 64 VGPRs
+    const BucketRef *__restrict__ list, uint32_t n_list, const uint64_t *__restrict__ kmers,
     uint32_t threshold, unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
     unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg /* timing experiments (SHK_DEBUG_B) */) {
     constexpr uint32_t S = KmerTable<W>::S;
-    __shared__ KmerTable<W> tb;                         // ~half the LDS: two workgroups per CU overlap their fixed latencies
-    __shared__ CountCtl ctl;
+    // k-mers per thread that travel in registers: covers the bucket size the host aims for (<= 1.1 S, binomial
+    // spread of a few per cent); the rare longer bucket is read from memory by the residue path below
+    constexpr int PF = (int)((S * 114u / 100u + COUNT_THREADS - 1) / COUNT_THREADS);
+    constexpr uint32_t PF_MAX = (uint32_t)PF * COUNT_THREADS;
+    __shared__ KmerTable<W> tb;
+    __shared__ CountCtlCore ctl;
     constexpr uint32_t ELIST = W == 1 ? S : 64;         // emit list: W >= 2 reuses the state words
     __shared__ uint16_t elist[ELIST];
-    const BucketRef ref = list[blockIdx.x];
-    const uint32_t nb = ref.nb;
-    const uint64_t *src = kmers + ref.first * W;
+    __shared__ uint32_t whist[500];                     // this workgroup's histogram over all its buckets
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x == 0) {
-        ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0; ctl.n_inst = 0;
-    }
-    while (true) {
-        __syncthreads();
-        if (ctl.sp == 0) break;
-        const uint32_t top = ctl.sp - 1;
-        const uint32_t res = ctl.st_res[top] + ctl.st_next[top] * ctl.st_step[top], mod = ctl.st_step[top] * ctl.st_factor[top];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (++ctl.st_next[top] == ctl.st_factor[top]) ctl.sp--;
-            ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
-            ctl.prog_num = 0; ctl.prog_den = nb;
-        }
-        kmer_table_reset<W>(tb, ctl);
-        unsigned long long mine = 0;
-        // the k-mer of the next iteration is requested before the current one is inserted
-        auto fetch = [&](uint32_t i, Kmer<W> &c) {
-            if (i < nb) {
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) whist[b] = 0;
+    if (threadIdx.x == 0) ctl.n_inst = 0;
+    auto load_ref = [&](uint32_t e) -> BucketRef {
+        BucketRef r; r.first = 0; r.nb = 0; r.pad = 0;
+        if (e < n_list) r = list[e];
+        return r;
+    };
+    auto fetch_all = [&](const BucketRef &r, Kmer<W> (&d)[PF]) {
+        const uint64_t *src = kmers + r.first * W;
 #pragma unroll
-                for (int j = 0; j < W; j++) c.w[j] = src[(uint64_t)i * W + j];
+        for (int u = 0; u < PF; u++) {
+            // (uniform base per u + one 32-bit lane offset for all loads: no 64-bit address registers per load)
+            const uint64_t *src_u = src + (uint64_t)u * COUNT_THREADS * W;
+            const uint32_t i = (uint32_t)u * COUNT_THREADS + threadIdx.x;
+            if (i < r.nb) {
+#pragma unroll
+                for (int j = 0; j < W; j++) d[u].w[j] = src_u[threadIdx.x * (uint32_t)W + (uint32_t)j];
             }
-        };
-        Kmer<W> nxt = km_zero<W>();
-        fetch(threadIdx.x, nxt);
-        for (uint32_t i0 = 0; i0 < nb; i0 += COUNT_THREADS) {
-            if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i0 + 1u); break; }
-            const uint32_t i = i0 + threadIdx.x;
-            const Kmer<W> c = nxt;
-            fetch(i + COUNT_THREADS, nxt);
-            bool fresh = false;
-            if (i < nb && dbg != 3) {
-                const uint32_t h = km_mix32<W>(c);
-                if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {
-                    const int r = lds_insert<W, false>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u);
-                    if (!r) ctl.overflow = 1;
-                    fresh = r == 2;
-                    mine++;
-                }
-            }
-            if (dbg == 3 && i < nb && c.w[0] == 0x123456789ull) ctl.overflow = 1;
-            // most k-mers of an error-rich bucket are new keys: one LDS atomic per wave for the fill level
-            const unsigned long long fm = __ballot(fresh);
-            if (lane == 0 && fm) atomicAdd(&ctl.n_used, (uint32_t)__popcll(fm));
         }
-        if (dbg == 2 || dbg == 3) return;                   // timing experiments: no emit
+    };
+    auto emit = [&](unsigned long long mine) {
+        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, dbg, whist);
+        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, dbg, whist);   // (the state words are not read after counting)
+    };
+    uint32_t e = blockIdx.x;
+    BucketRef ref = load_ref(e), ref_n = load_ref(e + gridDim.x);
+    Kmer<W> kv[PF];                                      // (one buffer: two would cost the second workgroup per CU its registers)
+#pragma unroll
+    for (int u = 0; u < PF; u++) kv[u] = km_zero<W>();
+    if (ref.nb <= PF_MAX) fetch_all(ref, kv);
+    for (; e < n_list; e += gridDim.x) {
+        const BucketRef cur = ref;
+        ref = ref_n; ref_n = load_ref(e + 2u * gridDim.x);
+        const uint32_t nb = cur.nb;
+        bool done = false;
+        if (nb <= PF_MAX) {
+            // ---- the common case: the bucket fits the table, its k-mers are in registers
+            __syncthreads();                                             // the previous bucket's rows are out
+            if (threadIdx.x == 0) {
+                ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
+                ctl.prog_num = 0; ctl.prog_den = nb;
+            }
+            kmer_table_reset<W>(tb, ctl);
+            unsigned long long mine = 0;
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                if ((uint32_t)u * COUNT_THREADS < nb && !(ctl.overflow || ctl.n_used > (S / 10) * 9)) {   // (whole waves: uniform enough for the ballot)
+                    const uint32_t i = (uint32_t)u * COUNT_THREADS + threadIdx.x;
+                    bool fresh = false;
+                    if (i < nb && dbg != 3) {
+                        const uint32_t h = km_mix32<W>(kv[u]);
+                        const int r = lds_insert<W, false>(tb, ctl, kv[u], h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u);
+                        if (!r) ctl.overflow = 1;
+                        fresh = r == 2;
+                        mine++;
+                    }
+                    if (dbg == 3 && i < nb && kv[u].w[0] == 0x123456789ull) ctl.overflow = 1;
+                    // most k-mers of an error-rich bucket are new keys: one LDS atomic per wave for the fill level
+                    const unsigned long long fm = __ballot(fresh);
+                    if (lane == 0 && fm) atomicAdd(&ctl.n_used, (uint32_t)__popcll(fm));
+                }
+                __builtin_amdgcn_sched_barrier(0);                       // one insert at a time: no hoisting of all PF hashes (registers)
+            }
+            // the registers are free again: the next bucket's k-mers travel while this one is scanned,
+            // its rows reserved and written
+            if (ref.nb && ref.nb <= PF_MAX) fetch_all(ref, kv);
+            if (dbg == 2 || dbg == 3) continue;                          // timing experiments: no emit
+            __syncthreads();
+            if (!(ctl.overflow != 0 || ctl.n_used > (S / 10) * 9)) { emit(mine); done = true; }
+        } else if (ref.nb && ref.nb <= PF_MAX) fetch_all(ref, kv);
+        if (done) continue;
+        // ---- a bucket that does not fit (or is longer than the registers hold): residue classes of the key
+        // hash, every round reads the bucket from memory again
+        const uint64_t *src = kmers + cur.first * W;
         __syncthreads();
-        const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
-        if (over) {
-            if (threadIdx.x == 0) atomicAdd(&flags[1], 1u);      // (statistic: buckets split by residue class)
-            if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
+        if (threadIdx.x == 0) { ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0; }
+        while (true) {
+            __syncthreads();
+            if (ctl.sp == 0) break;
+            const uint32_t top = ctl.sp - 1;
+            const uint32_t res = ctl.st_res[top] + ctl.st_next[top] * ctl.st_step[top], mod = ctl.st_step[top] * ctl.st_factor[top];
             __syncthreads();
             if (threadIdx.x == 0) {
-                const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
-                const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
-                uint32_t factor = 2;
-                while ((double)factor * (0.6 * S) < est && mod * factor < 4096u) factor <<= 1;
-                ctl.st_res[ctl.sp] = res; ctl.st_step[ctl.sp] = mod; ctl.st_factor[ctl.sp] = factor; ctl.st_next[ctl.sp] = 0;
-                ctl.sp += 1;
+                if (++ctl.st_next[top] == ctl.st_factor[top]) ctl.sp--;
+                ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
+                ctl.prog_num = 0; ctl.prog_den = nb;
             }
-            continue;
+            kmer_table_reset<W>(tb, ctl);
+            unsigned long long mine = 0;
+            auto fetch = [&](uint32_t i, Kmer<W> &c) {
+                if (i < nb) {
+#pragma unroll
+                    for (int j = 0; j < W; j++) c.w[j] = src[(uint64_t)i * W + j];
+                }
+            };
+            Kmer<W> nxt = km_zero<W>();
+            fetch(threadIdx.x, nxt);
+            for (uint32_t i0 = 0; i0 < nb; i0 += COUNT_THREADS) {
+                if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i0 + 1u); break; }
+                const uint32_t i = i0 + threadIdx.x;
+                const Kmer<W> c = nxt;
+                fetch(i + COUNT_THREADS, nxt);
+                bool fresh = false;
+                if (i < nb) {
+                    const uint32_t h = km_mix32<W>(c);
+                    if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {
+                        const int r = lds_insert<W, false>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), 1u);
+                        if (!r) ctl.overflow = 1;
+                        fresh = r == 2;
+                        mine++;
+                    }
+                }
+                const unsigned long long fm = __ballot(fresh);
+                if (lane == 0 && fm) atomicAdd(&ctl.n_used, (uint32_t)__popcll(fm));
+            }
+            __syncthreads();
+            const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
+            if (over) {
+                if (threadIdx.x == 0) atomicAdd(&flags[1], 1u);      // (statistic: bucket rounds split by residue class)
+                if (mod >= 4096 || ctl.sp + 1 > 16) { if (threadIdx.x == 0) flags[0] = 1; break; }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const uint32_t num = ctl.prog_num ? ctl.prog_num : ctl.prog_den;
+                    const double est = (double)ctl.n_used * (double)ctl.prog_den / (double)num;
+                    uint32_t factor = 2;
+                    while ((double)factor * (0.6 * S) < est && mod * factor < 4096u) factor <<= 1;
+                    ctl.st_res[ctl.sp] = res; ctl.st_step[ctl.sp] = mod; ctl.st_factor[ctl.sp] = factor; ctl.st_next[ctl.sp] = 0;
+                    ctl.sp += 1;
+                }
+                continue;
+            }
+            emit(mine);
         }
-        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, dbg);
-        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, dbg);   // (the state words are not read after counting)
     }
     __syncthreads();
+    if (dbg != 1)
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+        if (whist[b]) atomicAdd(&histo[b], (unsigned long long)whist[b]);
     if (threadIdx.x == 0 && ctl.n_inst && dbg != 8) atomicAdd(n_inst, ctl.n_inst);
 }
 

@@ -249,6 +249,7 @@ public:
     ~Pipeline() override { EvTimer::resolve(pending_timers_, times_); if (stream_) stream_pool_put(stream_dev_, stream_); }
     int init(std::string &err) {
         HIPCHK(hipGetDevice(&stream_dev_));
+        { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, stream_dev_); n_cus_ = cus > 0 ? cus : 256; }
         stream_ = stream_pool_get(stream_dev_);
         if (!stream_) HIPCHK(hipStreamCreate(&stream_));
         HIPCHK(ctl_.alloc(16, err) ? hipErrorOutOfMemory : hipSuccess);
@@ -538,8 +539,10 @@ public:
                         } else bad.push_back(items[i].p);
                     }
                     if ((uint32_t)n_list) {
-                        hipLaunchKernelGGL(k_count_buckets<W>, dim3((uint32_t)n_list), dim3(COUNT_THREADS), 0, stream_,
-                                           d_blist.p, d_kmers.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                        // persistent workgroups, two per CU (the k-mer table is half the LDS)
+                        const uint32_t bgrid = (uint32_t)std::min<unsigned long long>(n_list, 2ull * (unsigned long long)n_cus_);
+                        hipLaunchKernelGGL(k_count_buckets<W>, dim3(bgrid), dim3(COUNT_THREADS), 0, stream_,
+                                           d_blist.p, (uint32_t)n_list, d_kmers.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
                                            ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), (uint32_t)env_u64("SHK_DEBUG_B", 0));
                         HIPCHK(hipGetLastError());
                         HIPCHK(hipStreamSynchronize(stream_));      // d_items / d_kmers are reused by the next pass
@@ -1133,6 +1136,7 @@ private:
     hipStream_t stream_ = nullptr; int stream_dev_ = 0;
     StageTimes times_;
     std::vector<EvTimer::Pending> pending_timers_;
+    int n_cus_ = 256;
     DevBuf<unsigned long long> ctl_;
     // count table
     DevBuf<uint64_t> tkeys_[W]; DevBuf<uint32_t> tcnt_, tstate_; uint64_t tslots_ = 0;

@@ -65,7 +65,10 @@ for case in range(n_cases):
     env = {}
     if rng.random() < 0.3: env["SHK_HOST_PARSER"] = "1"
     if rng.random() < 0.2: env["SHK_BATCH_BASES"] = str(int(rng.integers(2000, 200000)))
-    if rng.random() < 0.2: env["SHK_PART_P"] = str(int(rng.choice([64, 256, 16384])))
+    if rng.random() < 0.3: env["SHK_PART_P"] = str(int(rng.choice([2, 8, 64, 256, 16384])))   # few partitions: LDS tables overflow
+    if rng.random() < 0.15: env["SHK_PROBE_PARTS"] = str(int(rng.choice([0, 1, 4])))
+    if rng.random() < 0.1: env["SHK_OVF_CAP_PCT"] = "60"            # bucket regions overflow: re-scatter / residue classes
+    if rng.random() < 0.1: env["SHK_NO_REPARTITION"] = "1"
     old = {e: os.environ.get(e) for e in env}
     os.environ.update(env)
     desc = dict(case=case, k=k, glen=glen, rl=rl, cov=cov, err=err, circ=circular, mc=min_count, mq=min_qual, fit=do_fit,
