@@ -173,6 +173,7 @@ struct FqParams {
     uint64_t n_lines;      // '\n' count (+1 if the text does not end with one)
     uint64_t n_nl;         // '\n' count
     uint32_t k, min_qual;
+    uint32_t dbg;          // timing experiments only (SHK_DEBUG_FQ)
 };
 
 __device__ __forceinline__ uint32_t base_code(uint8_t c) {
@@ -207,8 +208,9 @@ __global__ __launch_bounds__(256) void k_read_wave(const uint8_t *__restrict__ t
                                                    const unsigned long long *__restrict__ line_end, FqParams fp,
                                                    uint64_t n_reads, unsigned long long *__restrict__ seg_cnt,
                                                    unsigned long long *__restrict__ base_cnt,
-                                                   unsigned long long *__restrict__ stats /* [0]=bad flag [1]=input bases */,
-                                                   uint32_t *__restrict__ seg_off, uint32_t *__restrict__ out) {
+                                                   unsigned long long *__restrict__ stats /* [0]=bad flag [6..70)=input bases, partial sums */,
+                                                   uint32_t *__restrict__ seg_off, uint32_t *__restrict__ out,
+                                                   uint2 *__restrict__ edge /* mode 1: per segment {head, tail} partial words */) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -226,53 +228,122 @@ __global__ __launch_bounds__(256) void k_read_wave(const uint8_t *__restrict__ t
             ls[i] = __shfl(le, i) + 1ull;                        // (~0 + 1 = 0 for the first line)
             e_[i] = __shfl(le, i + 1);
         }
+        // Everything that depends only on the line ends is requested in ONE round of loads: the last byte of
+        // every line (a trailing '\r'), the first bytes of the header and '+' lines, the counts of pass 0
+        // (mode 1) and — for records of up to 64*NP bases, i.e. every short read — all sequence and quality
+        // bytes (a '\r' that gets cut off afterwards is no valid base anyway).  The record then costs two
+        // dependent memory round trips instead of four.
+        constexpr int NP = 4;
+        const uint64_t s1 = ls[1], s3 = ls[3];
+        const uint64_t Lraw = e_[1] - s1;
+        const bool small = Lraw <= 64u * NP;
+        uint32_t last_b = 0, head_b = 0;
+        if (lane < 4) { const uint64_t e = e_[lane], s0 = ls[lane]; if (e > s0) last_b = text[e - 1]; }
+        if (lane == 4 && e_[0] > ls[0]) head_b = text[ls[0]];
+        if (lane == 5 && e_[2] > ls[2]) head_b = text[ls[2]];
+        uint64_t so = 0, bo = 0;
+        if (MODE == 1) { so = seg_cnt[r]; bo = base_cnt[r]; }
+        uint32_t sb[NP], qb[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint64_t i = 64u * p + (uint64_t)lane;
+            sb[p] = 'N'; qb[p] = 0;
+            if (small && i < Lraw) { sb[p] = text[s1 + i]; if (s3 + i < fp.n) qb[p] = text[s3 + i]; }
+        }
         // trailing '\r' of each line
-        uint32_t cr = 0;
-        if (lane < 4) { const uint64_t e = e_[lane], s0 = ls[lane]; cr = (e > s0 && text[e - 1] == '\r') ? 1u : 0u; }
+        const uint32_t cr = (lane < 4 && last_b == '\r') ? 1u : 0u;
 #pragma unroll
         for (int i = 0; i < 4; i++) e_[i] -= (uint64_t)__shfl((int)cr, i);
-        const uint64_t s1 = ls[1], s3 = ls[3];
         const uint64_t L = e_[1] - s1;
         if (MODE == 0) {
-            uint32_t h = 0;
-            if (lane == 0) h = (e_[0] > ls[0] && text[ls[0]] == '@') ? 1u : 0u;
-            if (lane == 2) h = (e_[2] > ls[2] && text[ls[2]] == '+') ? 1u : 0u;
-            const bool ok = __shfl((int)h, 0) && __shfl((int)h, 2) && L == e_[3] - s3;
+            const bool ok = e_[0] > ls[0] && __shfl((int)head_b, 4) == '@' && e_[2] > ls[2] && __shfl((int)head_b, 5) == '+' &&
+                            L == e_[3] - s3;
             if (!ok) { if (lane == 0) { stats[0] = 1; seg_cnt[r] = 0; base_cnt[r] = 0; } continue; }
             if (lane == 0) my_in += L;
         }
-        uint64_t so = 0, bo = 0;
-        if (MODE == 1) { so = seg_cnt[r]; bo = base_cnt[r]; }
         uint64_t run = 0, nseg = 0, nb = 0;                      // wave-uniform
+        // mode 1 packs the 2-bit stream of a short record from the codes it already holds (segmented OR over
+        // the lanes of one output word) instead of gathering 16 bytes per word from memory again
+        unsigned long long m[NP];
+        uint32_t code[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const uint64_t i = 64u * p + (uint64_t)lane;
+            const bool valid = small && i < L && acgt_valid(sb[p]) && (int)qb[p] - 33 >= (int)fp.min_qual;
+            m[p] = __ballot(valid);
+            code[p] = acgt_code(sb[p]);
+        }
         auto close_run = [&](uint64_t end_pos /* text position one past the run */) {
             if (MODE == 0 && run > 16384 && lane == 0) stats[0] = 1;       // very long runs are split by the host parser
             if (run >= fp.k) {
                 if (MODE == 1) {
                     const uint64_t src = end_pos - run, b0 = bo + nb;
                     if (lane == 0) seg_off[so + nseg] = (uint32_t)b0;
-                    // output words [b0/16, (b0+run-1)/16]
-                    const uint64_t w_first = b0 >> 4, w_last = (b0 + run - 1) >> 4;
-                    for (uint64_t w = w_first + (uint64_t)lane; w <= w_last; w += 64) {
-                        const uint64_t lo = w << 4;                               // first stream base of the word
-                        const uint64_t from = lo < b0 ? b0 : lo, to = (lo + 16 < b0 + run) ? lo + 16 : b0 + run;
-                        uint32_t word = 0;
-                        for (uint64_t b = from; b < to; b++) word |= acgt_code(text[src + (b - b0)]) << (2 * (uint32_t)(b - lo));
-                        if (from == lo && to == lo + 16) out[w] = word; else atomicOr(&out[w], word);
+                    if (small) {
+                        const uint32_t ra = (uint32_t)(src - s1), rb = (uint32_t)(end_pos - s1);   // the run inside the record
+                        // a word is written by the lane that holds its last base of the run; the part of a word that a
+                        // piece boundary cuts off travels to the next piece (carry), so only the first and the last
+                        // word of a run — shared with the neighbouring runs — need an atomic
+                        uint32_t carry_wid = 0xFFFFFFFFu, carry_v = 0;                        // (wave-uniform)
+                        // The first and the last word of a run may be shared with the neighbouring runs (other waves).
+                        // They are not written here: their bits go to edge[segment] and k_merge_edges puts the shared
+                        // words together afterwards — atomicOr on them cost 2 ms per GB of text.
+                        const uint32_t hw = (uint32_t)(b0 >> 4), tw = (uint32_t)((b0 + run - 1) >> 4);
+                        const bool head_part = (b0 & 15u) != 0u || (hw == tw && ((b0 + run) & 15u) != 0u);
+                        const bool tail_part = ((b0 + run) & 15u) != 0u && !(hw == tw && head_part);
+                        if (lane == 0) {
+                            if (!head_part) edge[so + nseg].x = 0u;
+                            if (!tail_part) edge[so + nseg].y = 0u;
+                        }
+#pragma unroll
+                        for (int p = 0; p < NP; p++) {
+                            if (ra < 64u * (p + 1) && rb > 64u * p) {                        // (wave-uniform)
+                                const uint32_t i = 64u * p + (uint32_t)lane;
+                                const bool act = i >= ra && i < rb;
+                                const uint64_t q = b0 + (uint64_t)(i - ra);                     // stream position of this lane's base
+                                const uint32_t wid = act ? (uint32_t)(q >> 4) : 0xFFFFFFFEu;
+                                uint32_t v = act ? code[p] << (2u * ((uint32_t)q & 15u)) : 0u;
+                                if (lane == 0 && wid == carry_wid) v |= carry_v;
+#pragma unroll
+                                for (int d = 1; d < 16; d <<= 1) {                              // inclusive OR over the (<= 16, adjacent) lanes of a word
+                                    const uint32_t ov = (uint32_t)__shfl_up((int)v, d), ow = (uint32_t)__shfl_up((int)wid, d);
+                                    if (lane >= d && ow == wid) v |= ov;
+                                }
+                                const bool last = act && ((((uint32_t)q & 15u) == 15u) || i + 1u == rb);   // the word (inside this run) ends here
+                                if (last) {
+                                    const uint64_t w0 = (uint64_t)wid << 4;
+                                    const bool whole = w0 >= b0 && w0 + 16 <= b0 + run;          // all 16 bases belong to this run
+                                    if (whole) out[wid] = v;
+                                    else if (wid == hw && head_part) edge[so + nseg].x = v;
+                                    else edge[so + nseg].y = v;
+                                }
+                                const bool c63 = act && !last;                                  // meaningful in lane 63 only
+                                carry_wid = __builtin_amdgcn_readlane((int)(c63 ? wid : 0xFFFFFFFFu), 63);
+                                carry_v = __builtin_amdgcn_readlane((int)v, 63);
+                            }
+                        }
+                    } else {
+                        if (lane == 0) edge[so + nseg] = make_uint2(0u, 0u);             // (long records keep the atomics below)
+                        // output words [b0/16, (b0+run-1)/16]
+                        const uint64_t w_first = b0 >> 4, w_last = (b0 + run - 1) >> 4;
+                        for (uint64_t w = w_first + (uint64_t)lane; w <= w_last; w += 64) {
+                            const uint64_t lo = w << 4;                               // first stream base of the word
+                            const uint64_t from = lo < b0 ? b0 : lo, to = (lo + 16 < b0 + run) ? lo + 16 : b0 + run;
+                            uint32_t word = 0;
+                            for (uint64_t b = from; b < to; b++) word |= acgt_code(text[src + (b - b0)]) << (2 * (uint32_t)(b - lo));
+                            if (from == lo && to == lo + 16) out[w] = word; else atomicOr(&out[w], word);
+                        }
                     }
                 }
                 nseg++; nb += run;
             }
             run = 0;
         };
-        for (uint64_t p0 = 0; p0 < L; p0 += 64) {
-            const uint64_t i = p0 + (uint64_t)lane;
-            bool valid = false;
-            if (i < L) valid = acgt_valid(text[s1 + i]) && (int)text[s3 + i] - 33 >= (int)fp.min_qual;
-            unsigned long long m = __ballot(valid);
+        auto scan_piece = [&](unsigned long long mm, uint64_t p0) {     // runs inside one 64-base piece (uniform bit scans)
             const uint32_t len = (uint32_t)((L - p0) < 64 ? (L - p0) : 64);
             uint32_t pos = 0;
             while (pos < len) {
-                const unsigned long long rest = m >> pos;
+                const unsigned long long rest = mm >> pos;
                 if (rest & 1ull) {                               // a stretch of valid bases
                     uint32_t ones = (~rest) ? (uint32_t)__ffsll((long long)~rest) - 1u : 64u;
                     if (ones > len - pos) ones = len - pos;
@@ -285,14 +356,48 @@ __global__ __launch_bounds__(256) void k_read_wave(const uint8_t *__restrict__ t
                     pos += zeros;
                 }
             }
+        };
+        if (small) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) if (64u * p < L) scan_piece(m[p], 64u * p);
+        } else {
+            for (uint64_t p0 = 0; p0 < L; p0 += 64) {
+                const uint64_t i = p0 + (uint64_t)lane;
+                bool valid = false;
+                if (i < L) valid = acgt_valid(text[s1 + i]) && (int)text[s3 + i] - 33 >= (int)fp.min_qual;
+                scan_piece(__ballot(valid), p0);
+            }
         }
         close_run(s1 + L);
         if (MODE == 0 && lane == 0) { seg_cnt[r] = nseg; base_cnt[r] = nb; }
     }
-    if (MODE == 0 && lane == 0 && my_in) atomicAdd(&stats[1], my_in);
+    // (one counter would serialise 262 144 same-address atomics: 3.2 ms, the whole cost of this pass; 64 counters)
+    if (MODE == 0 && lane == 0 && my_in) atomicAdd(&stats[6 + (blockIdx.x & 63u)], my_in);
 }
 
 __global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+
+// The words of the packed stream that two or more segments share: the segment that holds the word's first
+// base puts them together from its own tail bits and the head bits of the segments that start inside the word
+// (a segment of >= 15 bases: at most three segments meet in a word).  seg_off[n_seg] = n_bases is set.
+__global__ __launch_bounds__(256) void k_merge_edges(const uint32_t *__restrict__ seg_off, const uint2 *__restrict__ edge,
+                                                     uint64_t n_seg, uint32_t *__restrict__ out) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_seg; j += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t a = seg_off[j], b = seg_off[j + 1];
+        if ((b & 15u) == 0u) continue;                             // the last word is whole
+        const uint32_t w = (b - 1u) >> 4;
+        const uint2 ej = edge[j];
+        uint32_t v;
+        if (a > (w << 4)) {
+            // the segment lies inside one word: it owns it only if that word starts the stream's shared stretch,
+            // i.e. if no earlier segment reaches into it — impossible unless a is the word's first base
+            continue;
+        }
+        v = (a >> 4) == w ? ej.x : ej.y;                           // (a single-word segment keeps all its bits in .x)
+        for (uint64_t m = j + 1; m < n_seg && (seg_off[m] >> 4) == w; m++) v |= edge[m].x;
+        out[w] |= v;                                               // (words of long records were started with atomics)
+    }
+}
 
 // byte offset (inside its own file) after record `every*(j+1)` for the progress strings; bit 63 = second file
 __global__ __launch_bounds__(256) void k_progress_marks(const unsigned long long *__restrict__ line_end, FqParams fp,
@@ -363,15 +468,15 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
 
     const uint64_t n_chunks = (e + NL_CHUNK - 1) / NL_CHUNK;
     unsigned long long *chunk_cnt = sc.get<unsigned long long>(n_chunks, err);
-    unsigned long long *d_tot = sc.get<unsigned long long>(8, err);
+    unsigned long long *d_tot = sc.get<unsigned long long>(8 + 64, err);     // [8..72): partial sums of the input bases
     if (!chunk_cnt || !d_tot) return -4;
-    FQCHK(hipMemsetAsync(d_tot, 0, 64, st));
+    FQCHK(hipMemsetAsync(d_tot, 0, (8 + 64) * 8, st));
     hipLaunchKernelGGL(k_nl_count, dim3((unsigned)n_chunks), dim3(256), 0, st, text, (uint64_t)e, chunk_cnt);
     if (int rc = exclusive_scan(chunk_cnt, n_chunks, d_tot, st, sc, err)) return rc;
     unsigned long long n_nl = 0;
     FQCHK(hipMemcpyAsync(&n_nl, d_tot, 8, hipMemcpyDeviceToHost, st));
     FQCHK(hipStreamSynchronize(st));
-    FqParams fp; fp.n = e; fp.n_nl = n_nl; fp.n_lines = n_nl + (unterminated ? 1 : 0); fp.k = k; fp.min_qual = min_qual;
+    FqParams fp; fp.n = e; fp.n_nl = n_nl; fp.n_lines = n_nl + (unterminated ? 1 : 0); fp.k = k; fp.min_qual = min_qual; { const char *dv = getenv("SHK_DEBUG_FQ"); fp.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
     fp.part2_off = off2; fp.part1_len = e1; fp.part1_reads = 0;
     if (fp.n_lines % 4 != 0) return 1;                    // irregular framing: the host parser decides
     const uint64_t n_reads = fp.n_lines / 4;
@@ -391,24 +496,28 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     unsigned long long *base_cnt = sc.get<unsigned long long>(n_reads, err);
     if (!seg_cnt || !base_cnt) return -4;
     hipLaunchKernelGGL(k_read_wave<0>, dim3(grid1(n_reads * 64)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
-                       d_tot + 2, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                       d_tot + 2, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint2 *)nullptr);
     if (int rc = exclusive_scan(seg_cnt, n_reads, d_tot + 4, st, sc, err)) return rc;
     if (int rc = exclusive_scan(base_cnt, n_reads, d_tot + 5, st, sc, err)) return rc;
-    unsigned long long h[8];
-    FQCHK(hipMemcpyAsync(h, d_tot, 64, hipMemcpyDeviceToHost, st));
+    unsigned long long h[8 + 64];
+    FQCHK(hipMemcpyAsync(h, d_tot, sizeof h, hipMemcpyDeviceToHost, st));
     FQCHK(hipStreamSynchronize(st));
+    h[3] = 0;
+    for (int i = 0; i < 64; i++) h[3] += h[8 + i];
     if (h[2]) return 1;                                   // a malformed record: the host parser reports it
     const uint64_t n_seg = h[4], n_bases = h[5];
     if (n_bases >= 0xFFFFFFF0ull) { err = "input exceeds 2^32 bases per batch"; return -1; }
     const uint64_t n_words = (n_bases >> 4) + 2;          // partial word + one spare word (as PackedReads::finish)
     uint32_t *seg_off = sc.get<uint32_t>(n_seg + 1, err);
     uint32_t *bases = sc.get<uint32_t>(n_words, err);
-    if (!seg_off || !bases) return -4;
+    uint2 *edge = sc.get<uint2>(n_seg + 1, err);
+    if (!seg_off || !bases || !edge) return -4;
     FQCHK(hipMemsetAsync(bases, 0, n_words * 4, st));
     if (n_seg)
         hipLaunchKernelGGL(k_read_wave<1>, dim3(grid1(n_reads * 64)), dim3(256), 0, st, text, line_end, fp, n_reads, seg_cnt, base_cnt,
-                           d_tot + 2, seg_off, bases);
+                           d_tot + 2, seg_off, bases, edge);
     hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, st, seg_off + n_seg, (uint32_t)n_bases);
+    if (n_seg) hipLaunchKernelGGL(k_merge_edges, dim3(grid1(n_seg)), dim3(256), 0, st, seg_off, edge, n_seg, bases);
     FQCHK(hipGetLastError());
     // progress marks
     if (every) {
