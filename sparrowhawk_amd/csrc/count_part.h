@@ -668,11 +668,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     const uint32_t *__restrict__ part_list /* nullable: partitions to process */,
     OvfRec *__restrict__ ovf /* nullable: partitions that do not fit are listed here instead of being split */,
     uint32_t *__restrict__ ovf_n,
-    uint32_t probe_blocks, uint32_t defer_after /* != 0: a workgroup numbered >= probe_blocks (they start in
-                            order, so the first ones act as a sample of the partitions: partition = minimiser hash)
-                            that finds *ovf_n >= defer_after takes the input for error-rich and hands its partition
-                            to the k-mer-level repartition without trying it first.  Only the path taken depends
-                            on the timing, never the counts. */) {
+    uint32_t probe_blocks, uint32_t defer_after /* != 0: workgroups start in order, so the first ones act as a sample
+                            of the partitions (partition = minimiser hash).  ovf_n[1] counts the partitions that were
+                            really tried (low 16 bits) and those of them that overflowed (high 16 bits); a workgroup
+                            numbered >= probe_blocks that finds >= defer_after overflows AND >= 3/4 of the tried ones
+                            overflowed takes the input for error-rich and hands its partition to the k-mer-level
+                            repartition without trying it.  Only the path taken depends on the timing, never the counts. */) {
     constexpr int RW = 2 * W;
     constexpr uint32_t S = CountShared<W>::S;
     __shared__ CountShared<W> tb;
@@ -696,7 +697,13 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         if (threadIdx.x == 0) {
             ctl.pre[S_runs] = run; ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
             ctl.n_inst = 0; ctl.n_used = 0;
-            ctl.overflow = (ovf && defer_after && blockIdx.x >= probe_blocks && __hip_atomic_load(ovf_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= defer_after) ? 1u : 0u;
+            uint32_t force = 0;
+            if (ovf && defer_after && blockIdx.x >= probe_blocks) {
+                const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
+                force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
+            }
+            ctl.overflow = force;
         }
     }
     __syncthreads();
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets): report the
     // estimated number of distinct k-mers (distinct / instance ratio of what was inserted before the table
     // filled up, times all instances) and the exact number of instances
-    auto defer = [&](unsigned long long mine) {
+    auto defer = [&](unsigned long long mine, bool was_tried) {
         if (threadIdx.x == 0) ctl.tried = 0;
         __syncthreads();
         for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
@@ -724,11 +731,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         if (threadIdx.x == 0 && R) {
             const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.n_inst / (double)ctl.tried : (double)ctl.n_inst;
             const uint32_t slot = atomicAdd(ovf_n, 1u);
-            OvfRec o; o.p = p; o.est_distinct = !ctl.tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : (uint32_t)est; o.instances = ctl.n_inst;
+            OvfRec o; o.p = p; o.est_distinct = !was_tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : est < 1.0 ? 1u : (uint32_t)est; o.instances = ctl.n_inst;
             ovf[slot] = o;
         }
+        if (threadIdx.x == 0 && was_tried && defer_after) atomicAdd(&ovf_n[1], 0x10001u);      // tried, and it overflowed
     };
-    if (ctl.overflow) { defer(0ull); return; }            // (uniform: written before the barrier above)
+    if (ctl.overflow) { defer(0ull, false); return; }            // (uniform: written before the barrier above)
 
     while (true) {
         __syncthreads();
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         if (rvw.dbg == 8) return;                           // timing experiment: no defer / emit work at all
         if (over && ovf && mod == 1) {
             if (rvw.dbg == 9) return;                       // timing experiment: overflow detected, nothing reported
-            defer(mine);
+            defer(mine, true);
             return;
         }
         if (over) {
@@ -896,6 +904,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     }
     __syncthreads();
     if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
+    if (threadIdx.x == 0 && ovf && defer_after) atomicAdd(&ovf_n[1], 1u);                          // tried, and it fitted
 }
 
 

@@ -476,7 +476,7 @@ public:
             hipLaunchKernelGGL(k_count_partitions<W>, dim3(n_parts), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
-                               (uint32_t *)(ctl_.p + 3), n_probe + n_probe / 2, n_probe / 2);
+                               (uint32_t *)(ctl_.p + 3), n_probe / 2, n_probe / 8);
             HIPCHK(hipGetLastError());
             ms_out = t.stop();
             unsigned long long h[4];
