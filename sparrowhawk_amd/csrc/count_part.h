@@ -382,7 +382,7 @@ struct CountCtlCore {                                   // what the table, the e
     // pending residue classes of the key hash: entry = classes res + j*step (j = next .. factor-1) modulo step*factor
     uint32_t st_res[16], st_step[16], st_factor[16], st_next[16];
     uint32_t prog_num, prog_den;                        // how far the round got when the table filled up
-    unsigned long long n_inst, tried;
+    unsigned long long n_inst, tried, part_inst;        // (n_inst: over the workgroup's lifetime; part_inst: of the partition being handed over)
 };
 struct CountCtl : CountCtlCore {                        // + the run table of a partition (k_count_partitions)
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256) void k_pack_partition(const uint64_t *__restri
 
 template <int W>
 __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
-    RunView rvw, uint32_t threshold,
+    RunView rvw, uint32_t n_parts, uint32_t threshold,
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
     unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags,
@@ -678,27 +678,49 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     constexpr uint32_t S = CountShared<W>::S;
     __shared__ CountShared<W> tb;
     __shared__ CountCtl ctl;
-    const uint32_t p = part_list ? part_list[blockIdx.x] : blockIdx.x;
+    __shared__ uint32_t whist[500];                     // this workgroup's histogram over all its partitions
+    __shared__ uint32_t wtot[4];
     const int lane = threadIdx.x & 63;
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
-    // exclusive prefix of the run lengths of this partition
-    if (threadIdx.x < 64) {
-        uint32_t run = 0;
-        for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
-            const uint32_t g = g0 + threadIdx.x;
-            uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
-            if (g < S_runs) ctl.roff[g] = rvw.run_addr16[(uint64_t)p * S_runs + g];
-            uint32_t incl = f;
-            for (int o = 1; o < 64; o <<= 1) { uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-            if (g < S_runs) ctl.pre[g] = run + incl - f;
-            run += __shfl(incl, 63);
+    // PERSISTENT workgroups (one per CU: the tables take the whole LDS), workgroup g takes partitions
+    // g, g + G, ...  The run table of the next partition travels in registers while the current one is
+    // counted, the histogram stays in LDS until the workgroup is done: per partition there is no launch,
+    // no wait for the run table and no histogram flush (what 8192 instead of 4096 partitions used to cost).
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) whist[b] = 0;
+    if (threadIdx.x == 0) ctl.n_inst = 0;
+    auto load_runs = [&](uint32_t pi, uint32_t &cnt, unsigned long long &addr) {
+        cnt = 0; addr = 0;
+        if (pi < n_parts && threadIdx.x < S_runs) {
+            const uint32_t pp = part_list ? part_list[pi] : pi;
+            cnt = rvw.run_cnt[(uint64_t)pp * S_runs + threadIdx.x];
+            addr = rvw.run_addr16[(uint64_t)pp * S_runs + threadIdx.x];
+        }
+    };
+    uint32_t nx_cnt; unsigned long long nx_addr;
+    load_runs(blockIdx.x, nx_cnt, nx_addr);
+  for (uint32_t pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {
+    const uint32_t p = part_list ? part_list[pi] : pi;
+    // exclusive prefix of the run lengths of this partition (S_runs <= 256: threads 0..255, one run each)
+    {
+        const uint32_t f = nx_cnt;
+        uint32_t incl = f;
+        if (threadIdx.x < 256) {
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (lane == 63) wtot[threadIdx.x >> 6] = incl;
+        }
+        __syncthreads();                                 // (also: the previous partition is done with ctl / the tables)
+        if (threadIdx.x < 256) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += wtot[w];
+            if (threadIdx.x < S_runs) { ctl.pre[threadIdx.x] = off + incl - f; ctl.roff[threadIdx.x] = nx_addr; }
         }
         if (threadIdx.x == 0) {
-            ctl.pre[S_runs] = run; ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
-            ctl.n_inst = 0; ctl.n_used = 0;
+            ctl.pre[S_runs] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
+            ctl.part_inst = 0; ctl.n_used = 0;
             uint32_t force = 0;
-            if (ovf && defer_after && blockIdx.x >= probe_blocks) {
+            if (ovf && defer_after && pi >= probe_blocks) {
                 const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
                 force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
@@ -707,6 +729,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
     }
     __syncthreads();
+    load_runs(pi + gridDim.x, nx_cnt, nx_addr);          // the next partition's run table: in flight during this one
+   [&]() {                                              // one partition; `return` = done with it
     const uint32_t R = ctl.pre[S_runs];
     if (rvw.dbg == 5) return;                            // timing experiment: launch + run prefix only
 
@@ -726,12 +750,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             inst += (src[RW - 1] >> 58) + 1ull;
         }
         for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
-        if (lane == 0 && inst) atomicAdd(&ctl.n_inst, inst);
+        if (lane == 0 && inst) atomicAdd(&ctl.part_inst, inst);
         __syncthreads();
         if (threadIdx.x == 0 && R) {
-            const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.n_inst / (double)ctl.tried : (double)ctl.n_inst;
+            const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.part_inst / (double)ctl.tried : (double)ctl.part_inst;
             const uint32_t slot = atomicAdd(ovf_n, 1u);
-            OvfRec o; o.p = p; o.est_distinct = !was_tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : est < 1.0 ? 1u : (uint32_t)est; o.instances = ctl.n_inst;
+            OvfRec o; o.p = p; o.est_distinct = !was_tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : est < 1.0 ? 1u : (uint32_t)est; o.instances = ctl.part_inst;
             ovf[slot] = o;
         }
         if (threadIdx.x == 0 && was_tried && defer_after) atomicAdd(&ovf_n[1], 0x10001u);      // tried, and it overflowed
@@ -900,11 +924,15 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
         // (phase B is over: the record table's multiplicity words are free to hold the emit list)
         static_assert(2u * decltype(tb.rt)::SR >= S, "emit list");
-        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, reinterpret_cast<uint16_t *>(tb.rt.rst));
+        table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, reinterpret_cast<uint16_t *>(tb.rt.rst), 0u, whist);
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
     if (threadIdx.x == 0 && ovf && defer_after) atomicAdd(&ovf_n[1], 1u);                          // tried, and it fitted
+   }();
+  }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+        if (whist[b]) atomicAdd(&histo[b], (unsigned long long)whist[b]);
+    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
 }
 
 

@@ -473,7 +473,8 @@ public:
             // on configs[2] with the errors left in).  Decided on the device, inside the one launch.
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
-            hipLaunchKernelGGL(k_count_partitions<W>, dim3(n_parts), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
+            // (persistent workgroups, one per CU: the tables take the whole LDS)
+            hipLaunchKernelGGL(k_count_partitions<W>, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
                                (uint32_t *)(ctl_.p + 3), n_probe / 2, n_probe / 8);
@@ -553,7 +554,7 @@ public:
                 if (!bad.empty()) {
                     if (int rc = d_list.alloc(bad.size(), err)) return rc;
                     HIPCHK(hipMemcpyAsync(d_list.p, bad.data(), bad.size() * 4, hipMemcpyHostToDevice, stream_));
-                    hipLaunchKernelGGL(k_count_partitions<W>, dim3((unsigned)bad.size()), dim3(COUNT_THREADS), 0, stream_, rv, threshold,
+                    hipLaunchKernelGGL(k_count_partitions<W>, dim3(std::min<uint32_t>((uint32_t)bad.size(), (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, (uint32_t)bad.size(), threshold,
                                        dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                        (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
                     HIPCHK(hipGetLastError());
