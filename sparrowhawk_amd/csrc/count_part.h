@@ -6,8 +6,10 @@
 // together first, so that counting happens in the 160 KB LDS of one CU:
 //
 //   pass 1  k_partition         reads -> super-k-mer records, scattered by minimiser partition
-//   pass 2  k_count_partitions  one workgroup per partition: LDS hash table -> histogram +
-//                               (k-mer, count) rows with count > T
+//   pass 2  k_count_partitions  one partition at a time per (persistent) workgroup: LDS record table +
+//                               LDS k-mer table -> histogram + (k-mer, count) rows with count > T
+//           k_ovf_scatter / k_count_buckets   partitions whose distinct k-mers exceed the LDS table
+//                               (error-rich reads): split once more by k-mer hash, counted per bucket
 //
 // Minimiser = the m-mer (m = k - WBLK + 1) of a k-mer with the smallest canonical ntHash
 // (SPEC S3); partition = low bits of that hash.  Both strands of a k-mer share it, so every
