@@ -215,6 +215,14 @@ struct EvTimer {
         return ms;
     }
     ~EvTimer() { if (ok) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } }
+    // end of the timed region without waiting; elapsed() after the stream has been synchronised anyway
+    void mark() { if (ok) (void)hipEventRecord(b, st); }
+    double elapsed() {
+        if (!ok) return 0.0;
+        (void)hipEventSynchronize(b);
+        float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+        return ms;
+    }
     // stop without waiting: the pair of events goes on `pending` and is read when the timings are asked for
     // (a hipEventSynchronize between two phases that have nothing to wait for costs a pipeline bubble)
     struct Pending { std::string name; hipEvent_t a, b; };
@@ -363,10 +371,11 @@ public:
             if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
             else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
             HIPCHK(hipGetLastError());
-            const double ms = t.stop();
+            t.mark();
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipStreamSynchronize(stream_));
+            HIPCHK(hipStreamSynchronize(stream_));          // (one host round trip: flags and the timer together)
+            const double ms = t.elapsed();
             const uint32_t *fl = (const uint32_t *)&h[0];
             if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
             const uint32_t max_fill = (uint32_t)h[1];
@@ -479,10 +488,12 @@ public:
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
                                (uint32_t *)(ctl_.p + 3), n_probe / 2, n_probe / 8);
             HIPCHK(hipGetLastError());
-            ms_out = t.stop();
+            t.mark();
             unsigned long long h[4];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipStreamSynchronize(stream_));
+            HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));   // (final unless partitions overflowed)
+            HIPCHK(hipStreamSynchronize(stream_));          // one host round trip: counters, histogram and the timer
+            ms_out = t.elapsed();
             const uint32_t n_ovf = (uint32_t)h[3];
             if (n_ovf) {
                 EvTimer t2(stream_);
@@ -564,11 +575,10 @@ public:
                 times_.add("count_deferred_untried_x1", (double)n_untried);
                 times_.add("count_residue_rerun_x1", (double)bad.size());
                 HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipStreamSynchronize(stream_));
                 times_.add("count_bucket_splits_x1", (double)(h[2] >> 32));
             }
-            HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipStreamSynchronize(stream_));
             if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way residue splitting"; return -6; }
             n_rows = h[0]; inst_out = h[1];
             if (n_rows <= cap) {
