@@ -363,6 +363,34 @@ int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
     int flush_rc = SHK_OK;
     auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
     h->pipe->expect_more_batches();                      // the total is unknown while chunks keep coming
+    // a large chunk (whole records, like every chunk) is parsed on the device and counted as a batch of its
+    // own; small chunks — and any chunk the device parser finds irregular — are packed on the host below
+    {
+        const char *force_host = getenv("SHK_HOST_PARSER");
+        const char *mv = getenv("SHK_STREAM_DEVICE_MIN");
+        const size_t dev_min = (mv && *mv) ? (size_t)strtoull(mv, nullptr, 10) : ((size_t)8 << 20);
+        if (!(force_host && *force_host == '1') && n >= dev_min) {
+            std::vector<uint8_t> st;
+            const uint8_t *t = nullptr; size_t l = 0;
+            int rc = maybe_inflate(chunk, n, st, t, l, err);
+            if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : SHK_E_OOM, err);
+            if (l / 2 <= batch_bases()) {
+                GpuPacked gp;
+                rc = gpu_pack_fastq(t, l, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, h->stream_reads.n_reads);
+                if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+                if (rc == 0) {
+                    const uint64_t every = h->progress_every();
+                    for (size_t j = 0; j < gp.progress_bytes.size(); j++) prog(every * (gp.first_mark + j + 1), 0, 0);
+                    h->pipe->times().add("fastq_device_chunks_x1", 1.0);
+                    const int rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
+                    h->stream_reads.n_reads += gp.n_reads; h->stream_reads.n_input_bases += gp.n_input_bases;
+                    gpu_packed_free(gp);
+                    return rc2;
+                }
+                gpu_packed_free(gp);                    // not regular 4-line FASTQ: the host parser decides
+            }
+        }
+    }
     int rc = pack_fastq(chunk, n, h->k, h->min_qual, h->stream_reads, err, h->progress_every(), prog,
                         flush_every_reads(h), batch_bases(), flush);
     if (rc == -7) return flush_rc;

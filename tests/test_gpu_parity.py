@@ -440,6 +440,11 @@ def test_several_batches_per_handle():
         return h, sorted_table(*h.distinct())
     c, (ck, cc, _) = _with_env({"SHK_BATCH_BASES": 200000}, stream)
     assert c.timings().get("batch_pack_kernel", 0) > 0
+    # the same chunks through the device parser (large chunks take it by default), one batch per chunk
+    d, (dk, dc, _) = _with_env({"SHK_STREAM_DEVICE_MIN": 1000}, stream)
+    assert d.timings().get("fastq_device_chunks_x1", 0) == 3 and "fastq_device_chunks_x1" not in c.timings()
+    assert np.array_equal(dk, ck) and np.array_equal(dc, cc) and d.states == c.states
+    assert d.total_instances == c.total_instances
     o2 = run_oracle(parts, k=51, min_count=0)
     ok_, oc_ = o2.distinct()
     assert np.array_equal(ck, ok_) and np.array_equal(cc, oc_)
