@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 
@@ -61,8 +62,7 @@ std::string take_big_string() {
     for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].capacity() > g_pool[best].capacity()) best = i;
     std::string s = std::move(g_pool[best]);
     g_pool.erase(g_pool.begin() + best);
-    s.clear();
-    return s;
+    return s;                                           // (with its old size: the writer overwrites it)
 }
 void give_big_string(std::string &&s) {
     if (s.capacity() < (1u << 20)) return;
@@ -71,16 +71,29 @@ void give_big_string(std::string &&s) {
 }
 
 namespace {
-// appends JSON-escaped text: NL/TAB/QUOTE are the only specials the writers produce
-struct Esc {
-    std::string s;
-    void nl() { s += "\\n"; }
-    void tab() { s += "\\t"; }
-    void quote() { s += "\\\""; }
-    void raw(const char *p) { s += p; }                      // text without specials
-    void raw(const std::string &p) { s += p; }
-    void raw(const char *p, size_t n) { s.append(p, n); }
-    void num(uint64_t v) { s += std::to_string(v); }
+// The writers emit JSON-escaped text (NL/TAB/QUOTE are the only specials they produce) into a sink: one
+// sink measures, the other writes through a pointer — every section's size is known before a byte is
+// written, so the sections go straight to their places in one buffer, the big ones in parallel.
+static inline size_t n_digits(uint64_t v) { size_t n = 1; while (v >= 10) { v /= 10; n++; } return n; }
+struct SizeSink {
+    size_t n = 0;
+    void nl() { n += 2; }
+    void tab() { n += 2; }
+    void quote() { n += 2; }
+    void raw(const char *p) { n += strlen(p); }
+    void raw(const std::string &p) { n += p.size(); }
+    void raw(const char *, size_t m) { n += m; }
+    void num(uint64_t v) { n += n_digits(v); }
+};
+struct PtrSink {
+    char *p;
+    void nl() { *p++ = '\\'; *p++ = 'n'; }
+    void tab() { *p++ = '\\'; *p++ = 't'; }
+    void quote() { *p++ = '\\'; *p++ = '"'; }
+    void raw(const char *q) { const size_t m = strlen(q); memcpy(p, q, m); p += m; }
+    void raw(const std::string &q) { memcpy(p, q.data(), q.size()); p += q.size(); }
+    void raw(const char *q, size_t m) { memcpy(p, q, m); p += m; }
+    void num(uint64_t v) { const size_t m = n_digits(v); for (size_t i = m; i-- > 0;) { p[i] = (char)('0' + v % 10); v /= 10; } p += m; }
 };
 }  // namespace
 
@@ -171,66 +184,89 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     std::sort(links.begin(), links.end());
     links.erase(std::unique(links.begin(), links.end()), links.end());
 
-    // One pass, straight into the JSON text in key order (a 5 Mbp contig is copied three times —
-    // FASTA, GFA1, GFA2 — and never staged in per-format strings).
+    // Straight into the JSON text in key order (a 5 Mbp contig is copied three times — FASTA, GFA1, GFA2 —
+    // and never staged in per-format strings).
     size_t seq_bytes = 0;
     for (auto &c : contigs) seq_bytes += c.size();
-    Esc w;
-    w.s = take_big_string();
-    w.s.reserve(3 * seq_bytes + nc * 320 + links.size() * 200 + 256);
     std::vector<std::string> ids(nc), lens(nc), kcs(nc);
     for (size_t i = 0; i < nc; i++) {
         ids[i] = std::to_string(i + 1); lens[i] = std::to_string(contigs[i].size()); kcs[i] = std::to_string(contigs[i].kc);
     }
     const std::string ov = std::to_string(k - 1);
-    w.raw("{\"outfasta\":\"");
-    for (size_t i = 0; i < nc; i++) {
-        w.raw(">contig_"); w.raw(ids[i]); w.raw(" len="); w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.nl();
-        w.raw(contigs[i].data(), contigs[i].size()); w.nl();
-    }
-    w.raw("\",\"ncontigs\":"); w.num(nc);
-    w.raw(",\"outdot\":\"");
-    w.raw("digraph sparrowhawk {"); w.nl();
-    for (size_t i = 0; i < nc; i++) {
-        w.raw("  "); w.quote(); w.raw(ids[i]); w.quote(); w.raw(" [label="); w.quote(); w.raw(ids[i]); w.raw(" len=");
-        w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.quote(); w.raw("];"); w.nl();
-    }
-    for (const Link &L : links) {
-        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-        w.raw("  "); w.quote(); w.num(a); w.quote(); w.raw(" -> "); w.quote(); w.num(b); w.quote();
-        w.raw(" [label="); w.quote(); w.raw(ao ? "-" : "+"); w.raw(bo ? "-" : "+"); w.quote(); w.raw("];"); w.nl();
-    }
-    w.raw("}"); w.nl();
-    w.raw("\",\"outgfa\":\"");
-    w.raw("H"); w.tab(); w.raw("VN:Z:1.0"); w.nl();
-    for (size_t i = 0; i < nc; i++) {
-        w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab(); w.raw("LN:i:"); w.raw(lens[i]);
-        w.tab(); w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
-    }
-    for (const Link &L : links) {
-        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-        w.raw("L"); w.tab(); w.num(a); w.tab(); w.raw(ao ? "-" : "+"); w.tab(); w.num(b); w.tab();
-        w.raw(bo ? "-" : "+"); w.tab(); w.raw(ov); w.raw("M"); w.nl();
-    }
-    w.raw("\",\"outgfav2\":\"");
-    w.raw("H"); w.tab(); w.raw("VN:Z:2.0"); w.nl();
-    for (size_t i = 0; i < nc; i++) {
-        w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(lens[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab();
-        w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
-    }
-    for (const Link &L : links) {
-        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-        const uint64_t la = contigs[a - 1].size(), lb = contigs[b - 1].size();
-        w.raw("E"); w.tab(); w.raw("*"); w.tab(); w.num(a); w.raw(ao ? "-" : "+"); w.tab(); w.num(b);
-        w.raw(bo ? "-" : "+"); w.tab();
-        if (!ao) { w.num(la - (k - 1)); w.tab(); w.num(la); w.raw("$"); w.tab(); }
-        else { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == la) w.raw("$"); w.tab(); }
-        if (!bo) { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == lb) w.raw("$"); w.tab(); }
-        else { w.num(lb - (k - 1)); w.tab(); w.num(lb); w.raw("$"); w.tab(); }
-        w.raw(ov); w.raw("M"); w.nl();
-    }
-    w.raw("\"}");
-    out.json = std::move(w.s);
+    auto sec_fasta = [&](auto &w) {
+        w.raw("{\"outfasta\":\"");
+        for (size_t i = 0; i < nc; i++) {
+            w.raw(">contig_"); w.raw(ids[i]); w.raw(" len="); w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.nl();
+            w.raw(contigs[i].data(), contigs[i].size()); w.nl();
+        }
+        w.raw("\",\"ncontigs\":"); w.num(nc);
+    };
+    auto sec_dot = [&](auto &w) {
+        w.raw(",\"outdot\":\"");
+        w.raw("digraph sparrowhawk {"); w.nl();
+        for (size_t i = 0; i < nc; i++) {
+            w.raw("  "); w.quote(); w.raw(ids[i]); w.quote(); w.raw(" [label="); w.quote(); w.raw(ids[i]); w.raw(" len=");
+            w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.quote(); w.raw("];"); w.nl();
+        }
+        for (const Link &L : links) {
+            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+            w.raw("  "); w.quote(); w.num(a); w.quote(); w.raw(" -> "); w.quote(); w.num(b); w.quote();
+            w.raw(" [label="); w.quote(); w.raw(ao ? "-" : "+"); w.raw(bo ? "-" : "+"); w.quote(); w.raw("];"); w.nl();
+        }
+        w.raw("}"); w.nl();
+    };
+    auto sec_gfa1 = [&](auto &w) {
+        w.raw("\",\"outgfa\":\"");
+        w.raw("H"); w.tab(); w.raw("VN:Z:1.0"); w.nl();
+        for (size_t i = 0; i < nc; i++) {
+            w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab(); w.raw("LN:i:"); w.raw(lens[i]);
+            w.tab(); w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
+        }
+        for (const Link &L : links) {
+            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+            w.raw("L"); w.tab(); w.num(a); w.tab(); w.raw(ao ? "-" : "+"); w.tab(); w.num(b); w.tab();
+            w.raw(bo ? "-" : "+"); w.tab(); w.raw(ov); w.raw("M"); w.nl();
+        }
+    };
+    auto sec_gfa2 = [&](auto &w) {
+        w.raw("\",\"outgfav2\":\"");
+        w.raw("H"); w.tab(); w.raw("VN:Z:2.0"); w.nl();
+        for (size_t i = 0; i < nc; i++) {
+            w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(lens[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab();
+            w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
+        }
+        for (const Link &L : links) {
+            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+            const uint64_t la = contigs[a - 1].size(), lb = contigs[b - 1].size();
+            w.raw("E"); w.tab(); w.raw("*"); w.tab(); w.num(a); w.raw(ao ? "-" : "+"); w.tab(); w.num(b);
+            w.raw(bo ? "-" : "+"); w.tab();
+            if (!ao) { w.num(la - (k - 1)); w.tab(); w.num(la); w.raw("$"); w.tab(); }
+            else { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == la) w.raw("$"); w.tab(); }
+            if (!bo) { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == lb) w.raw("$"); w.tab(); }
+            else { w.num(lb - (k - 1)); w.tab(); w.num(lb); w.raw("$"); w.tab(); }
+            w.raw(ov); w.raw("M"); w.nl();
+        }
+        w.raw("\"}");
+    };
+    SizeSink z1, z2, z3, z4;
+    sec_fasta(z1); sec_dot(z2); sec_gfa1(z3); sec_gfa2(z4);
+    const size_t total = z1.n + z2.n + z3.n + z4.n;
+    // (a recycled string keeps its size: growing it is the only time its bytes are filled twice)
+    std::string js = take_big_string();
+    if (js.size() < total) js.resize(total);
+    char *base = &js[0];
+    auto run = [&](int which) {
+        if (which == 0) { PtrSink w{base}; sec_fasta(w); PtrSink d{base + z1.n}; sec_dot(d); }
+        else if (which == 1) { PtrSink w{base + z1.n + z2.n}; sec_gfa1(w); }
+        else { PtrSink w{base + z1.n + z2.n + z3.n}; sec_gfa2(w); }
+    };
+    if (seq_bytes >= (1u << 20)) {                          // three copies of megabytes: one thread each
+        std::thread t1(run, 1), t2(run, 2);
+        run(0);
+        t1.join(); t2.join();
+    } else { run(0); run(1); run(2); }
+    js.resize(total);
+    out.json = std::move(js);
     out.fasta.clear(); out.gfa1.clear(); out.gfa2.clear(); out.dot.clear();
 }
 
