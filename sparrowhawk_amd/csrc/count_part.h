@@ -661,6 +661,41 @@ __global__ __launch_bounds__(256) void k_pack_partition(const uint64_t *__restri
     }
 }
 
+// several packed batches become one: the S runs of partition p (one per batch) are copied back to back to
+// dst[base[p] ..) — a handle may receive any number of batches, a run table holds 256 per partition
+template <int RW>
+__global__ __launch_bounds__(256) void k_merge_runs(RunView rvw, const unsigned long long *__restrict__ base,
+                                                    uint64_t *__restrict__ dst) {
+    __shared__ uint32_t pre[257];
+    __shared__ unsigned long long roff[256];
+    const uint32_t p = blockIdx.x, S_runs = rvw.S;
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        uint32_t run = 0;
+        for (uint32_t g0 = 0; g0 < S_runs; g0 += 64) {
+            const uint32_t g = g0 + threadIdx.x;
+            const uint32_t f = g < S_runs ? rvw.run_cnt[(uint64_t)p * S_runs + g] : 0u;
+            if (g < S_runs) roff[g] = rvw.run_addr16[(uint64_t)p * S_runs + g];
+            uint32_t incl = f;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (g < S_runs) pre[g] = run + incl - f;
+            run += __shfl(incl, 63);
+        }
+        if (threadIdx.x == 0) pre[S_runs] = run;
+    }
+    __syncthreads();
+    const uint32_t R = pre[S_runs];
+    uint64_t *dst_p = dst + base[p] * RW;
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+        uint32_t lo = 0, hi = S_runs;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (pre[mid] <= r) lo = mid; else hi = mid; }
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(roff[lo] << 4) + (uint64_t)(r - pre[lo]) * RW;
+#pragma unroll
+        for (int o = 0; o < RW; o += 2)
+            *reinterpret_cast<ulonglong2 *>(dst_p + (uint64_t)r * RW + o) = *reinterpret_cast<const ulonglong2 *>(src + o);
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     RunView rvw, uint32_t n_parts, uint32_t threshold,

@@ -441,6 +441,36 @@ public:
         HIPCHK(stream_wait(stream_));
         batches_.push_back(std::move(b));
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
+        if (batches_.size() >= env_u64("SHK_MERGE_BATCHES_AT", 192)) return merge_batches(err);
+        return 0;
+    }
+
+    // Any number of batches per handle (chunked mode hands one on every chunk_size reads, a stream one per
+    // chunk): a run table holds 256 runs per partition, so when that many batches have piled up they are
+    // copied into one (every record moves once per ~200 batches).
+    int merge_batches(std::string &err) {
+        constexpr int RW = 2 * W;
+        if (batches_.size() < 2) return 0;
+        if (int rc = make_batch_run_view(err)) return rc;
+        std::unique_ptr<BatchRecs> m(new BatchRecs());
+        m->part_off.assign(pp_.P + 1, 0);
+        for (uint32_t p = 0; p < pp_.P; p++) {
+            unsigned long long tot = 0;
+            for (auto &b : batches_) tot += b->part_off[p + 1] - b->part_off[p];
+            m->part_off[p + 1] = m->part_off[p] + tot;
+        }
+        if (int rc = m->dense.alloc(m->part_off[pp_.P] * RW + 2, err)) return rc;
+        DevBuf<unsigned long long> base;
+        if (int rc = base.alloc(pp_.P, err)) return rc;
+        HIPCHK(hipMemcpyAsync(base.p, m->part_off.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
+        EvTimer t(stream_);
+        hipLaunchKernelGGL((k_merge_runs<RW>), dim3(pp_.P), dim3(256), 0, stream_, run_view_, base.p, m->dense.p);
+        HIPCHK(hipGetLastError());
+        times_.add("batch_merge_kernel", t.stop());
+        HIPCHK(stream_wait(stream_));
+        batches_.clear();
+        batches_.push_back(std::move(m));
+        run_off_.release(); run_cnt_.release(); have_parts_ = false;
         return 0;
     }
 

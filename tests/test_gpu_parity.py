@@ -429,6 +429,11 @@ def test_several_batches_per_handle():
     b = _with_env({"SHK_HOST_PARSER": 1}, lambda: product(fq, k=31, min_count=2, csize=1000))
     assert b.timings().get("batch_pack_kernel", 0) > 0
     assert b.get_assembly() == ref.get_assembly()
+    # any number of batches: 60 batches of 200 reads, merged into one whenever 16 have piled up
+    m = _with_env({"SHK_HOST_PARSER": 1, "SHK_MERGE_BATCHES_AT": 16}, lambda: product(fq, k=31, min_count=2, csize=200))
+    assert m.timings().get("batch_merge_kernel", 0) > 0
+    assert m.get_assembly() == ref.get_assembly() and m.get_preprocessing_info() == ref.get_preprocessing_info()
+    assert m.total_instances == ref.total_instances
     # streaming entry point with tiny batches, two-word keys, the distinct table itself
     recs = fq.decode().split("@r")[1:]
     parts = [("@r" + "@r".join(recs[i::3])).encode() for i in range(3)]
