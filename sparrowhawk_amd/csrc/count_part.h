@@ -93,6 +93,54 @@ __device__ __forceinline__ void part_build_record(const uint32_t *stage, uint32_
     }
     out[RW - 1] |= (uint64_t)(n - 1u) << 58;
 }
+// A record and its reverse complement describe the same k-mers (pass 2 canonicalises every k-mer it expands),
+// and at high coverage every locus is read on both strands: the smaller of the two spellings is stored, so
+// that pass 2's record table sees one record per locus instead of two (half the expansions).
+template <int RW>
+__device__ __forceinline__ void rec_canonicalise(uint64_t (&r)[RW], uint32_t n, int k) {
+    const uint32_t L = n + (uint32_t)k - 1u;                 // bases in the record (2L <= 64 RW - 6 bits)
+    uint64_t d[RW], rc[RW];
+#pragma unroll
+    for (int o = 0; o < RW; o++) d[o] = r[o];
+    d[RW - 1] &= (1ull << 58) - 1ull;                        // without the length field
+    // reverse the order of all 32*RW two-bit groups and complement them ...
+#pragma unroll
+    for (int o = 0; o < RW; o++) {
+        uint64_t y = __builtin_bitreverse64(d[RW - 1 - o]);
+        y = ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+        rc[o] = ~y;
+    }
+    // ... and move base 0 of the reversed string down to bit 0: shift right by 64 RW - 2L bits
+    const uint32_t sh = 64u * RW - 2u * L, ws = sh >> 6, bs = sh & 63u;
+    uint64_t t[RW];
+#pragma unroll
+    for (int o = 0; o < RW; o++) {
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < RW; q++) {                         // (register arrays: selects, no dynamic indexing)
+            if ((uint32_t)q == (uint32_t)o + ws) lo = rc[q];
+            if ((uint32_t)q == (uint32_t)o + ws + 1u) hi = rc[q];
+        }
+        t[o] = bs ? (lo >> bs) | (hi << (64u - bs)) : lo;
+    }
+    // keep the low 2L bits
+#pragma unroll
+    for (int o = 0; o < RW; o++) {
+        const int rem = (int)(2u * L) - 64 * o;
+        if (rem <= 0) t[o] = 0;
+        else if (rem < 64) t[o] &= (1ull << rem) - 1ull;
+    }
+    bool smaller = false, decided = false;                   // t < d as multiword integers?
+#pragma unroll
+    for (int o = RW - 1; o >= 0; o--) {
+        if (!decided && t[o] != d[o]) { smaller = t[o] < d[o]; decided = true; }
+    }
+    if (smaller) {
+#pragma unroll
+        for (int o = 0; o < RW; o++) r[o] = t[o];
+        r[RW - 1] |= (uint64_t)(n - 1u) << 58;
+    }
+}
 template <int RW>
 __device__ __forceinline__ void part_store_record(const uint64_t (&out)[RW], uint64_t *__restrict__ dst) {
 #pragma unroll
@@ -881,6 +929,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, min(R, (r0 - w_begin) * (COUNT_THREADS / 64) + 1u)); break; }
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
+            // one spelling per locus (pass 1 is bound by its instruction issue, this pass by latencies: done here)
+            if (n && rvw.dbg != 11) rec_canonicalise<RW>(rec.w, n, k);
             nxt = nxt2; have_nxt = have_nxt2;
             have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
             // phase A: identical records (the same genomic run seen in many reads) are counted
