@@ -375,8 +375,14 @@ public:
         pp_.P = P;
         // records per slice: mean run length is ~(WBLK+1)/2 k-mers (shorter if max_n caps it); 2x slack
         const uint64_t per_rec = pp_.max_n >= 16 ? 4 : 2;
-        uint64_t cap = inst_ub / (per_rec * P * pp_.G) + 32;
+        uint64_t cap = inst_ub / (per_rec * P * pp_.G) + 32 + env_u64("SHK_SLICE_PAD", 0);
         for (int attempt = 0; attempt < 2; attempt++) {
+            // The 256 producer workgroups append to slices [p][0..G) at the same time; when consecutive slices lie
+            // (almost) a multiple of 2 KB apart their writes keep meeting in the same memory channels
+            // (measured on the bench workload: slices of 2032 / 2064 / 4096 bytes 0.90 ms, of 2112 ... 3056 bytes
+            // 0.80 ms for k_partition).  Slice sizes stay >= 256 bytes away from a multiple of 2 KB.
+            if (env_u64("SHK_SLICE_NOSKEW", 0) == 0)
+                while ((cap * RW * 8) % 2048 < 256 || (cap * RW * 8) % 2048 > 1792) cap++;
             pp_.slice_cap = (uint32_t)cap;
             const uint64_t n_slices = (uint64_t)P * pp_.G;
             if (int rc = recs_.alloc(n_slices * cap * RW, err)) return rc;
