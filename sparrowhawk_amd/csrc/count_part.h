@@ -30,7 +30,6 @@ namespace shk {
 static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
 static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
 static constexpr int PART_MAX_P = 16384;             // LDS cursors: 64 KB
-static constexpr int MAX_RUNS = 512;                 // runs per partition a run table holds (producer workgroups of pass 1 / batches / source ranks)
 static constexpr int STAGE_WORDS = 10240;            // 163840 bases of a read tile in LDS
 static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
 
@@ -424,7 +423,7 @@ template <int W> struct KmerTable {
 };
 // pass 2 proper: the LDS is split between the k-mer table (63-72 KB) and the record table (70-88 KB)
 template <int W> struct CountShared : KmerTable<W> {
-    RecTable<W, (W == 1 ? 3968u : ((71680u / (16u * W + 6u)) & ~63u))> rt;   // 3968 / 1856 / 1280 / 1024 records
+    RecTable<W, (W == 1 ? 4096u : ((71680u / (16u * W + 6u)) & ~63u))> rt;   // 4096 / 1856 / 1280 / 1024 records
 };
 
 struct CountCtlCore {                                   // what the table, the emit and the residue rounds need
@@ -436,8 +435,8 @@ struct CountCtlCore {                                   // what the table, the e
     unsigned long long n_inst, tried, part_inst;        // (n_inst: over the workgroup's lifetime; part_inst: of the partition being handed over)
 };
 struct CountCtl : CountCtlCore {                        // + the run table of a partition (k_count_partitions)
-    uint32_t pre[MAX_RUNS + 1];                         // exclusive prefix of the run lengths
-    unsigned long long roff[MAX_RUNS];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
+    uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
+    unsigned long long roff[256];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
 };
 
 // Table placement hash: add/shift/xor only (Jenkins one-at-a-time finaliser); integer multiplies
@@ -644,7 +643,7 @@ static constexpr uint32_t OVF_MAX_F = 256;
 struct RunView {
     const unsigned long long *run_addr16;
     const uint32_t *run_cnt;
-    uint32_t S;            // runs per partition (<= MAX_RUNS)
+    uint32_t S;            // runs per partition (<= 256)
     int k;
     uint32_t dbg;          // timing experiments only (SHK_DEBUG_P2)
 };
@@ -681,7 +680,7 @@ __global__ __launch_bounds__(256) void k_pack_partition(const uint64_t *__restri
                                                         const uint32_t *__restrict__ fill, PartParams pp,
                                                         const unsigned long long *__restrict__ base,
                                                         uint64_t *__restrict__ dst) {
-    __shared__ uint32_t pre[MAX_RUNS + 1];
+    __shared__ uint32_t pre[257];
     const uint32_t p = blockIdx.x;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
@@ -715,8 +714,8 @@ __global__ __launch_bounds__(256) void k_pack_partition(const uint64_t *__restri
 template <int RW>
 __global__ __launch_bounds__(256) void k_merge_runs(RunView rvw, const unsigned long long *__restrict__ base,
                                                     uint64_t *__restrict__ dst) {
-    __shared__ uint32_t pre[MAX_RUNS + 1];
-    __shared__ unsigned long long roff[MAX_RUNS];
+    __shared__ uint32_t pre[257];
+    __shared__ unsigned long long roff[256];
     const uint32_t p = blockIdx.x, S_runs = rvw.S;
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
@@ -765,7 +764,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     __shared__ CountShared<W> tb;
     __shared__ CountCtl ctl;
     __shared__ uint32_t whist[500];                     // this workgroup's histogram over all its partitions
-    __shared__ uint32_t wtot[MAX_RUNS / 64];
+    __shared__ uint32_t wtot[4];
     const int lane = threadIdx.x & 63;
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
@@ -787,24 +786,22 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     load_runs(blockIdx.x, nx_cnt, nx_addr);
   for (uint32_t pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {
     const uint32_t p = part_list ? part_list[pi] : pi;
-    // exclusive prefix of the run lengths of this partition (S_runs <= MAX_RUNS: threads 0..MAX_RUNS-1, one run each)
+    // exclusive prefix of the run lengths of this partition (S_runs <= 256: threads 0..255, one run each)
     {
         const uint32_t f = nx_cnt;
         uint32_t incl = f;
-        if (threadIdx.x < MAX_RUNS) {
+        if (threadIdx.x < 256) {
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
             if (lane == 63) wtot[threadIdx.x >> 6] = incl;
         }
         __syncthreads();                                 // (also: the previous partition is done with ctl / the tables)
-        if (threadIdx.x < MAX_RUNS) {
+        if (threadIdx.x < 256) {
             uint32_t off = 0;
             for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += wtot[w];
             if (threadIdx.x < S_runs) { ctl.pre[threadIdx.x] = off + incl - f; ctl.roff[threadIdx.x] = nx_addr; }
         }
         if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < MAX_RUNS / 64; w++) tot += wtot[w];
-            ctl.pre[S_runs] = tot;
+            ctl.pre[S_runs] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
             ctl.sp = 1; ctl.st_res[0] = 0; ctl.st_step[0] = 1; ctl.st_factor[0] = 1; ctl.st_next[0] = 0;
             ctl.part_inst = 0; ctl.n_used = 0;
             uint32_t force = 0;
@@ -1033,7 +1030,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
                                                                uint64_t *__restrict__ kmers,
                                                                uint32_t *__restrict__ bucket_fill) {
     constexpr int RW = 2 * W;
-    __shared__ uint32_t pre[MAX_RUNS + 1];
+    __shared__ uint32_t pre[257];
     __shared__ uint32_t cursor[OVF_MAX_F];
     const OvfItem it = items[blockIdx.x];
     const uint32_t p = it.p, S_runs = rvw.S;

@@ -483,7 +483,7 @@ public:
     // run tables over the packed batches: partition p, run b = batch b's records of p
     int make_batch_run_view(std::string &err) {
         const uint32_t nb = (uint32_t)batches_.size();
-        if (nb > (uint32_t)MAX_RUNS) { err = "too many batches in one run table"; return -1; }
+        if (nb > 256) { err = "more than 256 batches per handle"; return -1; }
         const uint64_t n_runs = (uint64_t)pp_.P * nb;
         std::vector<unsigned long long> addr16(n_runs); std::vector<uint32_t> cnt(n_runs);
         for (uint32_t p = 0; p < pp_.P; p++)
