@@ -3,6 +3,7 @@
 // the short separators need escaping, so a 5 Mbp contig costs three memcpys, not a per-byte scan.
 #include "outputs.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -260,7 +261,9 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         else if (which == 1) { PtrSink w{base + z1.n + z2.n}; sec_gfa1(w); }
         else { PtrSink w{base + z1.n + z2.n + z3.n}; sec_gfa2(w); }
     };
-    if (seq_bytes >= (1u << 20)) {                          // three copies of megabytes: one thread each
+    const char *pm = getenv("SHK_WRITER_PAR_MIN");          // (tests force the threaded path on small outputs)
+    const size_t par_min = (pm && *pm) ? (size_t)strtoull(pm, nullptr, 10) : ((size_t)1 << 20);
+    if (seq_bytes >= par_min) {                             // three copies of megabytes: one thread each
         std::thread t1(run, 1), t2(run, 2);
         run(0);
         t1.join(); t2.join();

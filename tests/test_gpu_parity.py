@@ -505,6 +505,17 @@ def test_device_parser_takes_large_texts_in_pieces():
     assert e1.states == e2.states and e1.get_assembly() == e2.get_assembly() == ref.get_assembly()
 
 
+def test_threaded_output_writer_equals_the_serial_one():
+    """Megabyte outputs are written by three threads into one buffer whose section offsets are measured
+    first; forced here on a small fragmented assembly (many contigs, links) and compared byte for byte."""
+    g, fq = make_dataset(40000, 12, err=0.01, seed=201)
+    a = product(fq, k=31, min_count=1)
+    b = _with_env({"SHK_WRITER_PAR_MIN": 1}, lambda: product(fq, k=31, min_count=1))
+    assert json.loads(a.get_assembly())["ncontigs"] > 3
+    assert a.get_assembly() == b.get_assembly()
+    compare_all(b, run_oracle([fq], k=31, min_count=1))
+
+
 def test_long_reads_are_split_into_overlapping_segments():
     """A 60 kbp read (longer than a kernel segment) goes through the host packer, which cuts it into
     pieces overlapping by k-1 bases: every k-mer is counted exactly once."""
