@@ -9,6 +9,7 @@
 #include <string.h>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "fastq.h"
@@ -202,7 +203,8 @@ static size_t next_record_start(const uint8_t *t, size_t n, size_t from) {
 }
 
 // A text of more than one batch: pieces of ~2 * batch_bases() bytes, cut at record boundaries, go through
-// the device parser one after the other, each counted as its own batch (pass 1) before the next is parsed.
+// the device parser one after the other, each counted as its own batch (pass 1) before the next is parsed;
+// a helper thread uploads piece i+1 while piece i is parsed and counted (H2D is two thirds of the entry point).
 // handled = false (and nothing counted) when the very first piece is not regular 4-line FASTQ: the caller
 // then runs the host parser over everything.  A later piece that is not regular is parsed on the host from
 // there to the end of its file, with the record numbers and progress of the whole file.
@@ -211,65 +213,111 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
     handled = false;
     std::string err;
     const size_t piece_bytes = (size_t)(2 * batch_bases());
-    uint64_t reads_done = 0;
-    bool counted_any = false;
-    const double t0 = now_ms();
+    struct Piece { int file; size_t off, end; bool host_rest; };
+    std::vector<Piece> pieces;
     for (int f = 0; f < 2; f++) {
         const uint8_t *t = f ? t2 : t1;
         const size_t len = f ? l2 : l1;
         if (!t) continue;
-        const size_t done_before = f ? n1 : 0;
-        uint64_t file_reads = 0;
         size_t off = 0;
         while (off < len) {
             size_t end = len;
             if (len - off > piece_bytes + piece_bytes / 8) {
                 end = next_record_start(t, len, off + piece_bytes);
-                if (end == SIZE_MAX) end = off;          // no record boundary found: the host parser takes it from here
+                if (end == SIZE_MAX || end <= off) { pieces.push_back(Piece{f, off, len, true}); break; }   // no record boundary: host from here
             }
-            int rc = 1;
-            GpuPacked gp;
-            if (end > off) {
-                rc = gpu_pack_fastq(t + off, end - off, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, reads_done);
-                if (rc < 0) { gpu_packed_free(gp); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
-            }
-            if (rc == 1) {
-                gpu_packed_free(gp);
-                if (!counted_any) return SHK_OK;         // handled stays false
-                // the rest of this file on the host
-                PackedReads pr;
-                pr.n_reads = reads_done;
-                auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
-                    const uint64_t pct = total ? (100 * (done_before + off + bytes)) / total : 100;
-                    h->post_mode(("loop:" + std::to_string(reads) + ":" + std::to_string(pct)).c_str());
-                };
-                int flush_rc = SHK_OK;
-                auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
-                int rc2 = pack_fastq(t + off, len - off, h->k, h->min_qual, pr, err, h->progress_every(), prog, 0, batch_bases(), flush, file_reads);
-                if (rc2 == -7) return flush_rc;
-                if (rc2) return fail(h, rc2 == -3 ? SHK_E_PARSE : (rc2 == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
-                if (int rc3 = flush_host_batch(h, pr)) return rc3;
-                reads_done = pr.n_reads;
-                break;
-            }
-            if (!counted_any) h->pipe->expect_more_batches();
-            h->pipe->times().add("fastq_h2d_text", gp.h2d_ms);
-            h->pipe->times().add("fastq_device_kernels", gp.kernels_ms);
-            h->pipe->times().add("fastq_device_pieces_x1", 1.0);
-            const uint64_t every = h->progress_every();
-            for (size_t j = 0; j < gp.progress_bytes.size(); j++) {
-                const uint64_t bytes = gp.progress_bytes[j] & ~(1ull << 63);
-                const uint64_t pct = total ? (100 * (done_before + off + bytes)) / total : 100;
-                h->post_mode(("loop:" + std::to_string(every * (gp.first_mark + j + 1)) + ":" + std::to_string(pct)).c_str());
-            }
-            int rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
-            reads_done += gp.n_reads; file_reads += gp.n_reads;
-            gpu_packed_free(gp);
-            if (rc2) return rc2;
-            counted_any = true;
+            pieces.push_back(Piece{f, off, end, false});
             off = end;
         }
     }
+    const int device = current_device();
+    uint64_t reads_done = 0, file_reads = 0;
+    bool counted_any = false;
+    const double t0 = now_ms();
+    GpuText cur, nxt;
+    bool have_cur = false;
+    std::thread uploader;
+    int up_rc = 0; std::string up_err;
+    auto join_upload = [&]() { if (uploader.joinable()) uploader.join(); };
+    auto drop_all = [&]() { join_upload(); gpu_text_free(cur); gpu_text_free(nxt); };
+    // the rest of a file through the host parser (a piece that is not regular 4-line FASTQ, or no boundary found)
+    auto host_rest = [&](const Piece &pc) -> int {
+        const uint8_t *t = pc.file ? t2 : t1;
+        const size_t len = pc.file ? l2 : l1, done_before = pc.file ? n1 : 0;
+        PackedReads pr;
+        pr.n_reads = reads_done;
+        auto prog = [&](uint64_t reads, uint64_t bytes, uint64_t) {
+            const uint64_t pct = total ? (100 * (done_before + pc.off + bytes)) / total : 100;
+            h->post_mode(("loop:" + std::to_string(reads) + ":" + std::to_string(pct)).c_str());
+        };
+        int flush_rc = SHK_OK;
+        auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
+        if (!counted_any) h->pipe->expect_more_batches();
+        int rc2 = pack_fastq(t + pc.off, len - pc.off, h->k, h->min_qual, pr, err, h->progress_every(), prog, 0, batch_bases(), flush, file_reads);
+        if (rc2 == -7) return flush_rc;
+        if (rc2) return fail(h, rc2 == -3 ? SHK_E_PARSE : (rc2 == -4 ? SHK_E_OOM : SHK_E_PARAM), err);
+        if (int rc3 = flush_host_batch(h, pr)) return rc3;
+        reads_done = pr.n_reads;
+        counted_any = true;
+        return SHK_OK;
+    };
+    for (size_t i = 0; i < pieces.size(); i++) {
+        const Piece pc = pieces[i];
+        if (i == 0 || pieces[i - 1].file != pc.file) file_reads = 0;
+        if (pc.host_rest) {
+            if (!counted_any && i == 0) { drop_all(); return SHK_OK; }          // handled stays false: the caller's host path
+            if (int rc = host_rest(pc)) { drop_all(); return rc; }
+            continue;
+        }
+        const uint8_t *t = pc.file ? t2 : t1;
+        if (!have_cur) {
+            if (int rc = gpu_upload_text(t + pc.off, pc.end - pc.off, device, cur, err)) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
+            have_cur = true;
+        }
+        // the next piece travels while this one is parsed and counted
+        const bool prefetch = i + 1 < pieces.size() && !pieces[i + 1].host_rest;
+        if (prefetch) {
+            const Piece nx = pieces[i + 1];
+            const uint8_t *tn = nx.file ? t2 : t1;
+            uploader = std::thread([&, nx, tn]() { up_rc = gpu_upload_text(tn + nx.off, nx.end - nx.off, device, nxt, up_err); });
+        }
+        GpuPacked gp;
+        int rc = gpu_pack_fastq(nullptr, 0, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, reads_done, &cur);
+        if (rc < 0) { gpu_packed_free(gp); drop_all(); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+        if (rc == 1) {
+            gpu_packed_free(gp);
+            drop_all(); have_cur = false;
+            if (!counted_any) return SHK_OK;             // handled stays false
+            Piece rest = pc; rest.end = pc.file ? l2 : l1; rest.host_rest = true;
+            if (int rc2 = host_rest(rest)) return rc2;
+            while (i + 1 < pieces.size() && pieces[i + 1].file == pc.file) i++;      // the rest of this file is done
+            continue;
+        }
+        if (!counted_any) h->pipe->expect_more_batches();
+        h->pipe->times().add("fastq_h2d_text", gp.h2d_ms);
+        h->pipe->times().add("fastq_device_kernels", gp.kernels_ms);
+        h->pipe->times().add("fastq_device_pieces_x1", 1.0);
+        const uint64_t every = h->progress_every();
+        const size_t done_before = pc.file ? n1 : 0;
+        for (size_t j = 0; j < gp.progress_bytes.size(); j++) {
+            const uint64_t bytes = gp.progress_bytes[j] & ~(1ull << 63);
+            const uint64_t pct = total ? (100 * (done_before + pc.off + bytes)) / total : 100;
+            h->post_mode(("loop:" + std::to_string(every * (gp.first_mark + j + 1)) + ":" + std::to_string(pct)).c_str());
+        }
+        const int rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
+        reads_done += gp.n_reads; file_reads += gp.n_reads;
+        gpu_packed_free(gp);
+        if (rc2) { drop_all(); return rc2; }
+        counted_any = true;
+        // hand over to the uploaded next piece
+        join_upload();
+        gpu_text_free(cur); have_cur = false;
+        if (prefetch) {
+            if (up_rc) { gpu_text_free(nxt); return fail(h, up_rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, up_err); }
+            cur = nxt; nxt = GpuText(); have_cur = true;
+        }
+    }
+    drop_all();
     handled = true;
     h->n_reads = reads_done;
     h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t0);

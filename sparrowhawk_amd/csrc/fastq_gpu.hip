@@ -12,6 +12,7 @@
 // else — and every malformed record — is left to the host parser, which owns the error messages.
 // The result is the same packed layout bit for bit (tests/test_gpu_parity.py compares both).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <string>
 #include <vector>
@@ -435,14 +436,16 @@ static size_t trimmed_len(const uint8_t *t, size_t n) {
 }
 
 int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, uint32_t k, uint32_t min_qual,
-                   uint64_t every, void *stream_v, GpuPacked &out, std::string &err, uint64_t read_base) {
+                   uint64_t every, void *stream_v, GpuPacked &out, std::string &err, uint64_t read_base,
+                   const GpuText *uploaded) {
     hipStream_t st = (hipStream_t)stream_v;
     out = GpuPacked();
     Scratch sc;
+    if (uploaded && t2) { err = "an uploaded text cannot be combined with a second file"; return -1; }
     // ---- framing that can be decided on the host: trailing blank lines are ignored, the last line of a
     // file may lack its newline (one is supplied between the files)
-    const size_t e1 = trimmed_len(t1, n1), e2 = t2 ? trimmed_len(t2, n2) : 0;
-    const bool unterm1 = e1 && t1[e1 - 1] != '\n', unterm2 = e2 && t2[e2 - 1] != '\n';
+    const size_t e1 = uploaded ? uploaded->e : trimmed_len(t1, n1), e2 = t2 ? trimmed_len(t2, n2) : 0;
+    const bool unterm1 = uploaded ? uploaded->unterminated : (e1 && t1[e1 - 1] != '\n'), unterm2 = e2 && t2[e2 - 1] != '\n';
     const size_t off2 = e1 + ((unterm1 && e2) ? 1 : 0);
     const size_t e = off2 + e2;
     if (e == 0) {                                        // no records at all
@@ -454,16 +457,18 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
         out.d_bases = bs; out.d_seg_off = so; return 0;
     }
     const bool unterminated = e2 ? unterm2 : unterm1;
-    uint8_t *text = sc.get<uint8_t>(e + 32, err);
+    uint8_t *text = uploaded ? uploaded->d : sc.get<uint8_t>(e + 32, err);
     if (!text) return -4;
     hipEvent_t ev0, ev1, ev2;
     FQCHK(hipEventCreate(&ev0)); FQCHK(hipEventCreate(&ev1)); FQCHK(hipEventCreate(&ev2));
     struct EvGuard { hipEvent_t a, b, c; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipEventDestroy(c); } } evg{ev0, ev1, ev2};
     FQCHK(hipEventRecord(ev0, st));
-    if (e1) FQCHK(hipMemcpyAsync(text, t1, e1, hipMemcpyHostToDevice, st));
-    if (off2 > e1) FQCHK(hipMemsetAsync(text + e1, '\n', 1, st));
-    if (e2) FQCHK(hipMemcpyAsync(text + off2, t2, e2, hipMemcpyHostToDevice, st));
-    FQCHK(hipMemsetAsync(text + e, 0, 32, st));
+    if (!uploaded) {
+        if (e1) FQCHK(hipMemcpyAsync(text, t1, e1, hipMemcpyHostToDevice, st));
+        if (off2 > e1) FQCHK(hipMemsetAsync(text + e1, '\n', 1, st));
+        if (e2) FQCHK(hipMemcpyAsync(text + off2, t2, e2, hipMemcpyHostToDevice, st));
+        FQCHK(hipMemsetAsync(text + e, 0, 32, st));
+    }
     FQCHK(hipEventRecord(ev1, st));
 
     const uint64_t n_chunks = (e + NL_CHUNK - 1) / NL_CHUNK;
@@ -534,11 +539,36 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     }
     FQCHK(hipEventRecord(ev2, st));
     FQCHK(hipStreamSynchronize(st));
-    { float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); out.h2d_ms = a; out.kernels_ms = b; }
+    { float a = 0, b = 0; (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2); out.h2d_ms = uploaded ? uploaded->h2d_ms : a; out.kernels_ms = b; }
     out.bases_bytes = sc.keep(bases); out.seg_off_bytes = sc.keep(seg_off);
     out.d_bases = bases; out.d_seg_off = seg_off;
     out.n_seg = n_seg; out.n_bases = n_bases; out.n_reads = n_reads; out.n_input_bases = h[3];
     return 0;
+}
+
+int gpu_upload_text(const uint8_t *t, size_t n, int device, GpuText &out, std::string &err) {
+    out = GpuText();
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); err = "hipSetDevice failed"; return -5; }
+    out.e = trimmed_len(t, n);
+    out.unterminated = out.e && t[out.e - 1] != '\n';
+    size_t bytes = out.e + 32;
+    out.d = (uint8_t *)device_pool_alloc(bytes);
+    if (!out.d) { err = "out of device memory for the FASTQ text"; return -4; }
+    out.pool_bytes = bytes;
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (e == hipSuccess && out.e) e = hipMemcpyAsync(out.d, t, out.e, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemsetAsync(out.d + out.e, 0, 32, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    out.h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (s) (void)hipStreamDestroy(s);
+    if (e != hipSuccess) { err = std::string("upload of the FASTQ text: ") + hipGetErrorString(e); gpu_text_free(out); return -5; }
+    return 0;
+}
+void gpu_text_free(GpuText &t) {
+    if (t.d) device_pool_release(t.d, t.pool_bytes);
+    t = GpuText();
 }
 
 void gpu_packed_free(GpuPacked &p) {

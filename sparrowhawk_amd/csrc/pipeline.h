@@ -65,6 +65,7 @@ public:
 // returns nullptr (and err) if no device / bad k
 IPipeline *make_pipeline(int k, std::string &err);
 int device_count();
+int current_device();          // the calling thread's current HIP device
 
 // host-side helpers implemented with the same kmer.h arithmetic as the kernels
 int host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *orient);

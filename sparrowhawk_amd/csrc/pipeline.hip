@@ -1229,6 +1229,7 @@ private:
     uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;
 };
 
+int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
