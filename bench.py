@@ -97,10 +97,14 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a one-GPU box together with --one-gpu)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--mode", choices=["isolates", "sharded"], default="isolates",
-                    help="N>1: 'isolates' = every rank assembles its own isolate (independent objects, no "
-                         "data-path collective); 'sharded' = ONE pooled sample of N isolates, k-mer space "
-                         "partitioned across ranks with one RCCL all-to-all (sparrowhawk_amd/dist.py)")
+    ap.add_argument("--mode", choices=["isolates", "sharded"], default="sharded",
+                    help="N>1: 'sharded' (default, the north_star path) = ONE pooled sample of N isolates, every rank "
+                         "holds an equal share of its reads, k-mer space partitioned across ranks with one RCCL "
+                         "pairwise exchange inside libshk_hip.so (shk_shard_preprocess); 'isolates' = every rank "
+                         "assembles its own isolate (independent objects, no data-path collective) — the comparison point")
+    ap.add_argument("--collectives", choices=["lib", "torch"], default="lib",
+                    help="sharded mode: 'lib' = RCCL inside the library (production); 'torch' = the same shk_shard_* "
+                         "pieces driven by torch.distributed collectives (rehearsal with --backend gloo --one-gpu)")
     args = ap.parse_args()
 
     import torch                                         # before libshk_hip.so: one HIP runtime
@@ -131,8 +135,8 @@ def main():
     sharded = world > 1 and args.mode == "sharded"
     if sharded:
         # one pooled sample: N isolates, every rank holds an equal share of reads drawn from all of them
-        from sparrowhawk_amd.dist import Comm, sharded_preprocess
-        comm = Comm(device=dev)
+        from sparrowhawk_amd.dist import Comm, LibComm, sharded_preprocess, sharded_preprocess_rccl
+        comm = Comm(device=dev) if args.collectives == "torch" else LibComm(rank, world)
         d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
             torch, dev, args.genome * world, args.coverage, args.read_len, 0xEC02, read_seed=0x5EED + rank,
             n_reads=(args.genome * args.coverage + args.read_len - 1) // args.read_len)
@@ -148,8 +152,10 @@ def main():
 
     def one_step(keep=False):
         h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
-        if sharded:
+        if sharded and args.collectives == "torch":
             sharded_preprocess(h, d_bases, d_seg, n_reads, n_bases, n_reads, comm)
+        elif sharded:
+            sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads, comm)
         else:
             h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
         h.assemble()
@@ -230,7 +236,9 @@ def main():
                                f"({n_reads} reads, {n_bases} bases per GPU), k={args.k}, min_count={args.min_count}, "
                                f"{'error-free' if args.err == 0 else ('%g substitution errors%s' % (args.err, ', masked by quality' if args.mask_errors else ''))}, packed 2-bit in HBM",
                    "parallelism": ("single GPU" if world == 1 else
-                                   "one pooled sample, k-mer space sharded by minimiser partition, one RCCL all-to-all"
+                                   ("one pooled sample, k-mer space sharded by minimiser partition, one RCCL pairwise exchange "
+                                    "inside the library (shk_shard_preprocess), graph phases replicated" if args.collectives == "lib"
+                                    else "one pooled sample, sharded, collectives by torch.distributed (" + args.backend + ")")
                                    if sharded else "one isolate per rank (batch of isolates), no data-path collective"),
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,

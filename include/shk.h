@@ -118,6 +118,36 @@ int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **
 int shk_shard_set_solid(shk_handle *h, const void *const *d_keys /* [W] */, const void *d_cnt,
                         uint64_t n_rows, uint64_t n_instances_global);
 
+/* ---- the same sequence with the collectives INSIDE the library: RCCL over xGMI (librccl.so.1, opened on
+ * first use).  One communicator per process and GPU.  The caller only distributes the 128-byte id that rank 0
+ * obtains from shk_comm_unique_id() (ncclGetUniqueId) by whatever channel it has (MPI, a TCP store, a file),
+ * then every rank — with its GPU current — calls shk_comm_init (ncclCommInitRank).  shk_shard_preprocess is
+ * collective over the communicator: every rank calls it with its own share of the reads (n_seg may be 0) and
+ * the same n_partitions (0 = chosen from the global instance count).  It runs
+ *   pass 1 -> all-gather of the per-partition record counts (the size exchange) -> pack -> ONE pairwise
+ *   exchange of the records (grouped ncclSend/ncclRecv) -> pass 2 over the owned partitions -> all-reduce
+ *   of histogram + instance count (501 x u64) -> fit / filter -> all-gather of the solid rows -> install,
+ * leaving every rank's handle "preprocessed" with the identical global solid set; shk_assemble() follows as
+ * usual.  A Rust host binds these five functions and never writes a collective itself. */
+#define SHK_UNIQUE_ID_BYTES 128
+typedef struct shk_comm shk_comm;
+int shk_comm_unique_id(uint8_t id[SHK_UNIQUE_ID_BYTES]);
+shk_comm *shk_comm_init(const uint8_t id[SHK_UNIQUE_ID_BYTES], int rank, int world);   /* NULL on failure */
+const char *shk_comm_error(void);        /* message of the last failed shk_comm_* call on this thread */
+int shk_comm_rank(const shk_comm *c);
+int shk_comm_world(const shk_comm *c);
+void shk_comm_free(shk_comm *c);
+int shk_shard_preprocess(shk_handle *h, shk_comm *c, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                         uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions);
+/* host-only: the exchange plan shk_shard_preprocess derives from the gathered record counts (exposed for the
+ * CPU tests).  part_records_all: [world][n_partitions].  Outputs (caller-allocated): base [n_partitions],
+ * send_counts / recv_counts [world], run_off / run_cnt [n_owned][world], n_owned = partitions p with
+ * p % world == rank. */
+int shk_plan_exchange(const uint64_t *part_records_all, uint32_t world, uint32_t n_partitions, uint32_t rank,
+                      uint64_t *base, uint64_t *send_counts, uint64_t *recv_counts, uint64_t *run_off,
+                      uint32_t *run_cnt);
+uint32_t shk_choose_partitions(uint64_t total_instances_ub, uint32_t world, uint32_t key_words);
+
 /* ---- host-side packer (the parser the preprocess entry points use), exposed so a caller can
  * stage packed reads in HBM itself (bench.py, the multi-GPU shard layer). */
 typedef struct shk_packed {

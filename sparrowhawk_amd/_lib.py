@@ -40,6 +40,15 @@ SIGNATURES = {
     "shk_shard_count": (_int, [_vp, _vp, _vp, _vp, _u32, _u32, _vp, _vp]),
     "shk_shard_rows": (_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "shk_shard_set_solid": (_int, [_vp, _vp, _vp, _u64, _u64]),
+    "shk_comm_unique_id": (_int, [_vp]),
+    "shk_comm_init": (_vp, [_vp, _int, _int]),
+    "shk_comm_error": (_cp, []),
+    "shk_comm_rank": (_int, [_vp]),
+    "shk_comm_world": (_int, [_vp]),
+    "shk_comm_free": (None, [_vp]),
+    "shk_shard_preprocess": (_int, [_vp, _vp, _vp, _vp, _u64, _u64, _u64, _u32]),
+    "shk_plan_exchange": (_int, [_vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "shk_choose_partitions": (_u32, [_u64, _u32, _u32]),
     "shk_pack_fastq": (_int, [_cp, _sz, _u32, _u32, C.POINTER(ShkPacked), C.POINTER(_cp)]),
     "shk_packed_free": (None, [C.POINTER(ShkPacked)]),
     "shk_key_words": (_u32, [_vp]),

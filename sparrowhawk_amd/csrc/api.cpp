@@ -16,6 +16,7 @@
 #include "fastq_gpu.h"
 #include "outputs.h"
 #include "pipeline.h"
+#include "shard_comm.h"
 
 namespace shk {
 bool spectrum_fit(const uint64_t *histo500, uint32_t *out);
@@ -28,7 +29,7 @@ namespace {
 thread_local int g_new_err = 0;
 thread_local std::string g_new_msg;
 
-enum class St { Fresh, Streaming, Sharding, Preprocessed, Assembled };
+enum class St { Fresh, Streaming, Sharding, Preprocessed, Assembled, Failed };
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -44,21 +45,53 @@ struct shk_handle {
     IPipeline *pipe = nullptr;
     shk_progress_cb cb = nullptr;
     void *cb_user = nullptr;
-    std::string err, pre_json, asm_json, timings_json;
+    std::string err, first_err, pre_json, asm_json, timings_json;
     uint64_t histo[SHK_HISTO_BINS] = {0};
     uint32_t used_min_count = 0;
     bool fit_ok = false;
     PackedReads stream_reads;          // shk_push_reads accumulator
     uint64_t n_reads = 0;
+    uint64_t batches_started = 0;      // batches handed to the pipeline (a failure after the first one poisons the handle)
     AssemblyText text;
 
     const char *mode() const { return do_bloom ? "bloom" : (chunk_size > 0 ? "chunked" : "bulk"); }
     void post(const std::string &s) { if (cb) cb(s.c_str(), cb_user); }
     void post_mode(const char *suffix) { post(std::string("preprocess:") + mode() + ":" + suffix); }
+    // `loop:start` / `loop:end` exist for bulk and bloom only: the reference UI defines no such state for the
+    // chunked mode (AssemblyPage.vue:548-579 has :start, :fitting, :filtering and :loop:<n>[:<pct>])
+    void post_loop_edge(const char *suffix) { if (do_bloom || chunk_size == 0) post_mode(suffix); }
     uint64_t progress_every() const { return (!do_bloom && chunk_size > 0) ? chunk_size : 100000; }
 };
 
 static int fail(shk_handle *h, int code, const std::string &msg) { h->err = msg; return code; }
+
+// Every entry point that touches the device runs with the HANDLE's device current (the HIP current device is
+// per thread and new threads start on device 0: an FFI consumer may call from any thread) and restores the
+// caller's device afterwards; no exception crosses the C ABI (shk.h: "never aborts").
+struct DevGuard {
+    int prev;
+    explicit DevGuard(int dev) : prev(set_device(dev)) {}
+    ~DevGuard() { (void)set_device(prev); }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+enum class Poison { Never, AfterFirstBatch, Always };
+template <typename F> static int guarded(shk_handle *h, Poison poison, F &&body) {
+    if (!h) return SHK_E_PARAM;
+    if (h->st == St::Failed) return fail(h, SHK_E_STATE, "the handle failed earlier (" + h->first_err + "): free it and start again");
+    DevGuard g(h->pipe ? h->pipe->device() : current_device());
+    int rc;
+    try { rc = body(); }
+    catch (const std::bad_alloc &) { rc = fail(h, SHK_E_OOM, "out of host memory"); }
+    catch (const std::exception &e) { rc = fail(h, SHK_E_INTERNAL, std::string("unexpected exception: ") + e.what()); }
+    catch (...) { rc = fail(h, SHK_E_INTERNAL, "unexpected exception"); }
+    // a failed call leaves counted batches / a half-built graph behind: a second attempt on the same handle
+    // would double-count them, so the handle only accepts shk_free / shk_last_error from here on
+    if (rc != SHK_OK && rc != SHK_E_STATE &&
+        (poison == Poison::Always || (poison == Poison::AfterFirstBatch && (h->batches_started > 0 || h->st == St::Sharding))))
+        { h->st = St::Failed; h->first_err = h->err; }
+    return rc;
+}
 
 extern "C" {
 
@@ -97,6 +130,7 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
 
 void shk_free(shk_handle *h) {
     if (!h) return;
+    DevGuard g(h->pipe ? h->pipe->device() : current_device());
     give_big_string(std::move(h->asm_json));
     delete h->pipe;
     delete h;
@@ -111,6 +145,7 @@ static int count_one_batch(shk_handle *h, const uint32_t *d_bases, const uint32_
                            uint64_t n_bases) {
     std::string err;
     const double t0 = now_ms();
+    h->batches_started++;
     int rc = h->pipe->count_batch(d_bases, d_seg_off, n_seg, n_bases, err);
     h->pipe->times().add("preprocess_device_total_host_clock", now_ms() - t0);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
@@ -121,7 +156,7 @@ static int count_one_batch(shk_handle *h, const uint32_t *d_bases, const uint32_
 static int finish_counting(shk_handle *h) {
     std::string err;
     const double t0 = now_ms();
-    h->post_mode("loop:end");
+    h->post_loop_edge("loop:end");
     if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
     // the fit never returns less than 1 and falls back to min_count (SPEC S6)
     const uint32_t emit_thr = h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
@@ -230,13 +265,14 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
             off = end;
         }
     }
-    const int device = current_device();
+    const int device = h->pipe->device();
     uint64_t reads_done = 0, file_reads = 0;
     bool counted_any = false;
     const double t0 = now_ms();
     GpuText cur, nxt;
     bool have_cur = false;
-    std::thread uploader;
+    struct Joining { std::thread t; ~Joining() { if (t.joinable()) t.join(); } } upl;   // joined on every way out, exceptions included
+    std::thread &uploader = upl.t;
     int up_rc = 0; std::string up_err;
     auto join_upload = [&]() { if (uploader.joinable()) uploader.join(); };
     auto drop_all = [&]() { join_upload(); gpu_text_free(cur); gpu_text_free(nxt); };
@@ -279,7 +315,10 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
         if (prefetch) {
             const Piece nx = pieces[i + 1];
             const uint8_t *tn = nx.file ? t2 : t1;
-            uploader = std::thread([&, nx, tn]() { up_rc = gpu_upload_text(tn + nx.off, nx.end - nx.off, device, nxt, up_err); });
+            uploader = std::thread([&, nx, tn]() {
+                try { up_rc = gpu_upload_text(tn + nx.off, nx.end - nx.off, device, nxt, up_err); }
+                catch (...) { up_rc = -4; up_err = "out of host memory (uploader)"; }
+            });
         }
         GpuPacked gp;
         int rc = gpu_pack_fastq(nullptr, 0, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, reads_done, &cur);
@@ -324,13 +363,13 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
     return finish_counting(h);
 }
 
-int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
+static int preprocess_impl(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used (Assembler.ts:92: one preprocess per handle)");
     if (!fq1) return fail(h, SHK_E_PARAM, "preprocess: file1 is required");
     h->post("preprocess:start");
     h->post_mode("start");
-    h->post_mode("loop:start");
+    h->post_loop_edge("loop:start");
     std::string err;
     const double t0 = now_ms();
     const size_t total = n1 + (fq2 ? n2 : 0);
@@ -399,11 +438,11 @@ int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *
     return finish_counting(h);
 }
 
-int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
+static int push_reads_impl(shk_handle *h, const uint8_t *chunk, size_t n) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Fresh && h->st != St::Streaming) return fail(h, SHK_E_STATE, "push_reads: handle already preprocessed");
     if (h->st == St::Fresh) {
-        h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+        h->post("preprocess:start"); h->post_mode("start"); h->post_loop_edge("loop:start");
         h->st = St::Streaming;
     }
     std::string err;
@@ -446,7 +485,7 @@ int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
     return SHK_OK;
 }
 
-int shk_finish_reads(shk_handle *h) {
+static int finish_reads_impl(shk_handle *h) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Streaming) return fail(h, SHK_E_STATE, "finish_reads: no reads pushed");
     h->n_reads = h->stream_reads.n_reads;
@@ -456,12 +495,12 @@ int shk_finish_reads(shk_handle *h) {
     return finish_counting(h);
 }
 
-int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+static int preprocess_packed_device_impl(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
                                  uint64_t n_bases, uint64_t n_reads) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used");
     if (!d_bases || !d_seg_off) return fail(h, SHK_E_PARAM, "null device pointer");
-    h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+    h->post("preprocess:start"); h->post_mode("start"); h->post_loop_edge("loop:start");
     h->n_reads = n_reads;
     h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
     return run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_seg_off, n_seg, n_bases);
@@ -472,11 +511,11 @@ static uint32_t emit_threshold_of(const shk_handle *h) {
     return h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
 }
 
-int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+static int shard_partition_impl(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg, uint64_t n_bases,
                         uint64_t n_reads, uint32_t n_partitions, uint64_t *part_records) {
     if (!h || !part_records) return SHK_E_PARAM;
     if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "shard_partition: handle already used");
-    h->post("preprocess:start"); h->post_mode("start"); h->post_mode("loop:start");
+    h->post("preprocess:start"); h->post_mode("start"); h->post_loop_edge("loop:start");
     h->n_reads = n_reads;
     std::vector<uint64_t> pr;
     std::string err;
@@ -484,14 +523,14 @@ int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_of
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
     memcpy(part_records, pr.data(), (size_t)n_partitions * 8);
     h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
-    h->post_mode("loop:end");
+    h->post_loop_edge("loop:end");
     h->st = St::Sharding;
     return SHK_OK;
 }
 
 uint32_t shk_shard_record_bytes(shk_handle *h) { return h && h->pipe ? h->pipe->rec_words() * 8u : 0u; }
 
-int shk_shard_pack(shk_handle *h, void *d_send, const uint64_t *base_records, uint32_t n_partitions) {
+static int shard_pack_impl(shk_handle *h, void *d_send, const uint64_t *base_records, uint32_t n_partitions) {
     if (!h || !base_records) return SHK_E_PARAM;
     if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_pack: call shard_partition first");
     std::string err;
@@ -499,7 +538,7 @@ int shk_shard_pack(shk_handle *h, void *d_send, const uint64_t *base_records, ui
     return rc ? fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err) : SHK_OK;
 }
 
-int shk_shard_count(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
+static int shard_count_impl(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
                     uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local, uint64_t *n_instances_local) {
     if (!h || !histo500_local) return SHK_E_PARAM;
     if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_count: call shard_partition first");
@@ -511,7 +550,7 @@ int shk_shard_count(shk_handle *h, const void *d_recv, const uint64_t *run_off, 
     return SHK_OK;
 }
 
-int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **d_keys, const void **d_cnt,
+static int shard_rows_impl(shk_handle *h, const uint64_t *histo500_global, const void **d_keys, const void **d_cnt,
                    uint64_t *n_rows, uint32_t *used_min_count) {
     if (!h || !histo500_global || !d_keys || !d_cnt || !n_rows) return SHK_E_PARAM;
     if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_rows: call shard_count first");
@@ -530,7 +569,7 @@ int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **
     return SHK_OK;
 }
 
-int shk_shard_set_solid(shk_handle *h, const void *const *d_keys, const void *d_cnt, uint64_t n_rows,
+static int shard_set_solid_impl(shk_handle *h, const void *const *d_keys, const void *d_cnt, uint64_t n_rows,
                         uint64_t n_instances_global) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_set_solid: call shard_rows first");
@@ -550,7 +589,7 @@ const char *shk_get_preprocessing_info(shk_handle *h) {
     return h->pre_json.c_str();
 }
 
-int shk_assemble(shk_handle *h) {
+static int assemble_impl(shk_handle *h) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Preprocessed) return fail(h, SHK_E_STATE, "assemble: preprocess first (and only once)");
     std::string err;
@@ -608,13 +647,13 @@ uint64_t shk_n_distinct(shk_handle *h) { return h && h->pipe ? h->pipe->n_distin
 uint64_t shk_n_solid(shk_handle *h) { return h && h->pipe ? h->pipe->n_solid() : 0; }
 uint32_t shk_used_min_count(shk_handle *h) { return h ? h->used_min_count : 0; }
 
-int shk_get_distinct(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+static int get_distinct_impl(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Preprocessed) return fail(h, SHK_E_STATE, "get_distinct: only between preprocess and assemble");
     std::string err; int rc = h->pipe->get_distinct(keys, counts, cap, err);
     return rc ? fail(h, rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE, err) : SHK_OK;
 }
-int shk_get_solid(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+static int get_solid_impl(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Preprocessed && h->st != St::Assembled) return fail(h, SHK_E_STATE, "get_solid before preprocess");
     std::string err; int rc = h->pipe->get_solid(keys, counts, cap, err);
@@ -626,7 +665,7 @@ int shk_get_histo(shk_handle *h, uint64_t *histo500) {
     memcpy(histo500, h->histo, sizeof h->histo);
     return SHK_OK;
 }
-int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive, uint64_t cap) {
+static int get_adjacency_impl(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive, uint64_t cap) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Assembled) return fail(h, SHK_E_STATE, "get_adjacency before assemble");
     std::string err; int rc = h->pipe->get_adjacency(adj_initial, adj_final, alive, cap, err);
@@ -634,6 +673,7 @@ int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, u
 }
 const char *shk_get_timings(shk_handle *h) {
     if (!h || !h->pipe) return "{}";
+    DevGuard g(h->pipe->device());
     std::string j = "{";
     bool first = true;
     for (auto &kv : h->pipe->times().ms) {
@@ -645,6 +685,183 @@ const char *shk_get_timings(shk_handle *h) {
     j += "}";
     h->timings_json.swap(j);
     return h->timings_json.c_str();
+}
+
+// ---- collectives inside the library (shard_comm.hip: RCCL) ---------------------------------------------
+struct shk_comm { ShardComm *c = nullptr; };
+static thread_local std::string g_comm_err;
+
+static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                                 uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions) {
+    if (!cm || !cm->c) return fail(h, SHK_E_PARAM, "shard_preprocess: null communicator");
+    if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "shard_preprocess: handle already used");
+    if (comm_device(cm->c) != h->pipe->device()) return fail(h, SHK_E_PARAM, "shard_preprocess: communicator and handle live on different devices");
+    ShardComm *c = cm->c;
+    const uint32_t world = (uint32_t)comm_world(c), rank = (uint32_t)comm_rank(c);
+    const uint32_t W = (2 * h->k + 63) / 64;
+    void *st = h->pipe->stream();
+    std::string err;
+    auto cfail = [&](int rc) { return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); };
+    const double t0 = now_ms();
+    // ---- the partition count must be the same everywhere: from the global instance count
+    if (n_partitions == 0) {
+        uint64_t inst = n_bases > n_seg * (uint64_t)(h->k - 1) ? n_bases - n_seg * (uint64_t)(h->k - 1) : 0;
+        if (int rc = comm_allreduce_host_u64(c, &inst, 1, st, err)) return cfail(rc);
+        n_partitions = choose_partitions(inst, world, W == 1 ? 100000 : 40000);
+    }
+    if (n_partitions < world) return fail(h, SHK_E_PARAM, "shard_preprocess: fewer partitions than ranks");
+    const uint32_t P = n_partitions;
+    // ---- pass 1 on this rank's reads
+    std::vector<uint64_t> part(P, 0);
+    if (int rc = shard_partition_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads, P, part.data())) return rc;
+    // ---- the size exchange: every rank learns what every rank holds per partition
+    std::vector<uint64_t> all((size_t)world * P);
+    if (int rc = comm_allgather_host_u64(c, part.data(), P, all.data(), st, err)) return cfail(rc);
+    ExchangePlan plan;
+    if (int rc = plan_exchange(all.data(), world, P, rank, plan, err)) return cfail(rc);
+    const uint64_t rec_bytes = (uint64_t)h->pipe->rec_words() * 8u;
+    uint64_t n_send = 0, n_recv = 0;
+    for (uint32_t r = 0; r < world; r++) { n_send += plan.send_counts[r]; n_recv += plan.recv_counts[r]; }
+    // ---- pack (destination-major) and exchange
+    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, gk[4], gc;
+    send.bytes = (size_t)(n_send * rec_bytes + 64); send.p = device_pool_alloc(send.bytes);
+    recv.bytes = (size_t)(n_recv * rec_bytes + 64); recv.p = device_pool_alloc(recv.bytes);
+    if (!send.p || !recv.p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
+    if (int rc = shard_pack_impl(h, send.p, plan.base.data(), P)) return rc;
+    {
+        std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
+        uint64_t a = 0, b = 0;
+        for (uint32_t r = 0; r < world; r++) {
+            so[r] = a; sb[r] = plan.send_counts[r] * rec_bytes; a += sb[r];
+            ro[r] = b; rb[r] = plan.recv_counts[r] * rec_bytes; b += rb[r];
+        }
+        const double tx = now_ms();
+        if (int rc = comm_alltoallv(c, send.p, so.data(), sb.data(), recv.p, ro.data(), rb.data(), st, err)) return cfail(rc);
+        if (int rc = device_stream_sync(st, err)) return cfail(rc);
+        h->pipe->times().add("shard_exchange_host_clock", now_ms() - tx);
+        h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * rec_bytes) / 1e6);
+    }
+    device_pool_release(send.p, send.bytes); send.p = nullptr;
+    // ---- pass 2 over the owned partitions, then the global histogram
+    uint64_t red[SHK_HISTO_BINS + 1] = {0};
+    if (int rc = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
+                                  &red[SHK_HISTO_BINS])) return rc;
+    if (int rc = comm_allreduce_host_u64(c, red, SHK_HISTO_BINS + 1, st, err)) return cfail(rc);
+    // ---- fit / filter (identical on every rank), local solid rows
+    const void *keys[4] = {nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
+    uint64_t n_local = 0; uint32_t used = 0;
+    if (int rc = shard_rows_impl(h, red, keys, &cnt, &n_local, &used)) return rc;
+    // ---- all-gather of the solid rows
+    std::vector<uint64_t> counts(world);
+    if (int rc = comm_allgather_host_u64(c, &n_local, 1, counts.data(), st, err)) return cfail(rc);
+    uint64_t n_total = 0;
+    std::vector<uint64_t> off8(world), len8(world), off4(world), len4(world);
+    for (uint32_t r = 0; r < world; r++) { off8[r] = n_total * 8; len8[r] = counts[r] * 8; off4[r] = n_total * 4; len4[r] = counts[r] * 4; n_total += counts[r]; }
+    for (uint32_t j = 0; j < W; j++) {
+        gk[j].bytes = (size_t)(n_total * 8 + 64); gk[j].p = device_pool_alloc(gk[j].bytes);
+        if (!gk[j].p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
+        if (int rc = comm_allgatherv(c, keys[j], gk[j].p, off8.data(), len8.data(), st, err)) return cfail(rc);
+    }
+    gc.bytes = (size_t)(n_total * 4 + 64); gc.p = device_pool_alloc(gc.bytes);
+    if (!gc.p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
+    if (int rc = comm_allgatherv(c, cnt, gc.p, off4.data(), len4.data(), st, err)) return cfail(rc);
+    if (int rc = device_stream_sync(st, err)) return cfail(rc);
+    const void *kp[4] = {gk[0].p, gk[1].p, gk[2].p, gk[3].p};
+    if (int rc = shard_set_solid_impl(h, kp, gc.p, n_total, red[SHK_HISTO_BINS])) return rc;
+    h->pipe->times().add("shard_preprocess_host_clock", now_ms() - t0);
+    return SHK_OK;
+}
+
+int shk_comm_unique_id(uint8_t id[SHK_UNIQUE_ID_BYTES]) {
+    try { return comm_unique_id(id, g_comm_err) == 0 ? SHK_OK : SHK_E_DEVICE; }
+    catch (...) { g_comm_err = "unexpected exception"; return SHK_E_INTERNAL; }
+}
+shk_comm *shk_comm_init(const uint8_t id[SHK_UNIQUE_ID_BYTES], int rank, int world) {
+    try {
+        if (!id) { g_comm_err = "null id"; return nullptr; }
+        ShardComm *c = comm_create(id, rank, world, g_comm_err);
+        if (!c) return nullptr;
+        shk_comm *w = new (std::nothrow) shk_comm();
+        if (!w) { comm_destroy(c); g_comm_err = "out of host memory"; return nullptr; }
+        w->c = c;
+        return w;
+    } catch (...) { g_comm_err = "unexpected exception"; return nullptr; }
+}
+const char *shk_comm_error(void) { return g_comm_err.c_str(); }
+int shk_comm_rank(const shk_comm *c) { return c ? comm_rank(c->c) : 0; }
+int shk_comm_world(const shk_comm *c) { return c ? comm_world(c->c) : 0; }
+void shk_comm_free(shk_comm *c) {
+    if (!c) return;
+    DevGuard g(comm_device(c->c));
+    comm_destroy(c->c);
+    delete c;
+}
+int shk_shard_preprocess(shk_handle *h, shk_comm *c, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                         uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_preprocess_impl(h, c, d_bases, d_seg_off, n_seg, n_bases, n_reads, n_partitions); });
+}
+int shk_plan_exchange(const uint64_t *part_records_all, uint32_t world, uint32_t n_partitions, uint32_t rank,
+                      uint64_t *base, uint64_t *send_counts, uint64_t *recv_counts, uint64_t *run_off, uint32_t *run_cnt) {
+    try {
+        ExchangePlan pl; std::string err;
+        if (!base || !send_counts || !recv_counts || !run_off || !run_cnt) return SHK_E_PARAM;
+        if (plan_exchange(part_records_all, world, n_partitions, rank, pl, err)) return SHK_E_PARAM;
+        memcpy(base, pl.base.data(), pl.base.size() * 8);
+        memcpy(send_counts, pl.send_counts.data(), (size_t)world * 8);
+        memcpy(recv_counts, pl.recv_counts.data(), (size_t)world * 8);
+        memcpy(run_off, pl.run_off.data(), pl.run_off.size() * 8);
+        memcpy(run_cnt, pl.run_cnt.data(), pl.run_cnt.size() * 4);
+        return SHK_OK;
+    } catch (...) { return SHK_E_OOM; }
+}
+uint32_t shk_choose_partitions(uint64_t total_instances_ub, uint32_t world, uint32_t key_words) {
+    return choose_partitions(total_instances_ub, world ? world : 1, key_words <= 1 ? 100000 : 40000);
+}
+
+// ---- the guarded entry points (device guard, no exception across the ABI, failed-handle state) ----
+int shk_preprocess(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return preprocess_impl(h, fq1, n1, fq2, n2); });
+}
+int shk_push_reads(shk_handle *h, const uint8_t *chunk, size_t n) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return push_reads_impl(h, chunk, n); });
+}
+int shk_finish_reads(shk_handle *h) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return finish_reads_impl(h); });
+}
+int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
+                                 uint64_t n_bases, uint64_t n_reads) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return preprocess_packed_device_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads); });
+}
+int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg, uint64_t n_bases,
+                        uint64_t n_reads, uint32_t n_partitions, uint64_t *part_records) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_partition_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads, n_partitions, part_records); });
+}
+int shk_shard_pack(shk_handle *h, void *d_send, const uint64_t *base_records, uint32_t n_partitions) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_pack_impl(h, d_send, base_records, n_partitions); });
+}
+int shk_shard_count(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
+                    uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local, uint64_t *n_instances_local) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_count_impl(h, d_recv, run_off, run_cnt, n_owned, n_sources, histo500_local, n_instances_local); });
+}
+int shk_shard_rows(shk_handle *h, const uint64_t *histo500_global, const void **d_keys, const void **d_cnt,
+                   uint64_t *n_rows, uint32_t *used_min_count) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_rows_impl(h, histo500_global, d_keys, d_cnt, n_rows, used_min_count); });
+}
+int shk_shard_set_solid(shk_handle *h, const void *const *d_keys, const void *d_cnt, uint64_t n_rows,
+                        uint64_t n_instances_global) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_set_solid_impl(h, d_keys, d_cnt, n_rows, n_instances_global); });
+}
+int shk_assemble(shk_handle *h) {
+    return guarded(h, Poison::Always, [&] { return assemble_impl(h); });
+}
+int shk_get_distinct(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+    return guarded(h, Poison::Never, [&] { return get_distinct_impl(h, keys, counts, cap); });
+}
+int shk_get_solid(shk_handle *h, uint64_t *keys, uint32_t *counts, uint64_t cap) {
+    return guarded(h, Poison::Never, [&] { return get_solid_impl(h, keys, counts, cap); });
+}
+int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive, uint64_t cap) {
+    return guarded(h, Poison::Never, [&] { return get_adjacency_impl(h, adj_initial, adj_final, alive, cap); });
 }
 
 // ---- host-only self tests --------------------------------------------------------------------

@@ -25,6 +25,14 @@
 #include <type_traits>
 #include "kmer.h"
 
+// Timing experiments (parts of a kernel switched off: wrong results) exist only in `make ABLATE=1` builds,
+// which produce libshk_hip_ablate.so; in the shipped library every SHK_DBG(...) is the constant 0 and the
+// branches behind it are compiled out (they also cost registers in kernels that run one workgroup per CU).
+#ifndef SHK_ABLATE
+#define SHK_ABLATE 0
+#endif
+#define SHK_DBG(x) (SHK_ABLATE ? (uint32_t)(x) : 0u)
+
 namespace shk {
 
 static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
@@ -157,7 +165,8 @@ __device__ __forceinline__ void part_store_record(const uint64_t (&out)[RW], uin
 template <int RW>
 __device__ __noinline__ void wave_flush(SHK_LDS PartShared *sh_l, const SHK_LDS uint32_t *stage_l, uint32_t wave, uint32_t cnt,
                                         int k, uint32_t G, uint32_t slice_cap, uint32_t g, SHK_GLOBAL uint64_t *recs_g,
-                                        uint32_t dbg = 0) {
+                                        uint32_t dbg_arg = 0) {
+    const uint32_t dbg = SHK_DBG(dbg_arg);
     PartShared *sh = (PartShared *)sh_l;                 // address space is inferred from the cast
     uint64_t *recs = (uint64_t *)recs_g;
     const uint32_t *stage = (const uint32_t *)stage_l;
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 for (int t = 0; t < WBLK; t++) {
                     if (t % DESC_CHECK == 0) {
                         if (__ballot(dcnt > flush_at)) {                    // wave-uniform
-                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore);
+                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore));
                             dcnt = 0;
                         }
                     }
@@ -359,9 +368,9 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 else do_block(std::false_type{}, bq);
             }
             // close the last run of every segment (it ends with the segment's last k-mer)
-            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore); dcnt = 0; }
+            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore)); dcnt = 0; }
             if (run_p != NO_RUN) emit(L - (uint32_t)k + 1u);
-            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, pp.dbg_nostore);
+            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore));
             // ---- the next tile replaces this one once every wave has finished reading it
             __syncthreads();
             if (have_nxt) {
@@ -455,11 +464,22 @@ template <int W> __device__ __forceinline__ uint32_t km_mix32(const Kmer<W> &x) 
     return h;
 }
 
+// Counts are u32 and SATURATE at 0xFFFFFFFF (SPEC S4).  A count can only pass 2^32 when its partition holds
+// that many k-mer instances, which the caller knows before it starts (records x k-mers per record): `sat` is
+// uniform per partition and false for everything but such giants, so the common path keeps its no-return add.
+// Saturating form: an add that wrapped pins the count to the top; every later add wraps again and repairs it,
+// so whatever the interleaving the count reads 0xFFFFFFFF once the adds are done (the emit scan is behind a barrier).
+__device__ __forceinline__ void cnt_add(uint32_t *c, uint32_t weight, bool sat) {
+    if (!sat) { atomicAdd(c, weight); return; }
+    const uint32_t old = atomicAdd(c, weight);
+    if (old > 0xFFFFFFFFu - weight) atomicMax(c, 0xFFFFFFFFu);
+}
+
 // insert into the LDS table; returns false when the probe sequence is exhausted
 // (COUNT_USED = false: the caller keeps ctl.n_used itself from the return value 2 = "new key")
 template <int W, bool COUNT_USED = true>
 __device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtlCore &ctl, const Kmer<W> &key, uint32_t h,
-                                          uint32_t weight) {
+                                          uint32_t weight, bool sat = false) {
     constexpr uint32_t S = KmerTable<W>::S;
     if constexpr (W == 1) {
         // 4-way buckets: the whole bucket comes back from one pair of 16-byte LDS reads, so a hit
@@ -479,13 +499,13 @@ __device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtlCore &ctl, c
                 const unsigned long long old = atomicCAS((unsigned long long *)&tb.key0[4 * b + e], ~0ull, kk);
                 if (old == ~0ull) {
                     if constexpr (COUNT_USED) atomicAdd(&ctl.n_used, 1u);
-                    atomicAdd(&tb.cnt[4 * b + e], weight);
+                    cnt_add(&tb.cnt[4 * b + e], weight, sat);
                     return 2;
                 }
                 else if (old == kk) j = e;
                 else continue;                              // lost the slot to another key: look again
             }
-            atomicAdd(&tb.cnt[4 * b + j], weight);
+            cnt_add(&tb.cnt[4 * b + j], weight, sat);
             return 1;
         }
         return 0;
@@ -501,14 +521,14 @@ __device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtlCore &ctl, c
                 for (int j = 0; j < W; j++) tb.key[j][slot] = key.w[j];
                 __hip_atomic_store(&tb.state[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if constexpr (COUNT_USED) atomicAdd(&ctl.n_used, 1u);
-                atomicAdd(&tb.cnt[slot], weight);
+                cnt_add(&tb.cnt[slot], weight, sat);
                 return 2;
             }
             if (st == 1) continue;                          // owner is mid-write
             bool eq = true;
 #pragma unroll
             for (int j = 0; j < W; j++) eq = eq && tb.key[j][slot] == key.w[j];
-            if (eq) { atomicAdd(&tb.cnt[slot], weight); return 1; }
+            if (eq) { cnt_add(&tb.cnt[slot], weight, sat); return 1; }
             slot = slot + 1 == S ? 0 : slot + 1;
             if (++probes >= 48u) return 0;              // table (locally) full: the caller splits the class
         }
@@ -576,8 +596,9 @@ template <int W, typename LT>
 __device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtlCore &ctl, unsigned long long mine, uint32_t threshold,
                                            unsigned long long *__restrict__ histo, KeyArr<W> out_keys,
                                            uint32_t *__restrict__ out_cnt, unsigned long long out_cap,
-                                           unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg = 0,
+                                           unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg_arg = 0,
                                            uint32_t *hist_accum = nullptr /* LDS: the round's histogram is added here instead of to `histo` */) {
+    const uint32_t dbg = SHK_DBG(dbg_arg);
     constexpr uint32_t S = KmerTable<W>::S;
     const int lane = threadIdx.x & 63;
     if (dbg == 10) return;                                  // (timing experiments 10, 11, 4: stop after successive stages)
@@ -817,7 +838,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     load_runs(pi + gridDim.x, nx_cnt, nx_addr);          // the next partition's run table: in flight during this one
    [&]() {                                              // one partition; `return` = done with it
     const uint32_t R = ctl.pre[S_runs];
-    if (rvw.dbg == 5) return;                            // timing experiment: launch + run prefix only
+    // a k-mer count can only reach 2^32 (SPEC S4: saturating) in a partition of >= 2^32 instances = R x (<= 64 per record)
+    const bool sat = R >= (1u << 26);
+    if (SHK_DBG(rvw.dbg) == 5) return;                            // timing experiment: launch + run prefix only
 
     // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets): report the
     // estimated number of distinct k-mers (distinct / instance ratio of what was inserted before the table
@@ -911,7 +934,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
                 const uint32_t h = km_mix32<W>(c);
                 if (mod == 1 || ((h >> 20) & (mod - 1u)) == res) {         // sub-round filter: bits 20.. of h
-                    if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), weight)) ctl.overflow = 1;
+                    if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), weight, sat)) ctl.overflow = 1;
                     mine += weight;
                 }
             }
@@ -923,21 +946,21 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         uint32_t have_nxt = fetch(w_begin + (uint32_t)lane, nxt);
         uint32_t have_nxt2 = fetch(w_begin + 64u + (uint32_t)lane, nxt2);
         if (threadIdx.x == 0) ctl.prog_den = R ? R : 1u;
-        for (uint32_t r0 = w_begin; r0 < (rvw.dbg == 6 ? w_begin : w_end); r0 += 64) {
+        for (uint32_t r0 = w_begin; r0 < (SHK_DBG(rvw.dbg) == 6 ? w_begin : w_end); r0 += 64) {
             // the table filled up: stop early (every insert into a full table walks a long probe chain);
             // how far this round got (all waves advance alike) sizes the split
             if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, min(R, (r0 - w_begin) * (COUNT_THREADS / 64) + 1u)); break; }
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
             // one spelling per locus (pass 1 is bound by its instruction issue, this pass by latencies: done here)
-            if (n && rvw.dbg != 11) rec_canonicalise<RW>(rec.w, n, k);
+            if (n && SHK_DBG(rvw.dbg) != 11) rec_canonicalise<RW>(rec.w, n, k);
             nxt = nxt2; have_nxt = have_nxt2;
             have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
             // phase A: identical records (the same genomic run seen in many reads) are counted
             // once here and expanded once, with their multiplicity, in phase B
-            if (rvw.dbg == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
-            else if (rvw.dbg == 2) { if (n) expand(rec, n, 1u); }
-            else if (rvw.dbg == 7) { if (n) (void)rec_insert<W>(tb.rt, ctl, rec); }      // timing experiment: dedupe only
+            if (SHK_DBG(rvw.dbg) == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
+            else if (SHK_DBG(rvw.dbg) == 2) { if (n) expand(rec, n, 1u); }
+            else if (SHK_DBG(rvw.dbg) == 7) { if (n) (void)rec_insert<W>(tb.rt, ctl, rec); }      // timing experiment: dedupe only
             else if (n && !rec_insert<W>(tb.rt, ctl, rec)) {
                 // the record table is saturated.  If that happens in the first half of the records, most of
                 // them are unique (error-rich reads): their k-mers cannot fit the k-mer table either, so the
@@ -946,7 +969,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 else expand(rec, n, 1u);
             }
         }
-        if (rvw.dbg == 10) return;                          // timing experiment: phase A only, no phase B
+        if (SHK_DBG(rvw.dbg) == 10) return;                          // timing experiment: phase A only, no phase B
         {
             // phase B: every distinct record once, weighted.  The occupied slots are first listed in
             // order of record length (counting sort in LDS) so that the 64 records a wave expands
@@ -955,7 +978,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             auto &rt = tb.rt;
             if (threadIdx.x < 64) rt.nhist[threadIdx.x] = 0;
             __syncthreads();
-            if (rvw.dbg != 3)
+            if (SHK_DBG(rvw.dbg) != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
                 if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u);
             __syncthreads();
@@ -967,30 +990,30 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
                 if (threadIdx.x == 63) ctl.n_recs = incl;
             }
             __syncthreads();
-            if (rvw.dbg != 3)
+            if (SHK_DBG(rvw.dbg) != 3)
             for (uint32_t s = threadIdx.x; s < SRc; s += COUNT_THREADS)
                 if (rt.rst[s] >= 3u) rt.order[atomicAdd(&rt.nbase[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u)] = (uint16_t)s;
             __syncthreads();
             uint32_t n_recs = ctl.n_recs;
-            if (rvw.dbg == 3) n_recs = SRc;                 // timing experiment: slot order instead of length order
+            if (SHK_DBG(rvw.dbg) == 3) n_recs = SRc;                 // timing experiment: slot order instead of length order
             // (a table that filled up in phase A keeps its progress mark; phase B then stops at once)
             if (threadIdx.x == 0 && ctl.prog_num == 0) ctl.prog_den = n_recs ? n_recs : 1u;
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_recs; i += COUNT_THREADS) {
                 if (ctl.overflow || ctl.n_used > (S / 10) * 9) { atomicMax(&ctl.prog_num, i - threadIdx.x + 1u); break; }
-                const uint32_t s = rvw.dbg == 3 ? i : rt.order[i];
-                if (rvw.dbg == 3 && rt.rst[s] < 3u) continue;
+                const uint32_t s = SHK_DBG(rvw.dbg) == 3 ? i : rt.order[i];
+                if (SHK_DBG(rvw.dbg) == 3 && rt.rst[s] < 3u) continue;
                 Rec<RW> rec;
 #pragma unroll
                 for (int o = 0; o < RW; o++) rec.w[o] = rt.w[s][o];
-                if (rvw.dbg != 1) expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
+                if (SHK_DBG(rvw.dbg) != 1) expand(rec, (uint32_t)(rec.w[RW - 1] >> 58) + 1u, rt.rst[s] - 2u);
             }
         }
         __syncthreads();
         const bool over = ctl.overflow != 0 || ctl.n_used > (S / 10) * 9;
-        if (rvw.dbg == 8) return;                           // timing experiment: no defer / emit work at all
+        if (SHK_DBG(rvw.dbg) == 8) return;                           // timing experiment: no defer / emit work at all
         if (over && ovf && mod == 1) {
-            if (rvw.dbg == 9) return;                       // timing experiment: overflow detected, nothing reported
+            if (SHK_DBG(rvw.dbg) == 9) return;                       // timing experiment: overflow detected, nothing reported
             defer(mine, true);
             return;
         }
@@ -1131,7 +1154,8 @@ __global__ __launch_bounds__(COUNT_THREADS, 8) void k_count_buckets(   // 8 wave
     const BucketRef *__restrict__ list, uint32_t n_list, const uint64_t *__restrict__ kmers,
     uint32_t threshold, unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
-    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg /* timing experiments (SHK_DEBUG_B) */) {
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg_arg /* timing experiments (ABLATE builds) */) {
+    const uint32_t dbg = SHK_DBG(dbg_arg);
     constexpr uint32_t S = KmerTable<W>::S;
     // k-mers per thread that travel in registers: covers the bucket size the host aims for (<= 1.1 S, binomial
     // spread of a few per cent); the rare longer bucket is read from memory by the residue path below

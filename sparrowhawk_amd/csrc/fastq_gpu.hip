@@ -68,7 +68,14 @@ static inline unsigned grid1(uint64_t work, unsigned block = 256, unsigned cap =
 
 struct Scratch {                                  // blocks of the process-wide device pool, returned on scope exit
     std::vector<std::pair<void *, size_t>> ptrs;
-    ~Scratch() { for (auto &p : ptrs) if (p.first) device_pool_release(p.first, p.second); }
+    hipStream_t st = nullptr; bool bound = false;     // the stream the blocks are used on
+    void bind(hipStream_t s) { st = s; bound = true; }
+    // the pool has no stream-ordering bookkeeping: a block may be handed to another stream's user (the uploader
+    // thread) at once, so kernels still in flight on an early error return are waited for before the release
+    ~Scratch() {
+        if (bound && !ptrs.empty()) (void)hipStreamSynchronize(st);
+        for (auto &p : ptrs) if (p.first) device_pool_release(p.first, p.second);
+    }
     template <typename T> T *get(size_t count, std::string &err) {
         size_t bytes = (count ? count : 1) * sizeof(T);
         void *p = device_pool_alloc(bytes);
@@ -174,7 +181,6 @@ struct FqParams {
     uint64_t n_lines;      // '\n' count (+1 if the text does not end with one)
     uint64_t n_nl;         // '\n' count
     uint32_t k, min_qual;
-    uint32_t dbg;          // timing experiments only (SHK_DEBUG_FQ)
 };
 
 __device__ __forceinline__ uint32_t base_code(uint8_t c) {
@@ -440,7 +446,7 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
                    const GpuText *uploaded) {
     hipStream_t st = (hipStream_t)stream_v;
     out = GpuPacked();
-    Scratch sc;
+    Scratch sc; sc.bind(st);
     if (uploaded && t2) { err = "an uploaded text cannot be combined with a second file"; return -1; }
     // ---- framing that can be decided on the host: trailing blank lines are ignored, the last line of a
     // file may lack its newline (one is supplied between the files)
@@ -481,7 +487,7 @@ int gpu_pack_fastq(const uint8_t *t1, size_t n1, const uint8_t *t2, size_t n2, u
     unsigned long long n_nl = 0;
     FQCHK(hipMemcpyAsync(&n_nl, d_tot, 8, hipMemcpyDeviceToHost, st));
     FQCHK(hipStreamSynchronize(st));
-    FqParams fp; fp.n = e; fp.n_nl = n_nl; fp.n_lines = n_nl + (unterminated ? 1 : 0); fp.k = k; fp.min_qual = min_qual; { const char *dv = getenv("SHK_DEBUG_FQ"); fp.dbg = dv ? (uint32_t)atoi(dv) : 0u; }
+    FqParams fp; fp.n = e; fp.n_nl = n_nl; fp.n_lines = n_nl + (unterminated ? 1 : 0); fp.k = k; fp.min_qual = min_qual;
     fp.part2_off = off2; fp.part1_len = e1; fp.part1_reads = 0;
     if (fp.n_lines % 4 != 0) return 1;                    // irregular framing: the host parser decides
     const uint64_t n_reads = fp.n_lines / 4;

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
     }
     __syncthreads();
     if (in_lds && !KEYS_IN_LDS) for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = tab[t];
-    if (gt.dbg == 1) { if (threadIdx.x == 0) qcnt[P] = 0; return; }     // timing experiment: table build only
+    if (SHK_DBG(gt.dbg) == 1) { if (threadIdx.x == 0) qcnt[P] = 0; return; }     // timing experiment: table build only
     // ---- neighbours
     unsigned long long *myq = queries + 8ull * r0;
     const int lane = threadIdx.x & 63;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         if (act) {
             x = keys.load(i);
             rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
-            if (gt.dbg != 2) ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);      // (2: timing experiment without the scan)
+            if (SHK_DBG(gt.dbg) != 2) ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);      // (2: timing experiment without the scan)
             out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer
             last_b = km_base<W>(x, k, (int)gm - 1);                // last base of the first gm-mer
         }
@@ -353,9 +353,9 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
                 p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash_lut(ms.last, out_b, j, lut))
                            : min(ms.min_wo_last, nt32_prev_hash_lut(ms.first, j - 4u, last_b, lut))) & gt.gp_mask;
                 remote = p != P || !in_lds;
-                if (gt.dbg == 3) remote = false;                       // timing experiment: scan + candidates only
-                if (gt.dbg == 4 && remote) { remote = false; }         // timing experiment: no remote queue
-                else if (!remote && gt.dbg != 3) {
+                if (SHK_DBG(gt.dbg) == 3) remote = false;                       // timing experiment: scan + candidates only
+                if (SHK_DBG(gt.dbg) == 4 && remote) { remote = false; }         // timing experiment: no remote queue
+                else if (!remote && SHK_DBG(gt.dbg) != 3) {
                     bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
                     const uint64_t h = gt_hash<W>(c);
                     const uint32_t fp = (uint32_t)(h >> 32);

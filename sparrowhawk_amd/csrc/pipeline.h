@@ -60,12 +60,14 @@ public:
                                 uint64_t total_instances, std::string &err) = 0;
     virtual StageTimes &times() = 0;
     virtual void *stream() = 0;
+    virtual int device() const = 0;                  // the HIP device this pipeline's stream and buffers live on
 };
 
 // returns nullptr (and err) if no device / bad k
 IPipeline *make_pipeline(int k, std::string &err);
 int device_count();
 int current_device();          // the calling thread's current HIP device
+int set_device(int dev);       // makes `dev` current for the calling thread, returns the previous one
 
 // host-side helpers implemented with the same kmer.h arithmetic as the kernels
 int host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *orient);
@@ -80,5 +82,6 @@ void *device_pool_alloc(size_t &bytes);
 // best rate (GB/s) of `iters` pure streaming reads of a `bytes` buffer on the current device
 int stream_read_gbs(size_t bytes, int iters, double *gbs, std::string &err);
 void device_pool_release(void *p, size_t bytes);
+int device_stream_sync(void *stream, std::string &err);      // waits for a hipStream_t
 
 }  // namespace shk

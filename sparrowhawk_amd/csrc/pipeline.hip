@@ -99,6 +99,7 @@ namespace shk {
 struct DevPool {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> free_blocks;     // (device, bytes) -> block
+    std::map<void *, int> owner_dev;                               // every block handed out -> the device it lives on
     bool enabled = true;
     DevPool() { const char *v = getenv("SHK_NO_POOL"); enabled = !(v && *v == '1'); }
     static int cur_dev() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -111,7 +112,7 @@ struct DevPool {
             std::lock_guard<std::mutex> lk(mu);
             auto it = free_blocks.lower_bound(std::make_pair(dev, bytes));
             if (it != free_blocks.end() && it->first.first == dev && it->first.second <= bytes + bytes / 2 + (1u << 20)) {
-                void *p = it->second; bytes = it->first.second; free_blocks.erase(it); e = hipSuccess; return p;
+                void *p = it->second; bytes = it->first.second; free_blocks.erase(it); owner_dev[p] = dev; e = hipSuccess; return p;
             }
         }
         void *p = nullptr;
@@ -120,13 +121,19 @@ struct DevPool {
             trim();
             e = hipMalloc(&p, bytes);
         }
+        if (e == hipSuccess && enabled) { std::lock_guard<std::mutex> lk(mu); owner_dev[p] = dev; }
         return e == hipSuccess ? p : nullptr;
     }
-    void put(void *p, size_t bytes) {                  // called with the owning handle's device current
+    // a block goes back under the device it was allocated on, whatever device the calling thread has current
+    // (an FFI consumer may free a handle from another thread: the HIP current device is per thread)
+    void put(void *p, size_t bytes) {
         if (!p) return;
         if (!enabled) { (void)hipFree(p); return; }
         std::lock_guard<std::mutex> lk(mu);
-        free_blocks.emplace(std::make_pair(cur_dev(), bytes), p);
+        auto it = owner_dev.find(p);
+        const int dev = it != owner_dev.end() ? it->second : cur_dev();
+        if (it != owner_dev.end()) owner_dev.erase(it);
+        free_blocks.emplace(std::make_pair(dev, bytes), p);
     }
     void trim() {
         std::lock_guard<std::mutex> lk(mu);
@@ -263,6 +270,14 @@ static inline uint64_t env_u64(const char *name, uint64_t dflt) {
     const char *v = getenv(name);
     return (v && *v) ? strtoull(v, nullptr, 10) : dflt;
 }
+// SHK_DEBUG_* (timing experiments: results are wrong) are read by `make ABLATE=1` builds only
+static inline uint32_t env_dbg(const char *name) {
+#if SHK_ABLATE
+    return (uint32_t)env_u64(name, 0);
+#else
+    (void)name; return 0u;
+#endif
+}
 
 // minimiser length of the counting partitions and of the graph partitions
 static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
@@ -281,6 +296,7 @@ public:
     }
     StageTimes &times() override { EvTimer::resolve(pending_timers_, times_); return times_; }
     void *stream() override { return (void *)stream_; }
+    int device() const override { return stream_dev_; }
     uint64_t total_instances() const override { return total_instances_; }
     uint64_t n_distinct() const override { return n_distinct_; }
     uint64_t n_solid() const override { return n_solid_; }
@@ -358,10 +374,9 @@ public:
         constexpr int RW = 2 * W;
         const int wblk = k_ >= 23 ? 16 : 8;
         const uint64_t inst_ub = n_bases - n_seg * (uint64_t)(k_ - 1);
-        int cus = 256;
-        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+        const int cus = n_cus_;
         const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
-        pp_.k = k_; pp_.m = k_ - wblk + 1; pp_.dbg_nostore = (uint32_t)env_u64("SHK_DEBUG_NOSTORE", 0);
+        pp_.k = k_; pp_.m = k_ - wblk + 1; pp_.dbg_nostore = env_dbg("SHK_DEBUG_NOSTORE");
         pp_.max_n = std::min<uint32_t>(32u * RW - 3u - (uint32_t)(k_ - 1), 63u);
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
@@ -383,6 +398,7 @@ public:
             // 0.80 ms for k_partition).  Slice sizes stay >= 256 bytes away from a multiple of 2 KB.
             if (env_u64("SHK_SLICE_NOSKEW", 0) == 0)
                 while ((cap * RW * 8) % 2048 < 256 || (cap * RW * 8) % 2048 > 1792) cap++;
+            if (cap * pp_.G > 0xFFFFFFF0ull) { err = "a partition would hold more than 2^32 records"; return -1; }
             pp_.slice_cap = (uint32_t)cap;
             const uint64_t n_slices = (uint64_t)P * pp_.G;
             if (int rc = recs_.alloc(n_slices * cap * RW, err)) return rc;
@@ -411,7 +427,7 @@ public:
                                    (uint32_t)RW, run_off_.p, run_cnt_.p);
                 HIPCHK(hipGetLastError());
                 run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
-                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = (uint32_t)env_u64("SHK_DEBUG_P2", 0);
+                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = env_dbg("SHK_DEBUG_P2");
                 return 0;
             }
             times_.add("partition_retry", ms);
@@ -486,6 +502,11 @@ public:
         if (nb > 256) { err = "more than 256 batches per handle"; return -1; }
         const uint64_t n_runs = (uint64_t)pp_.P * nb;
         std::vector<unsigned long long> addr16(n_runs); std::vector<uint32_t> cnt(n_runs);
+        for (uint32_t p = 0; p < pp_.P; p++) {
+            unsigned long long r = 0;                     // a partition's record index is 32 bits wide in pass 2
+            for (uint32_t b = 0; b < nb; b++) r += batches_[b]->part_off[p + 1] - batches_[b]->part_off[p];
+            if (r > 0xFFFFFFF0ull) { err = "a partition holds more than 2^32 records"; return -1; }
+        }
         for (uint32_t p = 0; p < pp_.P; p++)
             for (uint32_t b = 0; b < nb; b++) {
                 const BatchRecs &B = *batches_[b];
@@ -607,7 +628,7 @@ public:
                         const uint32_t bgrid = (uint32_t)std::min<unsigned long long>(n_list, 2ull * (unsigned long long)n_cus_);
                         hipLaunchKernelGGL(k_count_buckets<W>, dim3(bgrid), dim3(COUNT_THREADS), 0, stream_,
                                            d_blist.p, (uint32_t)n_list, d_kmers.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
-                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), (uint32_t)env_u64("SHK_DEBUG_B", 0));
+                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), env_dbg("SHK_DEBUG_B"));
                         HIPCHK(hipGetLastError());
                         HIPCHK(stream_wait(stream_));      // d_items / d_kmers are reused by the next pass
                     }
@@ -826,7 +847,12 @@ public:
         run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
         run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned; run_view_.dbg = 0;
         uint64_t total_recs = 0;
-        for (uint64_t i = 0; i < n_runs; i++) total_recs += run_cnt[i];
+        for (uint32_t j = 0; j < n_owned; j++) {          // a partition's record index is 32 bits wide in pass 2
+            uint64_t r = 0;
+            for (uint32_t s = 0; s < n_sources; s++) r += run_cnt[(uint64_t)j * n_sources + s];
+            if (r > 0xFFFFFFF0ull) { err = "a partition holds more than 2^32 records"; return -1; }
+            total_recs += r;
+        }
         memset(histo, 0, 500 * 8);
         n_emitted_ = 0; emit_threshold_ = emit_threshold; n_distinct_ = 0;
         double ms = 0; uint64_t inst = 0;
@@ -872,7 +898,7 @@ public:
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
         g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
-        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = (uint32_t)env_u64("SHK_DEBUG_G", 0);
+        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
         g.n = (uint32_t)n_solid_;
         return g;
     }
@@ -1230,6 +1256,7 @@ private:
 };
 
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
+int set_device(int dev) { int prev = 0; (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); return prev; }
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -1260,6 +1287,7 @@ int device_upload(const void *host, size_t bytes, void **dptr, std::string &err)
     return 0;
 }
 void device_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
+int device_stream_sync(void *stream, std::string &err) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
 
 // ---- host-side self-test helpers (same arithmetic as the kernels) ---------------------------
 template <int W> static int host_canon_t(const char *seq, uint32_t k, uint64_t *out, int *orient) {

@@ -1,0 +1,242 @@
+// shard_comm.hip — RCCL collectives of the shard layer (see shard_comm.h) and the host-side exchange plan.
+//
+// Traffic shape (DESIGN.md "Multi-GPU"): ONE pairwise exchange of super-k-mer records (grouped
+// ncclSend/ncclRecv: xGMI is point-to-point, 7 links per GPU, and a pairwise exchange is the pattern that
+// keeps all of them busy at once), a 4 KB all-reduce of the histogram and an all-gather of the solid rows.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <mutex>
+#include <string.h>
+
+#include "shard_comm.h"
+#include "pipeline.h"
+
+namespace shk {
+
+static_assert(SHARD_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+
+namespace {
+
+// the RCCL entry points used here, bound at run time
+struct Rccl {
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // by soname first: a copy that is already mapped (torch ships one) is shared, not doubled
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        void *h = nullptr;
+        for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) { r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+        auto sym = [&](const char *n) -> void * { void *p = dlsym(h, n); if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n; return p; };
+        r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.ok = r.why.empty();
+    });
+    return r;
+}
+
+}  // namespace
+
+struct ShardComm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+};
+
+#define RCCLCHK(call)                                                                         \
+    do {                                                                                      \
+        const ncclResult_t _r = (call);                                                       \
+        if (_r != ncclSuccess) {                                                              \
+            err = std::string(#call) + ": " + (R.GetErrorString ? R.GetErrorString(_r) : "?"); \
+            return -5;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+int comm_unique_id(uint8_t id[SHARD_UNIQUE_ID_BYTES], std::string &err) {
+    Rccl &R = rccl();
+    if (!R.ok) { err = R.why; return -5; }
+    ncclUniqueId u;
+    RCCLCHK(R.GetUniqueId(&u));
+    memcpy(id, u.internal, SHARD_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+ShardComm *comm_create(const uint8_t id[SHARD_UNIQUE_ID_BYTES], int rank, int world, std::string &err) {
+    Rccl &R = rccl();
+    if (!R.ok) { err = R.why; return nullptr; }
+    if (world < 1 || rank < 0 || rank >= world) { err = "comm: bad rank / world"; return nullptr; }
+    ShardComm *c = new (std::nothrow) ShardComm();
+    if (!c) { err = "out of host memory"; return nullptr; }
+    c->rank = rank; c->world = world;
+    if (hipGetDevice(&c->device) != hipSuccess) { err = "no HIP device"; delete c; return nullptr; }
+    ncclUniqueId u;
+    memcpy(u.internal, id, SHARD_UNIQUE_ID_BYTES);
+    const ncclResult_t r = R.CommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) {
+        err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "?");
+        delete c; return nullptr;
+    }
+    return c;
+}
+
+void comm_destroy(ShardComm *c) {
+    if (!c) return;
+    Rccl &R = rccl();
+    if (c->comm && R.ok) (void)R.CommDestroy(c->comm);
+    delete c;
+}
+int comm_rank(const ShardComm *c) { return c ? c->rank : 0; }
+int comm_world(const ShardComm *c) { return c ? c->world : 1; }
+int comm_device(const ShardComm *c) { return c ? c->device : 0; }
+
+int comm_allreduce_u64(ShardComm *c, void *d_buf, size_t n, void *stream, std::string &err) {
+    Rccl &R = rccl();
+    if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!n) return 0;
+    RCCLCHK(R.AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
+    return 0;
+}
+
+int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes, void *stream, std::string &err) {
+    Rccl &R = rccl();
+    if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!bytes) return 0;
+    if (bytes % 8) { err = "comm_allgather: bytes must be a multiple of 8"; return -1; }
+    RCCLCHK(R.AllGather(d_send, d_recv, bytes / 8, ncclUint64, c->comm, (hipStream_t)stream));
+    return 0;
+}
+
+int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
+                   void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err) {
+    Rccl &R = rccl();
+    if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    for (int p = 0; p < c->world; p++)
+        if ((send_off[p] | send_bytes[p] | recv_off[p] | recv_bytes[p]) % 8) { err = "comm_alltoallv: offsets and sizes must be multiples of 8"; return -1; }
+    RCCLCHK(R.GroupStart());
+    for (int p = 0; p < c->world; p++) {
+        if (send_bytes[p])
+            RCCLCHK(R.Send((const char *)d_send + send_off[p], send_bytes[p] / 8, ncclUint64, p, c->comm, (hipStream_t)stream));
+        if (recv_bytes[p])
+            RCCLCHK(R.Recv((char *)d_recv + recv_off[p], recv_bytes[p] / 8, ncclUint64, p, c->comm, (hipStream_t)stream));
+    }
+    RCCLCHK(R.GroupEnd());
+    return 0;
+}
+
+int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64_t *off, const uint64_t *bytes,
+                    void *stream, std::string &err) {
+    Rccl &R = rccl();
+    if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    for (int s = 0; s < c->world; s++)
+        if ((off[s] | bytes[s]) % 4) { err = "comm_allgatherv: offsets and sizes must be multiples of 4"; return -1; }
+    RCCLCHK(R.GroupStart());
+    for (int s = 0; s < c->world; s++) {
+        if (!bytes[s]) continue;
+        RCCLCHK(R.Broadcast(s == c->rank ? d_send : (const void *)((char *)d_recv + off[s]), (char *)d_recv + off[s],
+                            bytes[s] / 4, ncclUint32, s, c->comm, (hipStream_t)stream));
+    }
+    RCCLCHK(R.GroupEnd());
+    return 0;
+}
+
+// ---- small host-side collectives ---------------------------------------------------------------------
+namespace {
+struct PoolBlock {
+    void *p = nullptr; size_t bytes = 0;
+    explicit PoolBlock(size_t b) : bytes(b ? b : 8) { p = device_pool_alloc(bytes); }
+    ~PoolBlock() { if (p) device_pool_release(p, bytes); }
+};
+}  // namespace
+
+int comm_allreduce_host_u64(ShardComm *c, uint64_t *host_inout, size_t n, void *stream, std::string &err) {
+    if (!n) return 0;
+    PoolBlock b(n * 8);
+    if (!b.p) { err = "device allocation failed (all-reduce staging)"; return -4; }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(b.p, host_inout, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
+    if (int rc = comm_allreduce_u64(c, b.p, n, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
+    if (hipMemcpyAsync(host_inout, b.p, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        err = std::string("all-reduce: ") + hipGetErrorString(hipGetLastError()); return -5;
+    }
+    return 0;
+}
+
+int comm_allgather_host_u64(ShardComm *c, const uint64_t *host_in, size_t n, uint64_t *host_out, void *stream, std::string &err) {
+    if (!n) return 0;
+    const size_t world = (size_t)comm_world(c);
+    PoolBlock in(n * 8), out(n * 8 * world);
+    if (!in.p || !out.p) { err = "device allocation failed (all-gather staging)"; return -4; }
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemcpyAsync(in.p, host_in, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
+    if (int rc = comm_allgather(c, in.p, out.p, n * 8, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
+    if (hipMemcpyAsync(host_out, out.p, n * 8 * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        err = std::string("all-gather: ") + hipGetErrorString(hipGetLastError()); return -5;
+    }
+    return 0;
+}
+
+// ---- host-side plan -------------------------------------------------------------------------------
+uint32_t choose_partitions(uint64_t total_instances_ub, uint32_t world, uint64_t per_part) {
+    uint32_t P = 64;
+    while (P < 16384u && (uint64_t)P * per_part < total_instances_ub) P <<= 1;
+    while (P < world) P <<= 1;
+    return P;
+}
+
+int plan_exchange(const uint64_t *pr, uint32_t world, uint32_t P, uint32_t rank, ExchangePlan &out, std::string &err) {
+    if (!pr || world < 1 || rank >= world || P < world) { err = "plan_exchange: bad arguments"; return -1; }
+    const uint64_t *mine = pr + (uint64_t)rank * P;
+    out.base.assign(P, 0); out.send_counts.assign(world, 0); out.recv_counts.assign(world, 0);
+    uint64_t off = 0;
+    for (uint32_t d = 0; d < world; d++)                       // destination-major, partitions ascending
+        for (uint32_t p = d; p < P; p += world) { out.base[p] = off; off += mine[p]; out.send_counts[d] += mine[p]; }
+    out.owned.clear();
+    for (uint32_t p = rank; p < P; p += world) out.owned.push_back(p);
+    const uint32_t n_owned = (uint32_t)out.owned.size();
+    std::vector<uint64_t> recv_base(world, 0);
+    for (uint32_t s = 0; s < world; s++) {
+        uint64_t t = 0;
+        for (uint32_t j = 0; j < n_owned; j++) t += pr[(uint64_t)s * P + out.owned[j]];
+        out.recv_counts[s] = t;
+    }
+    for (uint32_t s = 1; s < world; s++) recv_base[s] = recv_base[s - 1] + out.recv_counts[s - 1];
+    out.run_off.assign((uint64_t)n_owned * world, 0); out.run_cnt.assign((uint64_t)n_owned * world, 0);
+    for (uint32_t s = 0; s < world; s++) {
+        uint64_t within = 0;                                   // source s sends its partitions for this rank in ascending order
+        for (uint32_t j = 0; j < n_owned; j++) {
+            const uint64_t c = pr[(uint64_t)s * P + out.owned[j]];
+            if (c > 0xFFFFFFFFull) { err = "plan_exchange: more than 2^32 records of one partition on one rank"; return -1; }
+            out.run_off[(uint64_t)j * world + s] = recv_base[s] + within;
+            out.run_cnt[(uint64_t)j * world + s] = (uint32_t)c;
+            within += c;
+        }
+    }
+    return 0;
+}
+
+}  // namespace shk

@@ -1,4 +1,11 @@
-"""Shard layer: one process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm).
+"""Shard layer launcher: one process per GPU.
+
+The production path is `LibComm` + `sharded_preprocess_rccl`: the collectives run INSIDE libshk_hip.so
+(shk_shard_preprocess, csrc/shard_comm.hip: RCCL over xGMI); Python only carries the 128-byte ncclUniqueId
+from rank 0 to the other ranks (over whatever torch.distributed group the launcher has) and makes the one
+call.  `Comm` + `sharded_preprocess` below drive the same five shk_shard_* pieces with torch.distributed
+collectives instead; they exist so the sequence can be rehearsed where RCCL cannot run (gloo on CPU, or
+several ranks on the one GPU of a test box) and so the exchange plan can be tested without a GPU.
 
 Replaces the read-parallel (rayon) driver the north_star attributes to the crate's native build
 (not in the reference tree: SURVEY.md §8a row a15).  The k-mer space is partitioned by
@@ -122,6 +129,67 @@ class Comm:
         out = out.view(self.world, pad.numel())
         pieces = [out[s, :int(counts[s])] for s in range(self.world)]
         return torch.cat(pieces).to(t.device) if pieces else pad[:0].to(t.device)
+
+
+class LibComm:
+    """An RCCL communicator owned by libshk_hip.so (include/shk.h: shk_comm_*), one per process and GPU.
+    The unique id travels over an existing torch.distributed group (any backend) or, for world 1, nowhere."""
+
+    def __init__(self, rank=0, world=1, group=None):
+        self._L = _lib.load()
+        self._c = None
+        ident = (C.c_uint8 * 128)()
+        if rank == 0:
+            if self._L.shk_comm_unique_id(ident) != 0:
+                raise ShkError(-5, self._L.shk_comm_error().decode())
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+            if dist.get_backend(group) == "nccl":
+                t = t.cuda()
+            dist.broadcast(t, src=0, group=group)
+            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+        self._c = self._L.shk_comm_init(ident, int(rank), int(world))
+        if not self._c:
+            raise ShkError(-5, self._L.shk_comm_error().decode())
+        self.rank, self.world = int(rank), int(world)
+
+    def free(self):
+        if self._c:
+            self._L.shk_comm_free(self._c)
+            self._c = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sharded_preprocess_rccl(helper: AssemblyHelper, d_bases_ptr, d_seg_off_ptr, n_seg, n_bases, n_reads,
+                            comm: LibComm, n_partitions=0):
+    """Collective over `comm`: every rank hands in its share of the packed reads (device pointers); on return
+    every rank's helper is 'preprocessed' with the same global solid set.  One C call, no Python collectives."""
+    helper._check(helper._L.shk_shard_preprocess(helper._h, comm._c, d_bases_ptr if n_seg else None,
+                                                 d_seg_off_ptr if n_seg else None, int(n_seg), int(n_bases),
+                                                 int(n_reads), int(n_partitions or 0)))
+
+
+def lib_plan_exchange(part_records_all, rank):
+    """The exchange plan as the library computes it (shk_plan_exchange) — same dict as plan_exchange()."""
+    L = _lib.load()
+    pr = np.ascontiguousarray(part_records_all, dtype=np.uint64)
+    world, P = pr.shape
+    n_owned = len(range(rank, P, world))
+    base = np.zeros(P, dtype=np.uint64)
+    sc, rc = np.zeros(world, dtype=np.uint64), np.zeros(world, dtype=np.uint64)
+    ro, rn = np.zeros((n_owned, world), dtype=np.uint64), np.zeros((n_owned, world), dtype=np.uint32)
+    r = L.shk_plan_exchange(pr.ctypes.data, world, P, rank, base.ctypes.data, sc.ctypes.data, rc.ctypes.data,
+                            ro.ctypes.data, rn.ctypes.data)
+    if r != 0:
+        raise ShkError(r, "shk_plan_exchange")
+    return dict(owned=np.arange(rank, P, world), base=base, send_counts=sc, recv_counts=rc, run_off=ro, run_cnt=rn)
 
 
 def _ptr_tensor(torch, ptr, nbytes, device):

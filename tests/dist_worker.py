@@ -3,6 +3,10 @@
 mode "plan": CPU only — exercises plan_exchange + the record exchange with tagged fake records.
 mode "gpu" : every rank drives the real HIP path on cuda:0 (ranks share the one GPU of the test
              box; collectives go through gloo with host staging) and rank 0 writes the result.
+mode "rccl": the production path — the collectives run inside libshk_hip.so over RCCL
+             (shk_shard_preprocess); torch.distributed (gloo) only carries the ncclUniqueId.  Rank r
+             uses cuda:(r % device_count).  RCCL refuses two ranks on one GPU: the worker then
+             reports {"skipped": reason} instead of a result.
 """
 import json
 import os
@@ -53,6 +57,38 @@ def main():
         res = {"ok": bool(ok), "rank": rank, "P": choose_partitions(10 ** 9, world)}
         with open(f"{out_path}.{rank}", "w") as f:
             json.dump(res, f)
+    elif mode == "rccl":
+        from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
+        from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+        dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+        cfg = json.load(open(sys.argv[3]))
+        fq = open(cfg["fastq"], "rb").read()
+        k = cfg["k"]
+        try:
+            comm = LibComm(rank, world)
+        except ShkError as e:
+            with open(f"{out_path}.{rank}", "w") as f:
+                json.dump({"skipped": str(e)}, f)
+            dist.barrier()
+            dist.destroy_process_group()
+            return
+        recs = fq.decode().split("@r")[1:]
+        mine = ("@r" + "@r".join(recs[rank::world])).encode() if recs[rank::world] else b""
+        bases, seg, nb, nr = pack_fastq(mine, k, cfg["min_qual"])
+        d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+        d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        h = AssemblyHelper.new(k, True, cfg["min_count"], cfg["min_qual"], 0, False, cfg["do_fit"], False, False)
+        sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm,
+                                n_partitions=cfg.get("P") or 0)
+        h.assemble()
+        res = {"pre": h.get_preprocessing_info(), "asm": h.get_assembly(), "states": h.states,
+               "total_instances": h.total_instances, "timings": h.timings()}
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(res, f)
+        h.free()
+        comm.free()
     else:
         from sparrowhawk_amd import AssemblyHelper, pack_fastq
         from sparrowhawk_amd.dist import sharded_preprocess

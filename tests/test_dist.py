@@ -16,12 +16,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = os.path.join(ROOT, "tests", "dist_worker.py")
 
 
-def launch(nproc, args, port):
+def launch(nproc, args, port, timeout=600):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), WORKER] + args
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    # own process group: on a timeout the launcher AND its ranks are ended (no rank may outlive the test)
+    pr = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, start_new_session=True)
+    try:
+        out, errs = pr.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(pr.pid, signal.SIGKILL)
+        out, errs = pr.communicate()
+        raise AssertionError(f"ranks did not finish within {timeout} s\n" + out[-2000:] + errs[-2000:])
+    assert pr.returncode == 0, out[-3000:] + errs[-3000:]
 
 
 def test_plan_exchange_is_consistent_single_process():
@@ -44,6 +52,26 @@ def test_plan_exchange_is_consistent_single_process():
             off += int(allp[r, p])
     assert choose_partitions(10, 8) == 64 and choose_partitions(4 * 10 ** 9, 8) == 16384
     assert choose_partitions(100_000 * 1000, 2) == 1024
+
+
+def test_library_plan_equals_the_python_plan():
+    """shk_plan_exchange (what shk_shard_preprocess runs between its collectives) against dist.plan_exchange."""
+    from sparrowhawk_amd.dist import plan_exchange, lib_plan_exchange
+    from sparrowhawk_amd import _lib
+    rng = np.random.default_rng(7)
+    for world, P in ((1, 64), (2, 64), (3, 64), (8, 128), (8, 16384), (5, 8)):
+        allp = rng.integers(0, 1000, (world, P)).astype(np.uint64)
+        allp[rng.integers(0, world, 4), rng.integers(0, P, 4)] = 0
+        for r in range(world):
+            a, b = plan_exchange(allp, r), lib_plan_exchange(allp, r)
+            for key in ("owned", "base", "send_counts", "recv_counts", "run_off", "run_cnt"):
+                assert np.array_equal(np.asarray(a[key], dtype=np.uint64), np.asarray(b[key], dtype=np.uint64)), (world, P, r, key)
+    L = _lib.load()
+    from sparrowhawk_amd.dist import choose_partitions
+    for tot in (10, 10 ** 6, 10 ** 8, 4 * 10 ** 9, 3 * 10 ** 10):
+        for world in (1, 2, 8):
+            assert L.shk_choose_partitions(tot, world, 1) == choose_partitions(tot, world)
+            assert L.shk_choose_partitions(tot, world, 2) == choose_partitions(tot, world, per_part=40_000)
 
 
 @pytest.mark.parametrize("world", [2, 3])
@@ -85,3 +113,60 @@ def test_sharded_pipeline_two_ranks_one_gpu(k, do_fit, P):
     h.assemble()
     assert h.get_assembly() == res[0]["asm"]
     assert res[0]["states"][0] == "preprocess:start" and res[0]["states"][-1] == "assembly:end"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,do_fit,P", [(31, False, 0), (51, True, 64)])
+def test_rccl_inside_the_library_world_1(k, do_fit, P):
+    """shk_shard_preprocess with a one-rank RCCL communicator (ncclCommInitRank, grouped send/recv to itself,
+    all-reduce, broadcast-gather): same bytes as the plain single-GPU path and as the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    from util import make_dataset, run_oracle
+    from sparrowhawk_amd import AssemblyHelper, pack_fastq
+    from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+    g, fq = make_dataset(40000, 40, err=0.01, seed=500 + k)
+    dev = torch.device("cuda", 0)
+    comm = LibComm(0, 1)
+    bases, seg, nb, nr = pack_fastq(fq, k, 20)
+    d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+    d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    h = AssemblyHelper.new(k, True, 3, 20, 0, False, do_fit, False, False)
+    sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm, n_partitions=P)
+    h.assemble()
+    o = run_oracle([fq], k=k, min_count=3, min_qual=20, do_fit=do_fit)
+    o.assemble()
+    assert h.get_preprocessing_info() == o.preprocessing_json()
+    assert h.get_assembly() == o.assembly_json()
+    assert h.total_instances == o.total_instances
+    assert "shard_exchange_host_clock" in h.timings()
+    h2 = AssemblyHelper.new(k, True, 3, 20, 0, False, do_fit, False, False)
+    h2.preprocess(fq)
+    h2.assemble()
+    assert h2.get_assembly() == h.get_assembly()
+    comm.free()
+
+
+@pytest.mark.gpu
+def test_rccl_inside_the_library_two_ranks():
+    """Two ranks through shk_shard_preprocess.  On a one-GPU box RCCL refuses the second rank on the same
+    device (duplicate GPU): the test then skips, saying so; on a box with >= 2 GPUs it compares with the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset, run_oracle
+    k = 31
+    g, fq = make_dataset(40000, 40, err=0.01, seed=777)
+    with tempfile.TemporaryDirectory() as d:
+        fqp = os.path.join(d, "reads.fq")
+        open(fqp, "wb").write(fq)
+        cfgp = os.path.join(d, "cfg.json")
+        json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": False}, open(cfgp, "w"))
+        out = os.path.join(d, "res")
+        launch(2, ["rccl", out, cfgp], 29711, timeout=240)
+        res = [json.load(open(f"{out}.{r}")) for r in range(2)]
+    if any("skipped" in r for r in res):
+        pytest.skip("RCCL with two ranks needs two GPUs: " + "; ".join(r.get("skipped", "ok") for r in res))
+    o = run_oracle([fq], k=k, min_count=3, min_qual=20)
+    o.assemble()
+    assert res[0]["asm"] == res[1]["asm"] == o.assembly_json()
+    assert res[0]["pre"] == res[1]["pre"] == o.preprocessing_json()

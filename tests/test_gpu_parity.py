@@ -172,8 +172,16 @@ def test_progress_states_and_modes():
         h = product(fq, k=31, min_count=5, do_fit=True, **kw)
         s = h.states
         assert s[0] == "preprocess:start" and s[1] == f"preprocess:{mode}:start"
-        assert s[2] == f"preprocess:{mode}:loop:start"
-        assert f"preprocess:{mode}:loop:end" in s
+        # loop:start / loop:end exist for bulk and bloom only (AssemblyPage.vue:467,492,508,533); the chunked
+        # branch of the reference UI (:548-579) knows :start, :fitting, :filtering and :loop:<n>[:<pct>] only
+        assert (s[2] == f"preprocess:{mode}:loop:start") == (mode != "chunked")
+        assert (f"preprocess:{mode}:loop:end" in s) == (mode != "chunked")
+        ui_chunked = {"preprocess:chunked:start", "preprocess:chunked:fitting", "preprocess:chunked:filtering"}
+        for st in s:
+            if st.startswith("preprocess:chunked:") and st not in ui_chunked:
+                parts = st.split(":")
+                assert parts[2] == "loop" and parts[3].isdigit() and (len(parts) == 4 or parts[4].isdigit()), st
+        assert any(st.startswith(f"preprocess:{mode}:loop:") and st.split(":")[3].isdigit() for st in s)
         assert (f"preprocess:bulk:sorting" in s) == (mode == "bulk")
         assert f"preprocess:{mode}:fitting" in s and f"preprocess:{mode}:filtering" in s
         i = s.index("preprocess:saving")
@@ -528,3 +536,53 @@ def test_long_reads_are_split_into_overlapping_segments():
         o = run_oracle([fq], k=k, min_count=1)
         compare_all(h, o)
         assert h.total_instances == 2 * (len(seq) - k + 1)
+
+
+def test_counts_saturate_at_u32_max():
+    """SPEC S4: counts are u32 and saturate at 0xFFFFFFFF.  Forced through the shard layer's run tables: the
+    same packed records are listed 256 times as the runs of their partition (weights via repeated records),
+    so a poly-A 31-mer seen 2^24 + a bit times counts past 2^32, while every other count is 256 x the oracle's."""
+    import ctypes as C
+    import torch
+    from sparrowhawk_amd import pack_fastq
+    k, reps = 31, 256
+    n_polya = (1 << 24) // 120 + 50                       # 120 windows per 150-base read: just past 2^24 instances
+    g, fq_small = make_dataset(3000, 20, seed=91)
+    polya = b"".join(b"@a%d\n%s\n+\n%s\n" % (i, b"A" * 150, b"I" * 150) for i in range(n_polya))
+    fq = fq_small + polya
+    o = run_oracle([fq], k=k, min_count=0, min_qual=0)
+    ok_, oc_ = o.solid()                                  # min_count 0: every distinct k-mer
+    dev = torch.device("cuda", 0)
+    bases, seg, nb, nr = pack_fastq(fq, k, 0)
+    d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+    d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    h = AssemblyHelper.new(k, True, 0, 0, 0, False, False, False, False)
+    L = h._L
+    P = 64
+    part = np.zeros(P, dtype=np.uint64)
+    h._check(L.shk_shard_partition(h._h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, P, part.ctypes.data))
+    rec_bytes = L.shk_shard_record_bytes(h._h)
+    base = np.concatenate([[0], np.cumsum(part)[:-1]]).astype(np.uint64)
+    send = torch.empty(int(part.sum()) * rec_bytes + 64, dtype=torch.uint8, device=dev)
+    h._check(L.shk_shard_pack(h._h, send.data_ptr(), base.ctypes.data, P))
+    run_off = np.ascontiguousarray(np.repeat(base[:, None], reps, axis=1))            # [P][reps]: the same run again and again
+    run_cnt = np.ascontiguousarray(np.repeat(part[:, None], reps, axis=1).astype(np.uint32))
+    assert int(run_cnt.sum(axis=1).max()) >= 1 << 26      # the poly-A partition takes the saturating path
+    histo = np.zeros(500, dtype=np.uint64)
+    inst = C.c_uint64(0)
+    h._check(L.shk_shard_count(h._h, send.data_ptr(), run_off.ctypes.data, run_cnt.ctypes.data, P, reps, histo.ctypes.data, C.byref(inst)))
+    assert inst.value == reps * o.total_instances
+    keys = (C.c_void_p * 1)()
+    cnt = C.c_void_p()
+    n_rows, used = C.c_uint64(0), C.c_uint32(0)
+    h._check(L.shk_shard_rows(h._h, histo.ctypes.data, keys, C.byref(cnt), C.byref(n_rows), C.byref(used)))
+    h._check(L.shk_shard_set_solid(h._h, keys, cnt, n_rows.value, inst.value))
+    hk, hc, _ = sorted_table(*h.solid())
+    assert np.array_equal(hk, ok_)
+    expect = np.minimum(oc_.astype(np.uint64) * reps, 0xFFFFFFFF).astype(np.uint32)
+    assert int((expect == 0xFFFFFFFF).sum()) == 1 and int(ok_[expect == 0xFFFFFFFF][0, 0]) == 0      # AAAA...A
+    assert np.array_equal(hc, expect), "counts differ from min(256 x oracle, 2^32 - 1)"
+    eh = np.zeros(500, dtype=np.uint64)
+    np.add.at(eh, np.minimum(expect.astype(np.int64), 500) - 1, 1)
+    assert np.array_equal(histo, eh)

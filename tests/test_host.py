@@ -124,6 +124,70 @@ def test_host_fit_equals_oracle_fit(lib):
     assert lib.shk_host_fit(z.ctypes.data, C.byref(out)) == 0
 
 
+def _mixture_histogram(a, b, lam):
+    """h[c] = a * Pois(c; 1) + b * Pois(c; lam), c = 1..500 (the zero class is never observed)."""
+    from math import exp, lgamma, log
+    return np.array([int(round(a * exp(-1.0 - lgamma(c + 1)) + b * exp(c * log(lam) - lam - lgamma(c + 1))))
+                     for c in range(1, 501)], dtype=np.uint64)
+
+
+def test_fit_against_an_independent_python_em(lib):
+    """a7 pin: the product's fit (csrc/fit.cpp) and the oracle's (shk_oracle.c) are near-twins in C; this
+    restatement (tests/util.py: py_fit) is written from SPEC S6 alone and must agree with both."""
+    from util import py_fit
+    rng = np.random.default_rng(11)
+    spectra = []
+    for trial in range(40):
+        lam = rng.uniform(3, 120)
+        h = _mixture_histogram(rng.uniform(1e3, 1e6), rng.uniform(1e3, 1e6), lam)
+        spectra.append(h + rng.integers(0, 5, 500).astype(np.uint64))
+    spectra.append(np.zeros(500, dtype=np.uint64))                        # empty: fails
+    spectra.append(_mixture_histogram(1e5, 0.0, 5.0))                     # errors only: no coverage peak -> fails
+    spectra.append(_mixture_histogram(0.0, 1e5, 40.0))                    # coverage only
+    one = np.zeros(500, dtype=np.uint64); one[499] = 7                    # everything in the saturating bin
+    spectra.append(one)
+    n_ok = 0
+    for h in spectra:
+        out = C.c_uint32(0)
+        ok = bool(lib.shk_host_fit(h.ctypes.data, C.byref(out)))
+        ok_o, v_o = oracle_fit(h)
+        ok_p, v_p = py_fit(h)
+        assert ok == ok_o == ok_p
+        if ok:
+            n_ok += 1
+            assert out.value == v_o == v_p
+    assert n_ok >= 40
+
+
+def test_fit_threshold_is_the_analytic_crossing_point(lib):
+    """Closed form (SPEC S6): for a well separated mixture a*Pois(1) + b*Pois(lam) observed on c >= 1 the EM's
+    fixed point is lam* = lam and w* = a(1-1/e) / (a(1-1/e) + b) (the error component loses its zero class, the
+    coverage component loses nothing worth mentioning), and the threshold is the last count at which the error
+    component still wins: c* - 1 with c* the smallest integer above
+        x = (lam* - 1 + ln(w* / (1 - w*))) / ln(lam*).
+    Cases are kept where x is not within 0.15 of an integer, so the residual overlap cannot move c*."""
+    from math import ceil, e, floor, log
+    from util import py_fit
+    rng = np.random.default_rng(5)
+    checked = 0
+    for trial in range(200):
+        lam = float(rng.uniform(20, 120))
+        a, b = float(rng.uniform(1e5, 1e7)), float(rng.uniform(1e5, 1e7))
+        w = a * (1 - 1 / e) / (a * (1 - 1 / e) + b)
+        x = (lam - 1 + log(w / (1 - w))) / log(lam)
+        if abs(x - round(x)) < 0.15 or x < 2:
+            continue
+        expect = min(max(int(floor(x)) + 1 - 1, 1), 30)               # c* = floor(x) + 1, threshold c* - 1
+        h = _mixture_histogram(a, b, lam)
+        out = C.c_uint32(0)
+        assert lib.shk_host_fit(h.ctypes.data, C.byref(out)) == 1
+        assert out.value == expect, (lam, a, b, x)
+        assert oracle_fit(h) == (True, expect)
+        assert py_fit(h) == (True, expect)
+        checked += 1
+    assert checked >= 100
+
+
 def test_product_does_not_touch_the_oracle():
     """The product path must never import, load or link anything under oracle/."""
     pkg = os.path.join(ROOT, "sparrowhawk_amd")

@@ -77,6 +77,56 @@ def py_nthash(s):
     return min(fh, rh)
 
 
+def py_fit(histo, min_count_fallback=None, iters=200):
+    """SPEC S6 written from the text of the spec, in Python floats (IEEE binary64) with math.lgamma/log/exp —
+    independent of csrc/fit.cpp and oracle/shk_oracle.c (which share their loop structure).  Vectorless on
+    purpose: sums run in ascending c like the spec's, so ties in the last bit cannot flip an integer result.
+    Returns (ok, used_min_count) — used_min_count is None when the fit fails."""
+    from math import exp, lgamma, log
+    h = [float(int(x)) for x in histo]
+    assert len(h) == 500
+    tot = sum(h)
+    if tot == 0.0:
+        return False, min_count_fallback
+    den = sum(h[c - 1] for c in range(2, 501))
+    lam = (sum(c * h[c - 1] for c in range(2, 501)) / den) if den > 0 else 2.0
+    lam = max(2.0, lam)
+    w = 0.5
+    lg = [lgamma(c + 1.0) for c in range(0, 501)]
+
+    def logp(c, mean, logmean):
+        return c * logmean - mean - lg[c]
+
+    def exp(x, _e=exp):                     # IEEE semantics: overflow is +inf (C's exp), not an exception
+        try:
+            return _e(x)
+        except OverflowError:
+            return float("inf")
+
+    for _ in range(iters):
+        l1w, lw, llam = log(1.0 - w), log(w), log(lam)
+        sw = sn = sd = 0.0
+        for c in range(1, 501):
+            hc = h[c - 1]
+            if hc == 0.0:
+                continue
+            r = 1.0 / (1.0 + exp((l1w + logp(c, lam, llam)) - (lw + logp(c, 1.0, 0.0))))
+            sw += hc * r
+            sn += hc * (1.0 - r) * c
+            sd += hc * (1.0 - r)
+        w = min(max(sw / tot, 1e-9), 1.0 - 1e-9)
+        if sd > 0.0:
+            lam = sn / sd
+        lam = max(lam, 1.000001)
+    if lam < 2.5:
+        return False, min_count_fallback
+    l1w, lw, llam = log(1.0 - w), log(w), log(lam)
+    for c in range(2, 501):
+        if l1w + logp(c, lam, llam) > lw + logp(c, 1.0, 0.0):
+            return True, min(max(c - 1, 1), 30)
+    return False, min_count_fallback
+
+
 def sorted_table(keys, cnt):
     """Sort rows of (keys[n,W], cnt[n]) by key, most significant word first."""
     if len(cnt) == 0:
