@@ -165,3 +165,127 @@ def to_fastq_fixed(codes, quals):
     out[:, 15 + L:15 + 2 * L] = quals
     out[:, 15 + 2 * L] = 10
     return out.tobytes()
+
+
+# ---- configs[3] / configs[4] inputs: many genomes, generated on the device from one seed -------------------
+_M64 = (1 << 64) - 1
+
+
+def _mix64(torch, x):
+    """splitmix64 finaliser on int64 tensors (two's complement wrap-around = arithmetic mod 2^64)."""
+    def c(v):                                   # python int -> the int64 with the same bit pattern
+        return v - (1 << 64) if v >= (1 << 63) else v
+    x = x + c(0x9E3779B97F4A7C15)
+    x = (x ^ ((x >> 30) & ((1 << 34) - 1))) * c(0xBF58476D1CE4E5B9)
+    x = (x ^ ((x >> 27) & ((1 << 37) - 1))) * c(0x94D049BB133111EB)
+    return x ^ ((x >> 31) & ((1 << 33) - 1))
+
+
+def substitution_flags(torch, read_idx, read_len, err, seed):
+    """Substitution errors as a pure function of (seed, read index, position in the read as sequenced): returns
+    (flag bool[R, L], shift int32[R, L] in 1..3).  Recomputable for any subset of reads, so a check can ask for
+    the errors of exactly the reads that cover a position without the generator having kept 150 flags per read."""
+    j = torch.arange(read_len, device=read_idx.device, dtype=torch.int64)
+    u = _mix64(torch, (read_idx.to(torch.int64)[:, None] * read_len + j[None, :]) ^ (seed * 0x632BE59BD9B4E019 % (1 << 62)))
+    thr = int(err * (1 << 40))
+    flag = ((u >> 13) & ((1 << 40) - 1)) < thr
+    shift = (((u >> 3) & 0x3FF) % 3 + 1).to(torch.int32)
+    return flag, shift
+
+
+class DeviceSample(DeviceReads):
+    """Reads of MANY genomes (a batch of isolates pooled, or a metagenome) in HBM."""
+    def __init__(self):
+        super().__init__()
+        self.genome_off = None   # int64[n_genomes+1] offsets into the concatenated genome codes (self.genome, int8)
+        self.gid = None          # int32[n_reads] source genome of each read
+        self.read_index0 = 0     # global index of this share's first read (errors are a function of the global index)
+        self.err = 0.0
+        self.err_seed = 0
+        self.read_len = 0
+        self.weights = None      # float64[n_genomes] read-sampling probability of each genome
+
+
+def device_genomes(torch, dev, lengths, seed):
+    """Concatenated uniform i.i.d. genomes (int8 codes) + offsets; the same on every rank for one seed."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    off = np.concatenate([[0], np.cumsum(np.asarray(lengths, dtype=np.int64))])
+    total = int(off[-1])
+    codes = torch.empty(total, dtype=torch.int8, device=dev)
+    step = 1 << 28
+    for b0 in range(0, total, step):
+        n = min(step, total - b0)
+        codes[b0:b0 + n] = torch.randint(0, 4, (n,), generator=g, device=dev, dtype=torch.int8)
+    return codes, torch.from_numpy(off).to(dev)
+
+
+def device_sample_reads(torch, dev, genomes, genome_off, weights, n_reads, read_len, k, seed, err=0.0,
+                        read_index0=0, chunk=1 << 18):
+    """n_reads reads (global indices read_index0 ...) drawn from the genomes with probabilities `weights`
+    (numpy float64, sums to 1): uniform start, random strand, substitution errors at rate `err` that are a pure
+    function of (seed, global read index, position).  Every read is one segment (no quality masking).
+    Every rank of a sharded run calls this with its own read_index0 and gets its share of ONE sample."""
+    out = DeviceSample()
+    out.genome, out.genome_off = genomes, genome_off
+    out.n_reads = out.n_seg = int(n_reads)
+    out.n_bases = out.n_input_bases = int(n_reads) * read_len
+    out.read_index0, out.err, out.err_seed, out.read_len = int(read_index0), float(err), int(seed), read_len
+    out.weights = np.asarray(weights, dtype=np.float64)
+    out.instances = int(n_reads) * (read_len - k + 1)
+    lens = (genome_off[1:] - genome_off[:-1])
+    cdf = torch.from_numpy(np.cumsum(out.weights)).to(dev)
+    ar = torch.arange(read_len, device=dev)
+    n_words = (out.n_bases + 15) // 16 + 1
+    words = torch.zeros(n_words, dtype=torch.int32, device=dev)
+    shifts = 2 * torch.arange(16, device=dev, dtype=torch.int32)
+    gids, starts, strands = [], [], []
+    assert (chunk * read_len) % 16 == 0
+    for r0 in range(0, int(n_reads), chunk):
+        R = min(chunk, int(n_reads) - r0)
+        idx = torch.arange(read_index0 + r0, read_index0 + r0 + R, device=dev, dtype=torch.int64)
+        # three independent uniforms per read from the read's global index: genome, start, strand
+        u1 = _mix64(torch, idx ^ (seed * 0x2545F4914F6CDD1D % (1 << 62)))
+        u2 = _mix64(torch, u1 ^ 0x5851F42D4C957F2D)
+        u3 = _mix64(torch, u2 ^ 0x14057B7EF767814F)
+        f1 = ((u1 >> 11) & ((1 << 53) - 1)).to(torch.float64) / float(1 << 53)
+        gid = torch.clamp(torch.searchsorted(cdf, f1, right=True), max=cdf.numel() - 1)
+        span = lens[gid] - read_len + 1
+        f2 = ((u2 >> 11) & ((1 << 53) - 1)).to(torch.float64) / float(1 << 53)
+        st = genome_off[gid] + torch.clamp((f2 * span.to(torch.float64)).to(torch.int64), max=span - 1)
+        strand = ((u3 >> 17) & 1).bool()
+        codes = genomes[st[:, None] + ar[None, :]].to(torch.int32)
+        codes = torch.where(strand[:, None], (3 - codes).flip(1), codes)       # as sequenced
+        if err > 0:
+            flag, shift = substitution_flags(torch, idx, read_len, err, seed)
+            codes = torch.where(flag, (codes + shift) & 3, codes)
+        flat = codes.reshape(-1)
+        pad = (-flat.numel()) % 16
+        if pad:
+            flat = torch.cat([flat, torch.zeros(pad, dtype=torch.int32, device=dev)])
+        w = (flat.reshape(-1, 16) << shifts[None, :]).sum(dim=1, dtype=torch.int32)
+        w0 = (r0 * read_len) // 16
+        words[w0:w0 + w.numel()] = w
+        gids.append(gid.to(torch.int32)); starts.append(st); strands.append(strand)
+    out.words = words
+    out.seg_off = (torch.arange(int(n_reads) + 1, device=dev, dtype=torch.int64) * read_len).to(torch.int32)
+    out.gid, out.starts, out.strand = torch.cat(gids), torch.cat(starts), torch.cat(strands)
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    return out
+
+
+def metagenome_spec(n_genomes=2000, mean_len=3_000_000, sigma=1.0, seed=0xEC05):
+    """SURVEY.md 8d cfg 5: genome lengths ~3 Mbp (uniform +-20 %), log-normal abundance (sigma 1).  A genome's
+    share of the reads is proportional to abundance x length.  numpy only (identical on every rank)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    lengths = rng.integers(int(mean_len * 0.8), int(mean_len * 1.2) + 1, size=n_genomes).astype(np.int64)
+    abundance = np.exp(rng.normal(0.0, sigma, size=n_genomes))
+    w = abundance * lengths
+    return lengths, w / w.sum()
+
+
+def isolate_batch_spec(n_isolates=96, lo=2_000_000, hi=7_000_000, seed=0xEC04):
+    """SURVEY.md 8d cfg 4: 96 genomes with lengths uniform in [2 M, 7 M] bp; isolate i is generated from seed + i."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    return rng.integers(lo, hi + 1, size=n_isolates).astype(np.int64)

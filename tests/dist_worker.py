@@ -57,6 +57,36 @@ def main():
         res = {"ok": bool(ok), "rank": rank, "P": choose_partitions(10 ** 9, world)}
         with open(f"{out_path}.{rank}", "w") as f:
             json.dump(res, f)
+    elif mode == "batch":
+        # configs[3] rounds path: every isolate sharded over the ranks (both on cuda:0; collectives over gloo)
+        import hashlib
+        from sparrowhawk_amd import synth
+        from sparrowhawk_amd.batch import assemble_batch
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        comm = Comm(device=dev)
+        cfg = json.load(open(sys.argv[3]))
+        lengths, k, seed0, L = cfg["lengths"], cfg["k"], cfg["seed0"], 150
+        cache = {}
+
+        def reads_for(i, share_rank, share_world):
+            n_reads = int(lengths[i]) * cfg["coverage"] // L
+            if i not in cache:
+                cache.clear()
+                cache[i] = synth.device_genomes(torch, dev, [int(lengths[i])], seed0 + i)
+            g, off = cache[i]
+            lo, hi = n_reads * share_rank // share_world, n_reads * (share_rank + 1) // share_world
+            return synth.device_sample_reads(torch, dev, g, off, np.array([1.0]), hi - lo, L, k, seed0 + i,
+                                             err=cfg["err"], read_index0=lo)
+        out = assemble_batch(len(lengths), reads_for, dict(k=k, min_count=cfg["min_count"], min_qual=20), mode="rounds",
+                             rank=rank, world=world, torch_comm=comm)
+        res = {}
+        for i, (pre, asm, t) in out.items():
+            res[str(i)] = {"pre": pre, "asm_sha256": hashlib.sha256(asm.encode()).hexdigest()}
+            if cfg.get("keep"):
+                res[str(i)]["asm"] = asm
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(res, f)
     elif mode == "rccl":
         from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
         from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl

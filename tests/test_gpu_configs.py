@@ -1,0 +1,271 @@
+"""The BASELINE.json configs the bench line is NOT quoted on, each exercised on the GPU at its per-GPU share:
+
+  configs[0]  5 Mbp isolate, 50x, k = 31 (the reference's CPU-plumbing case), full size
+  configs[3]  batch of 96 isolates on 8 GPUs -> 12 isolates of 2-7 Mbp per GPU, 100x, 0.5 % errors: through
+              the replica path (one isolate per handle, no collective) and through the sharded rounds path
+              (2 ranks on the one GPU; collectives rehearsed over gloo, RCCL needs one GPU per rank);
+              per-isolate bytes identical across both, and, at a size the oracle covers, equal to the oracle
+  configs[4]  metagenome of 2 000 genomes (log-normal abundance, sigma 1), 200 M reads on 8 GPUs -> 25 M reads
+              per GPU, 0.5 % errors, min_count = 2, generated on the device from seed 0xEC05
+
+Full-size runs are checked through the closed forms of tests/test_gpu_fullsize.py (the oracle needs minutes at
+these sizes): window counts, sum_c c*histo[c], exact counts of sampled genome k-mers recomputed from the
+generator's read placement and its (recomputable) substitution flags, contigs that are substrings of a genome,
+byte-identical reruns."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from sparrowhawk_amd import AssemblyHelper, synth
+from sparrowhawk_amd.batch import assemble_batch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = 150
+COMP = str.maketrans("ACGT", "TGCA")
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+def codes_str(t):
+    return "".join("ACGT"[c] for c in t.cpu().tolist())
+
+
+def contigs_of_json(asm):
+    fa = json.loads(asm)["outfasta"].split("\n")
+    return [l for l in fa if l and not l.startswith(">")]
+
+
+def lookup(sk, sc, words):
+    lo, hi = 0, len(sc)
+    for j in range(sk.shape[1] - 1, -1, -1):
+        col = sk[lo:hi, j]
+        a = np.searchsorted(col, np.uint64(words[j]), "left")
+        b = np.searchsorted(col, np.uint64(words[j]), "right")
+        lo, hi = lo + a, lo + b
+    return (int(sc[lo]) if hi > lo else 0), hi - lo
+
+
+def canonical_words(s, W):
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    def val(t):
+        v = 0
+        for ch in t:
+            v = (v << 2) | code[ch]
+        return v
+    v = min(val(s), val(s.translate(COMP)[::-1]))
+    return [(v >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(W)]
+
+
+def check_sampled_counts(torch, d, h, k, positions):
+    """count(genome k-mer at global position p) == number of reads that cover [p, p+k) without a substitution
+    inside, from the generator's placement (d.starts, d.strand) and its recomputable error flags."""
+    keys, cnt = h.solid()
+    W = keys.shape[1]
+    order = np.lexsort([keys[:, j] for j in range(W)])
+    sk, sc = keys[order], cnt[order]
+    used = h.used_min_count
+    n_present = 0
+    for p in positions:
+        sel = torch.nonzero((d.starts >= p + k - L) & (d.starts <= p)).flatten()
+        expect = int(sel.numel())
+        if d.err > 0 and expect:
+            flag, _ = synth.substitution_flags(torch, sel + d.read_index0, L, d.err, d.err_seed)      # as sequenced
+            off = p - d.starts[sel]                                   # window start in forward coordinates
+            off = torch.where(d.strand[sel], L - off - k, off)        # ... in the read as sequenced
+            cs = torch.zeros((sel.numel(), L + 1), dtype=torch.int32, device=flag.device)
+            cs[:, 1:] = torch.cumsum(flag.to(torch.int32), 1)
+            ar = torch.arange(sel.numel(), device=flag.device)
+            expect = int(((cs[ar, off + k] - cs[ar, off]) == 0).sum().item())
+        kmer = codes_str(d.genome[p:p + k])
+        got, n = lookup(sk, sc, canonical_words(kmer, W))
+        if expect > used:
+            assert n == 1 and got == expect, (p, got, expect)
+            n_present += 1
+        else:
+            assert n == 0, (p, "k-mer at or below the threshold must not be solid", got, expect)
+    return n_present
+
+
+# ---- configs[0] -----------------------------------------------------------------------------------------
+def test_config0_isolate_50x_k31(torch_dev):
+    torch, dev = torch_dev
+    G, k = 5_000_000, 31
+    n_reads = (G * 50 + L - 1) // L
+    d = synth.device_reads(torch, dev, G, n_reads, L, k, 0xEC01, keep_meta=True)
+    assert n_reads == 1_666_667
+    h = AssemblyHelper.new(k, True, 5, 20, 0, False, False, False, False)
+    h.preprocess_packed_device(d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads)
+    h.assemble()
+    hist = h.histo()
+    assert h.total_instances == n_reads * (L - k + 1)
+    assert int((hist * np.arange(1, 501, dtype=np.uint64)).sum()) == h.total_instances and int(hist[499]) == 0
+    assert h.n_solid == int(hist[5:].sum())
+    gs = codes_str(d.genome)
+    cs = contigs_of_json(h.get_assembly())
+    rc = gs.translate(COMP)[::-1]
+    # at 50x a few loci are covered <= 5 times: the contigs are the pieces between them, all substrings
+    assert 1 <= len(cs) <= 40 and all(c in gs or c in rc for c in cs)
+    assert sum(len(c) - k + 1 for c in cs) == h.n_solid
+    h2 = AssemblyHelper.new(k, True, 5, 20, 0, False, False, False, False)
+    h2.preprocess_packed_device(d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads)
+    h2.assemble()
+    assert h2.get_assembly() == h.get_assembly()
+
+
+# ---- configs[3] -----------------------------------------------------------------------------------------
+def isolate_reads_factory(torch, dev, lengths, coverage, err, k, seed0):
+    """reads_for(i, share_rank, share_world): isolate i from seed0 + i, this rank's contiguous share of its reads."""
+    cache = {}
+
+    def reads_for(i, share_rank, share_world):
+        n_reads = int(lengths[i]) * coverage // L
+        if i not in cache:
+            cache.clear()                                                        # one genome at a time in memory
+            cache[i] = synth.device_genomes(torch, dev, [int(lengths[i])], seed0 + i)
+        g, off = cache[i]
+        lo = n_reads * share_rank // share_world
+        hi = n_reads * (share_rank + 1) // share_world
+        return synth.device_sample_reads(torch, dev, g, off, np.array([1.0]), hi - lo, L, k, seed0 + i, err=err,
+                                         read_index0=lo)
+    return reads_for
+
+
+def run_rounds_two_ranks(cfg, port):
+    """The sharded rounds path with 2 ranks on the one GPU (tests/dist_worker.py mode 'batch')."""
+    from test_dist import launch
+    with tempfile.TemporaryDirectory() as d:
+        cfgp = os.path.join(d, "cfg.json")
+        json.dump(cfg, open(cfgp, "w"))
+        out = os.path.join(d, "res")
+        launch(2, ["batch", out, cfgp], port, timeout=900)
+        return [json.load(open(f"{out}.{r}")) for r in range(2)]
+
+
+def test_config3_batch_of_isolates_small_equals_oracle(torch_dev):
+    torch, dev = torch_dev
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import run_oracle
+    k, cov, err, seed0, n_iso = 31, 40, 0.005, 0xEC04, 12
+    lengths = synth.isolate_batch_spec(n_iso, 20_000, 70_000, seed0)
+    params = dict(k=k, min_count=3, min_qual=20)
+    reads_for = isolate_reads_factory(torch, dev, lengths, cov, err, k, seed0)
+    rep = assemble_batch(n_iso, reads_for, params, mode="replicas")
+    assert sorted(rep) == list(range(n_iso))
+    # the same isolates against the oracle: FASTQ text of exactly the generated reads
+    shifts = 2 * torch.arange(16, device=dev, dtype=torch.int32)
+    for i in range(n_iso):
+        d = reads_for(i, 0, 1)
+        codes = ((d.words[: (d.n_bases + 15) // 16, None] >> shifts[None, :]) & 3).reshape(-1)[: d.n_bases]
+        c = codes.reshape(d.n_reads, L).to(torch.uint8).cpu().numpy()
+        fq = synth.to_fastq(c, np.full(c.shape, 40 + 33, dtype=np.uint8))
+        o = run_oracle([fq], k=k, min_count=3, min_qual=20)
+        o.assemble()
+        assert rep[i][0] == o.preprocessing_json(), i
+        assert rep[i][1] == o.assembly_json(), i
+    # rounds: every isolate sharded over 2 ranks
+    res = run_rounds_two_ranks(dict(lengths=[int(x) for x in lengths], coverage=cov, err=err, k=k, min_count=3,
+                                    seed0=seed0, keep=True), 29731)
+    for i in range(n_iso):
+        assert res[0][str(i)]["asm"] == res[1][str(i)]["asm"] == rep[i][1], i
+        assert res[0][str(i)]["pre"] == rep[i][0], i
+
+
+def test_config3_share_of_one_gpu_full_size(torch_dev):
+    """12 of the 96 isolates (the share of one of 8 GPUs): 2-7 Mbp each, 100x, 0.5 % substitution errors left in."""
+    torch, dev = torch_dev
+    k, cov, err, seed0 = 31, 100, 0.005, 0xEC04
+    lengths = synth.isolate_batch_spec(96, 2_000_000, 7_000_000, seed0)[:12]
+    assert lengths.min() >= 2_000_000 and lengths.max() <= 7_000_000
+    params = dict(k=k, min_count=5, min_qual=20)
+    reads_for = isolate_reads_factory(torch, dev, lengths, cov, err, k, seed0)
+    checks = {}
+
+    def inspect(i, h):
+        d = reads_for(i, 0, 1)                                               # (same seed: the same reads again)
+        hist = h.histo()
+        assert h.total_instances == d.n_reads * (L - k + 1)
+        assert int(hist[499]) == 0 and int((hist * np.arange(1, 501, dtype=np.uint64)).sum()) == h.total_instances
+        assert h.n_solid == int(hist[5:].sum())
+        rng = np.random.default_rng(100 + i)
+        pos = rng.integers(300, int(lengths[i]) - 300 - k, size=60).tolist()
+        assert check_sampled_counts(torch, d, h, k, pos) >= 55
+        gs = codes_str(d.genome)
+        rc = gs.translate(COMP)[::-1]
+        cs = contigs_of_json(h.get_assembly())
+        assert sum(len(c) for c in cs) >= int(lengths[i]) - 2000
+        assert sum(1 for c in cs if c not in gs and c not in rc) <= 2           # (see test_gpu_fullsize: rare solid error k-mers)
+        checks[i] = len(cs)
+
+    rep = assemble_batch(12, reads_for, params, mode="replicas", on_result=inspect)
+    assert len(checks) == 12
+    res = run_rounds_two_ranks(dict(lengths=[int(x) for x in lengths], coverage=cov, err=err, k=k, min_count=5,
+                                    seed0=seed0, keep=False), 29732)
+    for i in range(12):
+        sha = hashlib.sha256(rep[i][1].encode()).hexdigest()
+        assert res[0][str(i)]["asm_sha256"] == res[1][str(i)]["asm_sha256"] == sha, i
+        assert res[0][str(i)]["pre"] == rep[i][0], i
+
+
+# ---- configs[4] -----------------------------------------------------------------------------------------
+def test_config4_metagenome_share_of_one_gpu(torch_dev):
+    """25 M of the 200 M reads (rank 3's share, global read indices 75 M ...) of the 2 000-genome metagenome."""
+    torch, dev = torch_dev
+    k, err, seed = 31, 0.005, 0xEC05
+    lengths, weights = synth.metagenome_spec(2000, 3_000_000, 1.0, seed)
+    assert 5.5e9 < lengths.sum() < 6.5e9
+    genomes, goff = synth.device_genomes(torch, dev, lengths, seed)
+    n_share = 25_000_000
+    d = synth.device_sample_reads(torch, dev, genomes, goff, weights, n_share, L, k, seed, err=err, read_index0=3 * n_share)
+    assert d.n_bases == 3_750_000_000
+
+    def run():
+        h = AssemblyHelper.new(k, False, 2, 20, 0, False, False, False, False)
+        h.preprocess_packed_device(d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads)
+        h.assemble()
+        return h
+    h = run()
+    hist = h.histo()
+    assert h.total_instances == n_share * (L - k + 1) == 3_000_000_000
+    assert int(hist[499]) == 0 and int((hist * np.arange(1, 501, dtype=np.uint64)).sum()) == h.total_instances
+    assert h.n_distinct == int(hist.sum()) and h.n_solid == int(hist[2:].sum()) > 0
+    # sampled exact counts in the most abundant genomes (coverage of this share: ~20x there, 0.6x on average)
+    top = np.argsort(-(weights / lengths))[:8]
+    rng = np.random.default_rng(9)
+    pos = []
+    for gi in top:
+        base = int(goff[gi].item())
+        pos += (base + rng.integers(300, int(lengths[gi]) - 300 - k, size=25)).tolist()
+    assert check_sampled_counts(torch, d, h, k, pos) >= 150
+    # ... and in mid-abundance genomes, where most k-mers stay at or below the threshold
+    mid = np.argsort(-(weights / lengths))[900:904]
+    pos = []
+    for gi in mid:
+        base = int(goff[gi].item())
+        pos += (base + rng.integers(300, int(lengths[gi]) - 300 - k, size=25)).tolist()
+    check_sampled_counts(torch, d, h, k, pos)
+    asm = h.get_assembly()
+    cs = contigs_of_json(asm)
+    n_nodes = sum(len(c) - k + 1 for c in cs)
+    assert 0 < n_nodes <= h.n_solid                                            # correction only ever removes nodes
+    # the longest contigs come from the most abundant genomes: substrings of one of them
+    tops = {int(gi): codes_str(genomes[int(goff[gi].item()): int(goff[gi + 1].item())]) for gi in top[:3]}
+    long_ones = sorted(cs, key=len, reverse=True)[:20]
+    hits = sum(1 for c in long_ones if any(c in g or c.translate(COMP)[::-1] in g for g in tops.values()))
+    assert hits >= 1
+    sha = hashlib.sha256(asm.encode()).hexdigest()
+    t = h.timings()
+    h.free()
+    h2 = run()
+    assert hashlib.sha256(h2.get_assembly().encode()).hexdigest() == sha
+    print("configs[4] share: n_distinct", int(hist.sum()), "n_solid", int(hist[2:].sum()), "ncontigs", len(cs), "timings", t)
