@@ -6,21 +6,48 @@
 // a12: collapse (SPEC S10).  Simple links over oriented nodes, splitters = all heads plus a 1/32
 // sample, one walker per splitter, the splitter list ranked by pointer jumping, then every node
 // scatters its base into the contig buffer.
-//   winfo[v] = {succ(v) or NIL, count(v>>1)}   one 8-byte read per walker step
+//   winfo[v] = {succ(v) or NIL, count(v>>1), top 32 bits of the canonical k-mer, -}   one 16-byte read per walker step
 //   ol[v]    = {owner splitter, position in its segment}
 // A node is sampled by a hash of its ID: a walker decides "is my successor a splitter" from the id it
 // just read, without touching the successor (heads are never reached through a simple link: a node
 // with a simple predecessor is not a head).
+//
+// Circular unitigs (a chain of simple links that closes on itself: bacterial chromosomes, plasmids) have no head.
+// SPEC S10 cuts them before their smallest k-mer.  The ranking handles them in the same pass as the linear chains:
+// next to the usual prefix sums every splitter carries (a) the smallest splitter index in the window of
+// predecessors it has seen, with the distance from that splitter to itself, and (b) the smallest k-mer of that
+// window.  Once the windows span the ring, (a) is a rank relative to the ring's smallest splitter — the ring is
+// "opened" there without a second ranking — and (b) is the SPEC's cut point; the emission rotates the spelling by
+// the difference.  K-mers are compared by their top 32 bits, which travel in winfo; the full key is only loaded
+// on a tie.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool node_sampled(uint32_t v, uint32_t split_mask) {
     return ((mix32(v ^ 0x5bd1e995u) >> 9) & split_mask) == 0;
+}
+
+// top 32 bits of the 2k-bit canonical k-mer (order-preserving prefix)
+template <int W> __device__ __forceinline__ uint32_t km_top32(const KeyArr<W> &keys, uint32_t idx, int k) {
+    const int used = 2 * k - 64 * (W - 1);                 // bits in the top word: 1..64 (k odd => even, >= 2)
+    const uint64_t hi = keys.w[W - 1][idx];
+    if (used >= 32) return (uint32_t)(hi >> (used - 32));
+    if constexpr (W >= 2) return (uint32_t)((hi << (32 - used)) | (keys.w[W - 2][idx] >> (32 + used)));
+    else return (uint32_t)(hi << (32 - used));            // (k < 16: the whole key)
+}
+// is the k-mer of oriented node a smaller than that of b?  (tops first; equal k-mers: the smaller oriented id)
+template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g, uint32_t ta, uint32_t a, uint32_t tb, uint32_t b) {
+    if (ta != tb) return ta < tb;
+    if ((a >> 1) == (b >> 1)) return a < b;
+    const Kmer<W> ka = g.keys.load(a >> 1), kb = g.keys.load(b >> 1);
+    if (km_less<W>(ka, kb)) return true;
+    if (km_less<W>(kb, ka)) return false;
+    return a < b;
 }
 
 static constexpr int SS_ITEMS = 16;            // oriented nodes per thread of k_succ_split
 
 template <int W>
 __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *__restrict__ alive,
-                                                    uint2 *__restrict__ winfo, uint32_t *__restrict__ spl,
+                                                    uint4 *__restrict__ winfo, uint32_t *__restrict__ spl,
                                                     uint2 *__restrict__ ol, unsigned int *__restrict__ n_spl,
                                                     uint32_t split_mask) {
     __shared__ uint32_t wtot[SS_ITEMS * 4];
@@ -33,17 +60,18 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
 #pragma unroll 1
     for (int it = 0; it < SS_ITEMS; it++) {
         const uint32_t v = base + (uint32_t)it * 256u + threadIdx.x;
-        uint32_t s = NIL, c = 0; bool al = false;
+        uint32_t s = NIL, c = 0, top = 0; bool al = false;
         if (v < total) {
             al = alive[v >> 1] != 0;
             if (al) {
                 c = g.cnt[v >> 1];
+                top = km_top32<W>(g.keys, v >> 1, g.k);
                 if (g.outdeg(v) == 1) {
                     const uint32_t u = g.only_out(v);
                     if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
                 }
             }
-            uint2 w; w.x = s; w.y = c; winfo[v] = w;
+            uint4 w; w.x = s; w.y = c; w.z = top; w.w = 0; winfo[v] = w;
         }
         const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node
         const bool p = al && (sp == NIL || node_sampled(v, split_mask));   // head or sampled
@@ -75,98 +103,192 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
     }
 }
 
-struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, pad; };
+// head: 0 = has a splitter before it; HEAD_LINEAR = first splitter of a linear chain; HEAD_ORPHAN = a circular
+// unitig without any sampled node, spelled from its smallest k-mer (k_orphan_cycles).
+// mintop / minnode: the smallest k-mer among the segment's nodes (its top 32 bits, the oriented node).
+struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, minnode, mintop, pad; };
+static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__ winfo,
+__global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint4 *__restrict__ winfo,
                                                        const uint32_t *__restrict__ spl, uint32_t n_spl,
                                                        uint2 *__restrict__ ol, SegRec *__restrict__ segs,
                                                        uint32_t split_mask) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
-        uint32_t cur = s, len = 0, nxt;
+        uint32_t cur = s, len = 0, nxt, mtop = 0xFFFFFFFFu, mnode = s;
         unsigned long long sum = 0;
         for (;;) {
-            const uint2 w = winfo[cur];
+            const uint4 w = winfo[cur];
             if (cur != s) { uint2 o; o.x = i; o.y = len; ol[cur] = o; }
+            if (len == 0 || node_key_less<W>(g, w.z, cur, mtop, mnode)) { mtop = w.z; mnode = cur; }
             sum += w.y;
             len++;
             nxt = w.x;
             if (nxt == NIL || node_sampled(nxt, split_mask)) break;
             cur = nxt;
         }
-        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum;
+        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum; r.minnode = mnode; r.mintop = mtop; r.pad = 0;
         r.next_spl = (nxt == NIL) ? NIL : ol[nxt].x;       // splitters got their owner in k_succ_split
-        r.head = winfo[s ^ 1u].x == NIL ? 1u : 0u; r.pad = 0;
+        r.head = winfo[s ^ 1u].x == NIL ? HEAD_LINEAR : 0u;
         segs[i] = r;
     }
 }
 
-// ---- splitter-list ranking on the device (pointer jumping over ~2N/64 elements) ------------------
-// P: predecessor pointer converging to the chain's head splitter (heads point to themselves);
-// A: nodes before this splitter in its chain; K: counts before it.
-__global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ segs, uint32_t n_spl,
-                                                   uint32_t *__restrict__ P, uint32_t *__restrict__ A,
-                                                   unsigned long long *__restrict__ K) {
+// A circular unitig that holds no sampled node (short ones: the chance is (31/32)^n) is owned by no walker: its
+// nodes are the alive nodes without an owner.  Every such node walks its cycle; the one that IS the cycle's smallest
+// k-mer acts: in orientation 0 it becomes a head splitter whose one segment is the whole cycle spelled from itself
+// (exactly SPEC S10's cut); in orientation 1 it is the mirror strand and nothing is emitted for it.
+static constexpr uint32_t ORPHAN_MAX = 1u << 16;          // (no sampled node among n: (31/32)^n; 65536 never happens)
+template <int W>
+__global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t *__restrict__ alive,
+                                                       const uint4 *__restrict__ winfo, uint2 *__restrict__ ol,
+                                                       uint32_t *__restrict__ spl, SegRec *__restrict__ segs,
+                                                       unsigned int *__restrict__ n_spl,
+                                                       uint32_t seg_cap, uint32_t *__restrict__ flags) {
+    const uint32_t total = g.n * 2;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        if (!alive[v >> 1] || ol[v].x != NIL) continue;
+        const uint4 w0 = winfo[v];
+        uint32_t best = v, btop = w0.z, n = 1, cur = w0.x, last = v;
+        unsigned long long sum = w0.y;
+        bool ok = true;
+        while (cur != v) {
+            if (cur == NIL || n >= ORPHAN_MAX) { ok = false; break; }
+            const uint4 w = winfo[cur];
+            if (node_key_less<W>(g, w.z, cur, btop, best)) { btop = w.z; best = cur; }
+            sum += w.y; n++; last = cur; cur = w.x;
+        }
+        if (!ok) { flags[0] = 1; continue; }
+        if (best != v || (v & 1u)) continue;                // not the cut point / the mirror strand
+        const uint32_t idx = atomicAdd(n_spl, 1u);
+        if (idx >= seg_cap) { flags[0] = 2; continue; }
+        spl[idx] = v;
+        cur = v;
+        for (uint32_t j = 0; j < n; j++) { uint2 o; o.x = idx; o.y = j; ol[cur] = o; cur = winfo[cur].x; }
+        SegRec r; r.node = v; r.next_spl = NIL; r.len = n; r.last = last; r.sum = sum; r.head = HEAD_ORPHAN;
+        r.minnode = v; r.mintop = btop; r.pad = 0;
+        segs[idx] = r;
+    }
+}
+
+// ---- splitter-list ranking on the device (pointer jumping over ~2N/32 elements) ------------------
+// P: predecessor pointer converging to the chain's head splitter (heads point to themselves); A / K: nodes / counts
+// between the start of splitter P and the start of this one.  For rings (see the file header): m = the smallest
+// splitter index among this splitter and the predecessors its window covers, d / dK = nodes / counts from the start
+// of m to the start of this one (the NEAREST occurrence of m going backwards, so d stays below the ring's length
+// however often the windows wrap), mt / mk = the smallest k-mer of the window (top 32 bits, oriented node).
+struct RankRec { uint32_t P, A, m, d; unsigned long long K, dK; uint32_t mt, mk; };
+// (the splitter count lives on the device: k_orphan_cycles may have appended to the list after the host read it)
+__global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ segs, const unsigned int *__restrict__ n_spl_p,
+                                                   RankRec *__restrict__ R) {
+    const uint32_t n_spl = *n_spl_p;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
         const SegRec r = segs[s];
-        if (r.head) { P[s] = s; A[s] = 0; K[s] = 0; }
-        if (r.next_spl != NIL) { P[r.next_spl] = s; A[r.next_spl] = r.len; K[r.next_spl] = r.sum; }
+        R[s].m = s; R[s].d = 0; R[s].dK = 0; R[s].mt = r.mintop; R[s].mk = r.minnode;
+        if (r.head) { R[s].P = s; R[s].A = 0; R[s].K = 0; }
+        if (r.next_spl != NIL) { R[r.next_spl].P = s; R[r.next_spl].A = r.len; R[r.next_spl].K = r.sum; }
     }
 }
 // one launch follows HOPS pointers (the reach grows HOPS-fold per launch instead of doubling: a launch
 // over ~300 k splitters is all latency, so ceil(log4 n) launches of four dependent reads beat
 // ceil(log2 n) launches of two); heads point to themselves with A = K = 0, so overshooting adds nothing
 static constexpr int RANK_HOPS = 4;
-__global__ __launch_bounds__(256) void k_rank_jump(uint32_t n_spl, const uint32_t *__restrict__ Pi,
-                                                   const uint32_t *__restrict__ Ai,
-                                                   const unsigned long long *__restrict__ Ki,
-                                                   uint32_t *__restrict__ Po, uint32_t *__restrict__ Ao,
-                                                   unsigned long long *__restrict__ Ko) {
+template <int W>
+__global__ __launch_bounds__(256) void k_rank_jump(Graph<W> g, const unsigned int *__restrict__ n_spl_p,
+                                                   const RankRec *__restrict__ Ri, RankRec *__restrict__ Ro) {
+    const uint32_t n_spl = *n_spl_p;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
-        uint32_t p = s, a = 0;
-        unsigned long long kc = 0;
+        uint32_t p = s, a = 0, bm = 0xFFFFFFFFu, bd = 0, bt = 0xFFFFFFFFu, bk = NIL;
+        unsigned long long kc = 0, bdk = 0;
 #pragma unroll
-        for (int h = 0; h < RANK_HOPS; h++) { a += Ai[p]; kc += Ki[p]; p = Pi[p]; }
-        Po[s] = p; Ao[s] = a; Ko[s] = kc;
+        for (int h = 0; h < RANK_HOPS; h++) {
+            const RankRec r = Ri[p];
+            // (a, kc): nodes / counts from the start of p to the start of s; p runs from near to far, so the
+            // strict '<' keeps the nearest occurrence of the smallest index
+            if (r.m < bm) { bm = r.m; bd = r.d + a; bdk = r.dK + kc; }
+            if (bk == NIL || (r.mk != bk && node_key_less<W>(g, r.mt, r.mk, bt, bk))) { bt = r.mt; bk = r.mk; }
+            a += r.A; kc += r.K;
+            p = min(r.P, n_spl - 1u);
+        }
+        RankRec o; o.P = p; o.A = a; o.K = kc; o.m = bm; o.d = bd; o.dK = bdk; o.mt = bt; o.mk = bk;
+        Ro[s] = o;
     }
 }
-struct HeadRec { uint32_t spl, head_node, tail_node, emit; unsigned long long len, kc; };
-// every chain's tail splitter reports the chain to its head's record slot.  A unitig exists on
-// both strands; the strand to emit is the lexicographically smaller spelling (SPEC S10), which
-// the first k characters decide: seq(head) against seq(rc(tail)).
+// rot: a circular unitig is spelled from its smallest k-mer (SPEC S10): the node at position p of the ring as ranked
+// (from its smallest splitter) is written at (p - rot) mod len
+struct HeadRec { uint32_t spl, head_node, tail_node, emit, rot, circ; unsigned long long len, kc; };
+struct EmitRec { unsigned long long off; uint32_t rot, len; };      // per chain: output offset (~0: not emitted), rotation
+struct FinRec { uint32_t slot, base; };                             // per splitter: its chain's record, nodes before it
+// Every chain's last splitter reports the chain: for a linear chain the tail (no next splitter), for a ring the
+// splitter in front of the ring's smallest one.  A unitig exists on both strands; of a linear one the strand to
+// emit is the lexicographically smaller spelling (SPEC S10), which the first k characters decide: seq(head)
+// against seq(rc(tail)); of a circular one it is the strand that holds the smallest k-mer in orientation 0.
 template <int W>
-__global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__restrict__ segs, uint32_t n_spl,
-                                                    const uint32_t *__restrict__ P, const uint32_t *__restrict__ A,
-                                                    const unsigned long long *__restrict__ K,
+__global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__restrict__ segs, const unsigned int *__restrict__ n_spl_p,
+                                                    const RankRec *__restrict__ R, const uint2 *__restrict__ ol,
                                                     HeadRec *__restrict__ heads, uint32_t *__restrict__ slot_of,
-                                                    unsigned int *__restrict__ n_heads) {
+                                                    unsigned int *__restrict__ n_heads, unsigned int *__restrict__ n_cyc) {
+    __shared__ uint32_t blk_cyc;
+    if (threadIdx.x == 0) blk_cyc = 0;
+    __syncthreads();
+    const uint32_t n_spl = *n_spl_p;
+    uint32_t my_cyc = 0;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
         const SegRec r = segs[s];
-        if (r.next_spl != NIL) continue;
-        const uint32_t root = P[s];
-        if (root >= n_spl || !segs[root].head) continue;       // (cannot happen: a chain with a tail has a head)
-        const uint32_t slot = atomicAdd(n_heads, 1u);          // one per chain
-        HeadRec h; h.spl = root; h.head_node = segs[root].node; h.tail_node = r.last;
-        {
-            const Kmer<W> a = g.seq(h.head_node), b = g.seq(h.tail_node ^ 1u);
-            if (km_less<W>(a, b)) h.emit = 1;
-            else if (km_less<W>(b, a)) h.emit = 0;
-            else h.emit = h.head_node <= (h.tail_node ^ 1u);       // the chain is its own mirror, or a tie on ids
+        const RankRec me = R[s];
+        const uint32_t hd = segs[me.P].head;
+        if (hd != 0u) {                                            // a chain with a head: linear, or an orphan cycle
+            if (r.next_spl != NIL) continue;
+            const uint32_t root = me.P;
+            const uint32_t slot = atomicAdd(n_heads, 1u);          // one per chain
+            HeadRec h; h.spl = root; h.head_node = segs[root].node; h.tail_node = r.last; h.rot = 0;
+            h.len = (unsigned long long)me.A + r.len; h.kc = me.K + r.sum;
+            if (hd == HEAD_ORPHAN) { h.circ = 1; h.emit = 1; }
+            else {
+                h.circ = 0;
+                const Kmer<W> a = g.seq(h.head_node), b = g.seq(h.tail_node ^ 1u);
+                if (km_less<W>(a, b)) h.emit = 1;
+                else if (km_less<W>(b, a)) h.emit = 0;
+                else h.emit = h.head_node <= (h.tail_node ^ 1u);   // the chain is its own mirror, or a tie on ids
+            }
+            heads[slot] = h; slot_of[root] = slot;
+        } else {                                                   // on a ring, ranked from its smallest splitter me.m
+            my_cyc++;
+            if (r.next_spl != me.m) continue;
+            const uint32_t root = me.m;
+            const uint32_t slot = atomicAdd(n_heads, 1u);
+            HeadRec h; h.spl = root; h.head_node = segs[root].node; h.tail_node = r.last; h.circ = 1;
+            h.len = (unsigned long long)me.d + r.len; h.kc = me.dK + r.sum;
+            const uint32_t vm = me.mk;                             // the ring's smallest k-mer
+            h.emit = (vm & 1u) ? 0u : 1u;
+            const uint2 o = ol[vm];
+            h.rot = R[o.x].d + o.y;
+            heads[slot] = h; slot_of[root] = slot;
         }
-        h.len = (unsigned long long)A[s] + r.len; h.kc = K[s] + r.sum;
-        heads[slot] = h; slot_of[root] = slot;
+    }
+    if (my_cyc) atomicAdd(&blk_cyc, my_cyc);
+    __syncthreads();
+    if (threadIdx.x == 0 && blk_cyc) atomicAdd(n_cyc, blk_cyc);
+}
+// per splitter: which chain record, and how many nodes of the chain come before it
+__global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ segs, const unsigned int *__restrict__ n_spl_p,
+                                                  const RankRec *__restrict__ R, const uint32_t *__restrict__ slot_of,
+                                                  FinRec *__restrict__ fin) {
+    const uint32_t n_spl = *n_spl_p;
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
+        const RankRec me = R[s];
+        const bool ring = segs[me.P].head == 0u;
+        FinRec f; f.slot = slot_of[ring ? me.m : me.P]; f.base = ring ? me.d : me.A;
+        fin[s] = f;
     }
 }
 
-// per node: splitter -> chain head -> output offset (~0 = chain not emitted)
+// per node: splitter -> chain record -> output offset (~0 = chain not emitted)
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
-                                              const uint2 *__restrict__ ol,
-                                              const uint32_t *__restrict__ P,
-                                              const uint32_t *__restrict__ A,
-                                              const uint32_t *__restrict__ slot_of,
-                                              const unsigned long long *__restrict__ head_off,
+                                              const uint2 *__restrict__ ol, const FinRec *__restrict__ fin,
+                                              const EmitRec *__restrict__ head_off,
                                               char *__restrict__ out) {
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
@@ -174,11 +296,13 @@ __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restr
         const uint2 own = ol[v];
         const uint32_t s = own.x;
         if (s == NIL) continue;
-        const uint32_t slot = slot_of[P[s]];
-        if (slot == NIL) continue;
-        const unsigned long long off = head_off[slot];
+        const FinRec f = fin[s];
+        if (f.slot == NIL) continue;
+        const EmitRec er = head_off[f.slot];
+        const unsigned long long off = er.off;
         if (off == ~0ull) continue;
-        const uint32_t pos = A[s] + own.y;
+        uint32_t pos = f.base + own.y;
+        if (er.rot) pos = pos >= er.rot ? pos - er.rot : pos + er.len - er.rot;    // a circular unitig starts at its smallest k-mer
         const Kmer<W> x = g.seq(v);
         char *dst = out + off;
         const uint32_t ACGT = 0x54474341u;                 // 'A','C','G','T' little-endian

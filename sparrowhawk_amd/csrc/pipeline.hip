@@ -1050,6 +1050,8 @@ public:
     }
 
     // ---- collapse ----------------------------------------------------------------------------
+    // Counters in ctl_: 5 = splitters (k_succ_split, then appended to by k_orphan_cycles), 6 = chains reported
+    // (k_rank_tails), 7 = splitters that sit on a circular unitig (statistic), 8 = flags of k_orphan_cycles.
     int collapse(std::vector<RawContig> &out, std::string &err) override {
         out.clear();
         if (!graph_ready_) { err = "graph not built"; return -2; }
@@ -1058,12 +1060,12 @@ public:
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
         DevBuf<uint32_t> spl;
-        DevBuf<uint2> winfo, ol;
+        DevBuf<uint4> winfo; DevBuf<uint2> ol;
         DevBuf<SegRec> segs;
         if (int rc = winfo.alloc(total, err)) return rc;
         if (int rc = spl.alloc(total, err)) return rc;
         if (int rc = ol.alloc(total, err)) return rc;
-        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 8, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 4 * 8, stream_));
         const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
@@ -1073,73 +1075,71 @@ public:
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
         times_.add("collapse_succ_split", t1.stop());
         times_.add("collapse_n_splitters_x1e-3", n_spl * 1e-3);
-        if (n_spl) {
-            if (int rc = segs.alloc(n_spl, err)) return rc;
+        // circular unitigs without a sampled node add one splitter each (k_orphan_cycles): room for them
+        const uint32_t seg_cap = n_spl + total / 8u + 1024u;
+        if (int rc = segs.alloc(seg_cap, err)) return rc;
+        const unsigned int *d_nspl = (const unsigned int *)(ctl_.p + 5);
+        {
             EvTimer t2(stream_);
-            hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
-                               spl.p, n_spl, ol.p, segs.p, split_mask);
+            if (n_spl) {
+                hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, g, winfo.p,
+                                   spl.p, n_spl, ol.p, segs.p, split_mask);
+            }
+            hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
+                               spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8));
             HIPCHK(hipGetLastError());
             t2.stop_later("collapse_walk", pending_timers_);
         }
-        // ---- rank the splitter list on the device: prefix of segment lengths by pointer jumping
-        DevBuf<uint32_t> Pa, Pb, Aa, Ab, slot_of; DevBuf<unsigned long long> Ka, Kb, d_off; DevBuf<HeadRec> d_heads;
+        // ---- rank the splitter list on the device: prefix sums by pointer jumping, rings in the same pass (collapse.h)
+        DevBuf<RankRec> Ra, Rb; DevBuf<uint32_t> slot_of; DevBuf<FinRec> fin; DevBuf<EmitRec> d_off; DevBuf<HeadRec> d_heads;
         DevBuf<char> d_out;
-        uint32_t *Pf = nullptr, *Af = nullptr;
-        std::vector<HeadRec> heads;
-        uint64_t covered = 0;
-        if (n_spl) {
-            if (int rc = Pa.alloc(n_spl, err)) return rc;
-            if (int rc = Pb.alloc(n_spl, err)) return rc;
-            if (int rc = Aa.alloc(n_spl, err)) return rc;
-            if (int rc = Ab.alloc(n_spl, err)) return rc;
-            if (int rc = Ka.alloc(n_spl, err)) return rc;
-            if (int rc = Kb.alloc(n_spl, err)) return rc;
-            if (int rc = slot_of.alloc(n_spl, err)) return rc;
-            if (int rc = d_heads.alloc(n_spl, err)) return rc;
-            EvTimer tr(stream_);
-            // cycle members have no head: give every element a defined pointer first
-            HIPCHK(hipMemsetAsync(Pa.p, 0, (size_t)n_spl * 4, stream_));
-            HIPCHK(hipMemsetAsync(Aa.p, 0, (size_t)n_spl * 4, stream_));
-            HIPCHK(hipMemsetAsync(Ka.p, 0, (size_t)n_spl * 8, stream_));
-            HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)n_spl * 4, stream_));
-            HIPCHK(hipMemsetAsync(ctl_.p + 6, 0, 8, stream_));
-            const int gr = grid_for(n_spl);
-            hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, n_spl, Pa.p, Aa.p, Ka.p);
-            uint32_t *Pi = Pa.p, *Po = Pb.p, *Ai = Aa.p, *Ao = Ab.p; unsigned long long *Ki = Ka.p, *Ko = Kb.p;
-            int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl) { reach *= RANK_HOPS; rounds++; } }
-            for (int r = 0; r < rounds; r++) {
-                hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, n_spl, Pi, Ai, Ki, Po, Ao, Ko);
-                std::swap(Pi, Po); std::swap(Ai, Ao); std::swap(Ki, Ko);
-            }
-            Pf = Pi; Af = Ai;
-            hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, n_spl, Pi, Ai, Ki, d_heads.p,
-                               slot_of.p, (unsigned int *)(ctl_.p + 6));
-            HIPCHK(hipGetLastError());
-            unsigned int n_heads = 0;
-            if (int rc = read_ctl(n_heads, 6, err)) return rc;
-            times_.add("collapse_rank_device", tr.stop());
-            heads.resize(n_heads);
-            if (n_heads) HIPCHK(hipMemcpy(heads.data(), d_heads.p, (size_t)n_heads * sizeof(HeadRec), hipMemcpyDeviceToHost));
+        if (int rc = Ra.alloc(seg_cap, err)) return rc;
+        if (int rc = Rb.alloc(seg_cap, err)) return rc;
+        if (int rc = slot_of.alloc(seg_cap, err)) return rc;
+        if (int rc = fin.alloc(seg_cap, err)) return rc;
+        if (int rc = d_heads.alloc(seg_cap, err)) return rc;
+        // (the list may have grown by the orphan cycles: at most n_spl + what fits seg_cap; grids cover the n_spl the
+        // host knows plus a margin, the kernels loop to the device-side count)
+        const int gr = grid_for((uint64_t)n_spl + 65536u);
+        int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)seg_cap) { reach *= RANK_HOPS; rounds++; } }
+        EvTimer tr(stream_);
+        HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
+        hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ra.p);
+        RankRec *Ri = Ra.p, *Ro = Rb.p;
+        for (int r = 0; r < rounds; r++) {
+            hipLaunchKernelGGL(k_rank_jump<W>, dim3(gr), dim3(256), 0, stream_, g, d_nspl, Ri, Ro);
+            std::swap(Ri, Ro);
         }
+        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, ol.p, d_heads.p, slot_of.p,
+                           (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
+        hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
+        HIPCHK(hipGetLastError());
+        unsigned long long hc[4];
+        HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(stream_wait(stream_));
+        if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : "collapse: broken cycle"; return -6; }
+        times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
+        const unsigned int n_heads = (unsigned int)hc[1];
+        times_.add("collapse_rank_device", tr.stop());
+        std::vector<HeadRec> heads(n_heads);
+        if (n_heads) HIPCHK(hipMemcpy(heads.data(), d_heads.p, (size_t)n_heads * sizeof(HeadRec), hipMemcpyDeviceToHost));
         // each unitig exists on both strands: keep the canonical one (decided on the device)
-        std::vector<unsigned long long> head_off(heads.size(), ~0ull);
+        std::vector<EmitRec> head_off(heads.size());
         std::vector<uint32_t> emitted;
         uint64_t out_bytes = 0;
         for (size_t i = 0; i < heads.size(); i++) {
-            covered += heads[i].len;
-            if (heads[i].emit) {
-                head_off[i] = out_bytes; out_bytes += heads[i].len + (uint64_t)(k_ - 1); emitted.push_back((uint32_t)i);
-            }
+            EmitRec e; e.off = ~0ull; e.rot = heads[i].rot; e.len = (uint32_t)heads[i].len;
+            if (heads[i].emit) { e.off = out_bytes; out_bytes += heads[i].len + (uint64_t)(k_ - 1); emitted.push_back((uint32_t)i); }
+            head_off[i] = e;
         }
         if (!emitted.empty()) {
             PinnedBuf &hout = hout_;
             if (int rc = hout.alloc(out_bytes, err)) return rc;
             if (int rc = d_off.alloc(head_off.size(), err)) return rc;
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
-            HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * sizeof(EmitRec), hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
-            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p,
-                               Pf, Af, slot_of.p, d_off.p, d_out.p);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
@@ -1148,74 +1148,10 @@ public:
             out.reserve(emitted.size());
             for (uint32_t i : emitted) {
                 RawContig rc; rc.kc = heads[i].kc;
-                rc.ext = hout.p + head_off[i]; rc.ext_n = heads[i].len + (uint64_t)(k_ - 1);
+                rc.ext = hout.p + head_off[i].off; rc.ext_n = heads[i].len + (uint64_t)(k_ - 1);
                 out.push_back(std::move(rc));
             }
             times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
-        }
-        // ---- circular unitigs (no head): rare; resolved on the host from succ[] (SPEC S10)
-        const uint64_t n_alive = (uint64_t)n - tips_removed_ - bubbles_removed_;
-        if (covered != 2 * n_alive) {
-            std::vector<uint8_t> halive(n);
-            HIPCHK(hipMemcpy(halive.data(), alive_.p, n, hipMemcpyDeviceToHost));
-            auto tc0 = std::chrono::steady_clock::now();
-            std::vector<uint32_t> hsucc(total), hcnt(n);
-            std::vector<uint64_t> hkeys((size_t)n * W);
-            {
-                std::vector<uint2> hw(total);
-                HIPCHK(hipMemcpy(hw.data(), winfo.p, (size_t)total * sizeof(uint2), hipMemcpyDeviceToHost));
-                for (uint32_t v = 0; v < total; v++) hsucc[v] = hw[v].x;
-            }
-            HIPCHK(hipMemcpy(hcnt.data(), scnt_.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-            {
-                std::vector<uint64_t> tmp(n);
-                for (int j = 0; j < W; j++) {
-                    HIPCHK(hipMemcpy(tmp.data(), skeys_[j].p, (size_t)n * 8, hipMemcpyDeviceToHost));
-                    for (uint32_t i = 0; i < n; i++) hkeys[(size_t)i * W + j] = tmp[i];
-                }
-            }
-            // nodes on headed chains: walk them again on the host to mark coverage
-            std::vector<SegRec> hseg(n_spl);
-            std::vector<uint32_t> hP(n_spl);
-            if (n_spl) {
-                HIPCHK(hipMemcpy(hseg.data(), segs.p, (size_t)n_spl * sizeof(SegRec), hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(hP.data(), Pf, (size_t)n_spl * 4, hipMemcpyDeviceToHost));
-            }
-            std::vector<uint8_t> on_chain(n, 0);
-            for (uint32_t i = 0; i < n_spl; i++) {
-                const uint32_t root = hP[i];
-                if (!(root < n_spl && hP[root] == root && hseg[root].head)) continue;   // splitter on a cycle
-                uint32_t v = hseg[i].node;
-                for (uint32_t j = 0; j < hseg[i].len; j++) { on_chain[v >> 1] = 1; v = hsucc[v]; }
-            }
-            auto key_of = [&](uint32_t idx) { Kmer<W> x; for (int j = 0; j < W; j++) x.w[j] = hkeys[(size_t)idx * W + j]; return x; };
-            std::vector<uint8_t> done(n, 0);
-            for (uint32_t i = 0; i < n; i++) {
-                if (!halive[i] || on_chain[i] || done[i]) continue;
-                // find the smallest canonical k-mer on this cycle (either strand holds the same nodes)
-                uint32_t v = i * 2, best = i; uint64_t len = 0;
-                do {
-                    if (km_less<W>(key_of(v >> 1), key_of(best))) best = v >> 1;
-                    v = hsucc[v]; len++;
-                    if (v == NIL || len > (uint64_t)total) { err = "collapse: broken cycle"; return -6; }
-                } while (v != i * 2);
-                RawContig rc; rc.kc = 0;
-                const char B[4] = {'A', 'C', 'G', 'T'};
-                v = best * 2;
-                Kmer<W> x = key_of(best);
-                for (int q = 0; q < k_; q++) rc.own.push_back(B[km_bits2<W>(x, 2 * (k_ - 1 - q))]);
-                for (uint64_t q = 0; q < len; q++) {
-                    done[v >> 1] = 1; rc.kc += hcnt[v >> 1];
-                    if (q > 0) {
-                        Kmer<W> y = key_of(v >> 1);
-                        if (v & 1) y = km_revcomp<W>(y, k_);
-                        rc.own.push_back(B[km_last_base<W>(y)]);
-                    }
-                    v = hsucc[v];
-                }
-                out.push_back(std::move(rc));
-            }
-            times_.add("collapse_host_cycles", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count());
         }
         return 0;
     }

@@ -221,7 +221,7 @@ def device_genomes(torch, dev, lengths, seed):
 
 
 def device_sample_reads(torch, dev, genomes, genome_off, weights, n_reads, read_len, k, seed, err=0.0,
-                        read_index0=0, chunk=1 << 18):
+                        read_index0=0, chunk=1 << 18, circular=False):
     """n_reads reads (global indices read_index0 ...) drawn from the genomes with probabilities `weights`
     (numpy float64, sums to 1): uniform start, random strand, substitution errors at rate `err` that are a pure
     function of (seed, global read index, position).  Every read is one segment (no quality masking).
@@ -250,11 +250,15 @@ def device_sample_reads(torch, dev, genomes, genome_off, weights, n_reads, read_
         u3 = _mix64(torch, u2 ^ 0x14057B7EF767814F)
         f1 = ((u1 >> 11) & ((1 << 53) - 1)).to(torch.float64) / float(1 << 53)
         gid = torch.clamp(torch.searchsorted(cdf, f1, right=True), max=cdf.numel() - 1)
-        span = lens[gid] - read_len + 1
+        span = lens[gid] if circular else lens[gid] - read_len + 1        # circular replicons: a read may start anywhere
         f2 = ((u2 >> 11) & ((1 << 53) - 1)).to(torch.float64) / float(1 << 53)
-        st = genome_off[gid] + torch.clamp((f2 * span.to(torch.float64)).to(torch.int64), max=span - 1)
+        rel = torch.clamp((f2 * span.to(torch.float64)).to(torch.int64), max=span - 1)
+        st = genome_off[gid] + rel
         strand = ((u3 >> 17) & 1).bool()
-        codes = genomes[st[:, None] + ar[None, :]].to(torch.int32)
+        if circular:
+            codes = genomes[genome_off[gid][:, None] + (rel[:, None] + ar[None, :]) % lens[gid][:, None]].to(torch.int32)
+        else:
+            codes = genomes[st[:, None] + ar[None, :]].to(torch.int32)
         codes = torch.where(strand[:, None], (3 - codes).flip(1), codes)       # as sequenced
         if err > 0:
             flag, shift = substitution_flags(torch, idx, read_len, err, seed)

@@ -195,3 +195,42 @@ def test_config2_isolate_1pct_errors_k51_min_count(torch_dev, masked):
     assert ok and h3.used_min_count == used and 2 <= used <= 30
     assert np.array_equal(h3.histo(), hist)
     assert h3.n_solid == int(hist[used:].sum())
+
+
+def test_circular_isolate_with_plasmid_full_size(torch_dev):
+    """A 5 Mbp CIRCULAR chromosome and a 50 kbp circular plasmid at 100x (what a bacterial isolate is): two circular
+    unitigs, resolved on the device, at the cost of the linear case."""
+    torch, dev = torch_dev
+    k = 31
+    lens_ = np.array([G, 50_000], dtype=np.int64)
+    genomes, goff = synth.device_genomes(torch, dev, lens_, 0xC1C)
+    w = lens_ / lens_.sum()
+    n_reads = int(lens_.sum()) * COV // L
+    d = synth.device_sample_reads(torch, dev, genomes, goff, w, n_reads, L, k, 0xC1C, circular=True)
+    h = run(d, k, 5)
+    hist = h.histo()
+    assert h.total_instances == n_reads * (L - k + 1)
+    assert int((hist * np.arange(1, 501, dtype=np.uint64)).sum()) == h.total_instances
+    cs = contigs_of(h)
+    assert sorted(len(c) for c in cs) == [50_000 + k - 1, G + k - 1]      # every k-mer of both circles, spelled once
+    for c in cs:
+        gi = 0 if len(c) > 1_000_000 else 1
+        gs = "".join("ACGT"[x] for x in genomes[int(goff[gi]):int(goff[gi + 1])].cpu().tolist())
+        dbl = gs + gs[:k + 10]
+        body = c[:len(c) - (k - 1)]                                         # one turn; the last k-1 bases repeat the start
+        assert len(body) == len(gs)
+        rc_ = c.translate(COMP)[::-1]
+        # the circle is cut at its smallest k-mer: a rotation of the genome or of its reverse complement
+        assert (body in (gs + gs)) or (rc_[:len(body)] in (gs + gs)), gi
+        assert c[:k - 1] == c[-(k - 1):]
+    out = json.loads(h.get_assembly())
+    assert "L\t1\t+\t1\t+\t30M" in out["outgfa"] and "L\t2\t+\t2\t+\t30M" in out["outgfa"]
+    t = h.timings()
+    assert "collapse_host_cycles" not in t and t["collapse_cycle_splitters_x1e-3"] > 100
+    assert h.get_assembly() == run(d, k, 5).get_assembly()
+    # against the linear case of the same size (same reads machinery, linear sampling)
+    dl = synth.device_sample_reads(torch, dev, genomes, goff, w, n_reads, L, k, 0xC1C, circular=False)
+    best_c = min(run(d, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
+    best_l = min(run(dl, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
+    print("assemble (device, host clock) circular %.3f ms, linear %.3f ms, ratio %.3f" % (best_c, best_l, best_c / best_l))
+    assert best_c <= 1.35 * best_l

@@ -115,6 +115,35 @@ def test_circular_genome_with_and_without_splitters():
         assert "L\t1\t+\t1\t+\t30M" in out["outgfa"]
 
 
+@pytest.mark.parametrize("k,split_log", [(31, None), (31, "0"), (31, "2"), (31, "9"), (51, None), (51, "12"), (21, "1")])
+def test_many_circular_and_linear_replicons(k, split_log, monkeypatch):
+    """Circular unitigs of every size next to linear ones, all on the device (SPEC S10): cycles with many sampled
+    splitters, with exactly one, with none (the sampling rate is moved around to force each), on both strands."""
+    if split_log is not None:
+        monkeypatch.setenv("SHK_SPLIT_LOG", split_log)
+    rng = np.random.default_rng(1000 + k)
+    texts = []
+    sizes = [k + 9, 64, 100, 333, 1000, 4000, 20000]
+    for j, n in enumerate(sizes):                                       # plasmids
+        g = synth.random_genome(n, 700 + 10 * k + j)
+        codes, quals = synth.sample_reads(g, max(60, n * 30 // 100), 100, 900 + j, circular=True)
+        texts.append(synth.to_fastq(codes, quals, prefix=f"c{j}_"))
+    for j, n in enumerate((500, 7000)):                                 # linear pieces
+        g = synth.random_genome(n, 800 + 10 * k + j)
+        codes, quals = synth.sample_reads(g, n * 30 // 100, 100, 950 + j)
+        texts.append(synth.to_fastq(codes, quals, prefix=f"l{j}_"))
+    fq = b"".join(texts)
+    h = product(fq, k=k, min_count=1)
+    o = run_oracle([fq], k=k, min_count=1)
+    out = compare_all(h, o)
+    assert out["ncontigs"] >= len(sizes) + 2
+    t = h.timings()
+    assert "collapse_host_cycles" not in t                              # no host walk any more
+    lens_ = sorted(len(l) for l in out["outfasta"].split("\n") if l and not l.startswith(">"))
+    for n in sizes:
+        assert n + k - 1 in lens_, (n, lens_)                           # a circular unitig of n nodes spells n + k - 1 bases
+
+
 def test_repeats_make_a_branching_graph():
     rng = np.random.default_rng(3)
     rep = synth.random_genome(400, 100)
