@@ -6,7 +6,7 @@
 // a12: collapse (SPEC S10).  Simple links over oriented nodes, splitters = all heads plus a 1/32
 // sample, one walker per splitter, the splitter list ranked by pointer jumping, then every node
 // scatters its base into the contig buffer.
-//   winfo[v] = {succ(v) or NIL, count(v>>1), top 32 bits of the canonical k-mer, -}   one 16-byte read per walker step
+//   winfo[v] = {succ(v) or NIL, count(v>>1)}   one 8-byte read per walker step
 //   ol[v]    = {owner splitter, position in its segment}
 // A node is sampled by a hash of its ID: a walker decides "is my successor a splitter" from the id it
 // just read, without touching the successor (heads are never reached through a simple link: a node
@@ -14,28 +14,26 @@
 //
 // Circular unitigs (a chain of simple links that closes on itself: bacterial chromosomes, plasmids) have no head.
 // SPEC S10 cuts them before their smallest k-mer.  The ranking handles them in the same pass as the linear chains:
-// next to the usual prefix sums every splitter carries (a) the smallest splitter index in the window of
-// predecessors it has seen, with the distance from that splitter to itself, and (b) the smallest k-mer of that
-// window.  Once the windows span the ring, (a) is a rank relative to the ring's smallest splitter — the ring is
-// "opened" there without a second ranking — and (b) is the SPEC's cut point; the emission rotates the spelling by
-// the difference.  K-mers are compared by their top 32 bits, which travel in winfo; the full key is only loaded
-// on a tie.
+// next to the usual prefix sums every splitter carries the smallest splitter index in the window of predecessors
+// it has seen, with the distance from that splitter to itself.  Once the windows span the ring this is a rank
+// relative to the ring's smallest splitter: the ring is "opened" there without a second ranking.  The SPEC's cut
+// point is then found by two streaming passes over the nodes (k_ring_min1 / k_ring_min2: coalesced key reads,
+// one atomic per wave) that return at once when the graph holds no ring, and the emission rotates the spelling
+// by the difference.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool node_sampled(uint32_t v, uint32_t split_mask) {
     return ((mix32(v ^ 0x5bd1e995u) >> 9) & split_mask) == 0;
 }
 
-// top 32 bits of the 2k-bit canonical k-mer (order-preserving prefix)
-template <int W> __device__ __forceinline__ uint32_t km_top32(const KeyArr<W> &keys, uint32_t idx, int k) {
-    const int used = 2 * k - 64 * (W - 1);                 // bits in the top word: 1..64 (k odd => even, >= 2)
+// the most significant 64 bits of the 2k-bit canonical k-mer of node idx (order-preserving prefix; the whole key for k <= 32)
+template <int W> __device__ __forceinline__ unsigned long long km_prefix64(const KeyArr<W> &keys, uint32_t idx, int k) {
+    const int used = 2 * k - 64 * (W - 1);                 // bits in the top word: 2..64
     const uint64_t hi = keys.w[W - 1][idx];
-    if (used >= 32) return (uint32_t)(hi >> (used - 32));
-    if constexpr (W >= 2) return (uint32_t)((hi << (32 - used)) | (keys.w[W - 2][idx] >> (32 + used)));
-    else return (uint32_t)(hi << (32 - used));            // (k < 16: the whole key)
+    if constexpr (W == 1) return hi;
+    else return used >= 64 ? hi : ((hi << (64 - used)) | (keys.w[W - 2][idx] >> used));
 }
-// is the k-mer of oriented node a smaller than that of b?  (tops first; equal k-mers: the smaller oriented id)
-template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g, uint32_t ta, uint32_t a, uint32_t tb, uint32_t b) {
-    if (ta != tb) return ta < tb;
+// is the k-mer of oriented node a smaller than that of b?  (equal k-mers: the smaller oriented id)
+template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g, uint32_t a, uint32_t b) {
     if ((a >> 1) == (b >> 1)) return a < b;
     const Kmer<W> ka = g.keys.load(a >> 1), kb = g.keys.load(b >> 1);
     if (km_less<W>(ka, kb)) return true;
@@ -47,7 +45,7 @@ static constexpr int SS_ITEMS = 16;            // oriented nodes per thread of k
 
 template <int W>
 __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *__restrict__ alive,
-                                                    uint4 *__restrict__ winfo, uint32_t *__restrict__ spl,
+                                                    uint2 *__restrict__ winfo, uint32_t *__restrict__ spl,
                                                     uint2 *__restrict__ ol, unsigned int *__restrict__ n_spl,
                                                     uint32_t split_mask) {
     __shared__ uint32_t wtot[SS_ITEMS * 4];
@@ -60,18 +58,17 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
 #pragma unroll 1
     for (int it = 0; it < SS_ITEMS; it++) {
         const uint32_t v = base + (uint32_t)it * 256u + threadIdx.x;
-        uint32_t s = NIL, c = 0, top = 0; bool al = false;
+        uint32_t s = NIL, c = 0; bool al = false;
         if (v < total) {
             al = alive[v >> 1] != 0;
             if (al) {
                 c = g.cnt[v >> 1];
-                top = km_top32<W>(g.keys, v >> 1, g.k);
                 if (g.outdeg(v) == 1) {
                     const uint32_t u = g.only_out(v);
                     if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
                 }
             }
-            uint4 w; w.x = s; w.y = c; w.z = top; w.w = 0; winfo[v] = w;
+            uint2 w; w.x = s; w.y = c; winfo[v] = w;
         }
         const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node
         const bool p = al && (sp == NIL || node_sampled(v, split_mask));   // head or sampled
@@ -105,30 +102,28 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
 
 // head: 0 = has a splitter before it; HEAD_LINEAR = first splitter of a linear chain; HEAD_ORPHAN = a circular
 // unitig without any sampled node, spelled from its smallest k-mer (k_orphan_cycles).
-// mintop / minnode: the smallest k-mer among the segment's nodes (its top 32 bits, the oriented node).
-struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, minnode, mintop, pad; };
+struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, pad; };
 static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint4 *__restrict__ winfo,
+__global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__ winfo,
                                                        const uint32_t *__restrict__ spl, uint32_t n_spl,
                                                        uint2 *__restrict__ ol, SegRec *__restrict__ segs,
                                                        uint32_t split_mask) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
-        uint32_t cur = s, len = 0, nxt, mtop = 0xFFFFFFFFu, mnode = s;
+        uint32_t cur = s, len = 0, nxt;
         unsigned long long sum = 0;
         for (;;) {
-            const uint4 w = winfo[cur];
+            const uint2 w = winfo[cur];
             if (cur != s) { uint2 o; o.x = i; o.y = len; ol[cur] = o; }
-            if (len == 0 || node_key_less<W>(g, w.z, cur, mtop, mnode)) { mtop = w.z; mnode = cur; }
             sum += w.y;
             len++;
             nxt = w.x;
             if (nxt == NIL || node_sampled(nxt, split_mask)) break;
             cur = nxt;
         }
-        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum; r.minnode = mnode; r.mintop = mtop; r.pad = 0;
+        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum; r.pad = 0;
         r.next_spl = (nxt == NIL) ? NIL : ol[nxt].x;       // splitters got their owner in k_succ_split
         r.head = winfo[s ^ 1u].x == NIL ? HEAD_LINEAR : 0u;
         segs[i] = r;
@@ -142,21 +137,21 @@ __global__ __launch_bounds__(256) void k_walk_segments(Graph<W> g, const uint4 *
 static constexpr uint32_t ORPHAN_MAX = 1u << 16;          // (no sampled node among n: (31/32)^n; 65536 never happens)
 template <int W>
 __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t *__restrict__ alive,
-                                                       const uint4 *__restrict__ winfo, uint2 *__restrict__ ol,
+                                                       const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
                                                        uint32_t *__restrict__ spl, SegRec *__restrict__ segs,
                                                        unsigned int *__restrict__ n_spl,
                                                        uint32_t seg_cap, uint32_t *__restrict__ flags) {
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1] || ol[v].x != NIL) continue;
-        const uint4 w0 = winfo[v];
-        uint32_t best = v, btop = w0.z, n = 1, cur = w0.x, last = v;
+        const uint2 w0 = winfo[v];
+        uint32_t best = v, n = 1, cur = w0.x, last = v;
         unsigned long long sum = w0.y;
         bool ok = true;
         while (cur != v) {
             if (cur == NIL || n >= ORPHAN_MAX) { ok = false; break; }
-            const uint4 w = winfo[cur];
-            if (node_key_less<W>(g, w.z, cur, btop, best)) { btop = w.z; best = cur; }
+            const uint2 w = winfo[cur];
+            if (node_key_less<W>(g, cur, best)) best = cur;
             sum += w.y; n++; last = cur; cur = w.x;
         }
         if (!ok) { flags[0] = 1; continue; }
@@ -166,8 +161,7 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
         spl[idx] = v;
         cur = v;
         for (uint32_t j = 0; j < n; j++) { uint2 o; o.x = idx; o.y = j; ol[cur] = o; cur = winfo[cur].x; }
-        SegRec r; r.node = v; r.next_spl = NIL; r.len = n; r.last = last; r.sum = sum; r.head = HEAD_ORPHAN;
-        r.minnode = v; r.mintop = btop; r.pad = 0;
+        SegRec r; r.node = v; r.next_spl = NIL; r.len = n; r.last = last; r.sum = sum; r.head = HEAD_ORPHAN; r.pad = 0;
         segs[idx] = r;
     }
 }
@@ -177,15 +171,15 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
 // between the start of splitter P and the start of this one.  For rings (see the file header): m = the smallest
 // splitter index among this splitter and the predecessors its window covers, d / dK = nodes / counts from the start
 // of m to the start of this one (the NEAREST occurrence of m going backwards, so d stays below the ring's length
-// however often the windows wrap), mt / mk = the smallest k-mer of the window (top 32 bits, oriented node).
-struct RankRec { uint32_t P, A, m, d; unsigned long long K, dK; uint32_t mt, mk; };
+// however often the windows wrap).
+struct RankRec { uint32_t P, A, m, d; unsigned long long K, dK; };
 // (the splitter count lives on the device: k_orphan_cycles may have appended to the list after the host read it)
 __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ segs, const unsigned int *__restrict__ n_spl_p,
                                                    RankRec *__restrict__ R) {
     const uint32_t n_spl = *n_spl_p;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
         const SegRec r = segs[s];
-        R[s].m = s; R[s].d = 0; R[s].dK = 0; R[s].mt = r.mintop; R[s].mk = r.minnode;
+        R[s].m = s; R[s].d = 0; R[s].dK = 0;
         if (r.head) { R[s].P = s; R[s].A = 0; R[s].K = 0; }
         if (r.next_spl != NIL) { R[r.next_spl].P = s; R[r.next_spl].A = r.len; R[r.next_spl].K = r.sum; }
     }
@@ -194,12 +188,11 @@ __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ se
 // over ~300 k splitters is all latency, so ceil(log4 n) launches of four dependent reads beat
 // ceil(log2 n) launches of two); heads point to themselves with A = K = 0, so overshooting adds nothing
 static constexpr int RANK_HOPS = 4;
-template <int W>
-__global__ __launch_bounds__(256) void k_rank_jump(Graph<W> g, const unsigned int *__restrict__ n_spl_p,
+__global__ __launch_bounds__(256) void k_rank_jump(const unsigned int *__restrict__ n_spl_p,
                                                    const RankRec *__restrict__ Ri, RankRec *__restrict__ Ro) {
     const uint32_t n_spl = *n_spl_p;
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
-        uint32_t p = s, a = 0, bm = 0xFFFFFFFFu, bd = 0, bt = 0xFFFFFFFFu, bk = NIL;
+        uint32_t p = s, a = 0, bm = 0xFFFFFFFFu, bd = 0;
         unsigned long long kc = 0, bdk = 0;
 #pragma unroll
         for (int h = 0; h < RANK_HOPS; h++) {
@@ -207,11 +200,10 @@ __global__ __launch_bounds__(256) void k_rank_jump(Graph<W> g, const unsigned in
             // (a, kc): nodes / counts from the start of p to the start of s; p runs from near to far, so the
             // strict '<' keeps the nearest occurrence of the smallest index
             if (r.m < bm) { bm = r.m; bd = r.d + a; bdk = r.dK + kc; }
-            if (bk == NIL || (r.mk != bk && node_key_less<W>(g, r.mt, r.mk, bt, bk))) { bt = r.mt; bk = r.mk; }
             a += r.A; kc += r.K;
             p = min(r.P, n_spl - 1u);
         }
-        RankRec o; o.P = p; o.A = a; o.K = kc; o.m = bm; o.d = bd; o.dK = bdk; o.mt = bt; o.mk = bk;
+        RankRec o; o.P = p; o.A = a; o.K = kc; o.m = bm; o.d = bd; o.dK = bdk;
         Ro[s] = o;
     }
 }
@@ -220,14 +212,17 @@ __global__ __launch_bounds__(256) void k_rank_jump(Graph<W> g, const unsigned in
 struct HeadRec { uint32_t spl, head_node, tail_node, emit, rot, circ; unsigned long long len, kc; };
 struct EmitRec { unsigned long long off; uint32_t rot, len; };      // per chain: output offset (~0: not emitted), rotation
 struct FinRec { uint32_t slot, base; };                             // per splitter: its chain's record, nodes before it
+struct RingMin { unsigned long long prefix; uint32_t vmin, is_ring; };   // per chain record: the ring's smallest k-mer (prefix, node)
 // Every chain's last splitter reports the chain: for a linear chain the tail (no next splitter), for a ring the
 // splitter in front of the ring's smallest one.  A unitig exists on both strands; of a linear one the strand to
 // emit is the lexicographically smaller spelling (SPEC S10), which the first k characters decide: seq(head)
-// against seq(rc(tail)); of a circular one it is the strand that holds the smallest k-mer in orientation 0.
+// against seq(rc(tail)); of a circular one it is the strand that holds the smallest k-mer in orientation 0
+// (k_ring_rot, once that k-mer is known).
 template <int W>
 __global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__restrict__ segs, const unsigned int *__restrict__ n_spl_p,
-                                                    const RankRec *__restrict__ R, const uint2 *__restrict__ ol,
+                                                    const RankRec *__restrict__ R,
                                                     HeadRec *__restrict__ heads, uint32_t *__restrict__ slot_of,
+                                                    RingMin *__restrict__ ringmin,
                                                     unsigned int *__restrict__ n_heads, unsigned int *__restrict__ n_cyc) {
     __shared__ uint32_t blk_cyc;
     if (threadIdx.x == 0) blk_cyc = 0;
@@ -253,6 +248,7 @@ __global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__
                 else h.emit = h.head_node <= (h.tail_node ^ 1u);   // the chain is its own mirror, or a tie on ids
             }
             heads[slot] = h; slot_of[root] = slot;
+            RingMin rm; rm.prefix = ~0ull; rm.vmin = NIL; rm.is_ring = 0; ringmin[slot] = rm;
         } else {                                                   // on a ring, ranked from its smallest splitter me.m
             my_cyc++;
             if (r.next_spl != me.m) continue;
@@ -260,11 +256,9 @@ __global__ __launch_bounds__(256) void k_rank_tails(Graph<W> g, const SegRec *__
             const uint32_t slot = atomicAdd(n_heads, 1u);
             HeadRec h; h.spl = root; h.head_node = segs[root].node; h.tail_node = r.last; h.circ = 1;
             h.len = (unsigned long long)me.d + r.len; h.kc = me.dK + r.sum;
-            const uint32_t vm = me.mk;                             // the ring's smallest k-mer
-            h.emit = (vm & 1u) ? 0u : 1u;
-            const uint2 o = ol[vm];
-            h.rot = R[o.x].d + o.y;
+            h.emit = 0; h.rot = 0;                                 // (k_ring_rot)
             heads[slot] = h; slot_of[root] = slot;
+            RingMin rm; rm.prefix = ~0ull; rm.vmin = NIL; rm.is_ring = 1; ringmin[slot] = rm;
         }
     }
     if (my_cyc) atomicAdd(&blk_cyc, my_cyc);
@@ -281,6 +275,111 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
         const bool ring = segs[me.P].head == 0u;
         FinRec f; f.slot = slot_of[ring ? me.m : me.P]; f.base = ring ? me.d : me.A;
         fin[s] = f;
+    }
+}
+
+// ---- the smallest k-mer of every ring (where SPEC S10 cuts it): two streaming passes over the oriented nodes.
+// Both return at once when the graph holds no ring (*n_cyc == 0).  Pass 1: the smallest 64-bit key prefix per ring
+// (the lanes of a wave nearly always sit on the same ring: one shuffle reduction and one atomic per wave and ring).
+// Pass 2: the nodes whose prefix equals it — one, unless k > 32 and two k-mers share 64 leading bits — settle the
+// exact minimum among themselves by compare-and-swap.
+template <int W>
+__global__ __launch_bounds__(256) void k_ring_min1(Graph<W> g, const uint8_t *__restrict__ alive, const uint2 *__restrict__ ol,
+                                                   const FinRec *__restrict__ fin, RingMin *__restrict__ ringmin,
+                                                   const unsigned int *__restrict__ n_cyc) {
+    if (*n_cyc == 0) return;
+    // block-level table ring -> smallest prefix seen by this block: the global atomics are one per block and ring
+    constexpr uint32_t TS = 64;
+    __shared__ uint32_t t_slot[TS];
+    __shared__ unsigned long long t_min[TS];
+    if (threadIdx.x < TS) { t_slot[threadIdx.x] = NIL; t_min[threadIdx.x] = ~0ull; }
+    __syncthreads();
+    auto put = [&](uint32_t sl, unsigned long long m) {
+        uint32_t i = mix32(sl) & (TS - 1u);
+        for (uint32_t t = 0; t < TS; t++) {
+            const uint32_t old = atomicCAS(&t_slot[i], NIL, sl);
+            if (old == NIL || old == sl) { atomicMin(&t_min[i], m); return; }
+            i = (i + 1u) & (TS - 1u);
+        }
+        atomicMin(&ringmin[sl].prefix, m);                       // table full: more than 64 rings in one block's nodes
+    };
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = g.n * 2;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    // this thread's rings and their minima so far: two entries, because a ring and its mirror strand interleave in
+    // memory (v and v ^ 1 are neighbours); a third ring evicts an entry into the block's table
+    uint32_t cs0 = NIL, cs1 = NIL; unsigned long long cm0 = ~0ull, cm1 = ~0ull;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += stride) {
+        if (!alive[v >> 1]) continue;
+        const uint32_t s = ol[v].x;
+        if (s == NIL) continue;
+        const uint32_t sl = fin[s].slot;
+        if (sl == NIL || !ringmin[sl].is_ring) continue;
+        const unsigned long long pf = km_prefix64<W>(g.keys, v >> 1, g.k);
+        if (sl == cs0) { if (pf < cm0) cm0 = pf; }
+        else if (sl == cs1) { if (pf < cm1) cm1 = pf; }
+        else if (cs0 == NIL) { cs0 = sl; cm0 = pf; }
+        else {
+            if (cs1 != NIL) put(cs1, cm1);
+            cs1 = sl; cm1 = pf;
+        }
+    }
+    // wave-level: one table update per distinct ring among the lanes, for either entry
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const uint32_t cs = e ? cs1 : cs0;
+        const unsigned long long cm = e ? cm1 : cm0;
+        unsigned long long todo = __ballot(cs != NIL);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t ls = (uint32_t)__shfl((int)cs, leader);
+            const bool mine = cs == ls;
+            unsigned long long x = mine ? cm : ~0ull;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const unsigned long long y = __shfl_xor(x, o); x = y < x ? y : x; }
+            if (lane == leader) put(ls, x);
+            todo &= ~__ballot(mine);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TS && t_slot[threadIdx.x] != NIL) atomicMin(&ringmin[t_slot[threadIdx.x]].prefix, t_min[threadIdx.x]);
+}
+template <int W>
+__global__ __launch_bounds__(256) void k_ring_min2(Graph<W> g, const uint8_t *__restrict__ alive, const uint2 *__restrict__ ol,
+                                                   const FinRec *__restrict__ fin, RingMin *__restrict__ ringmin,
+                                                   const unsigned int *__restrict__ n_cyc) {
+    if (*n_cyc == 0) return;
+    const uint32_t total = g.n * 2;
+    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
+        if (!alive[v >> 1]) continue;
+        const uint32_t s = ol[v].x;
+        if (s == NIL) continue;
+        const uint32_t sl = fin[s].slot;
+        if (sl == NIL) continue;
+        const RingMin rm = ringmin[sl];
+        if (!rm.is_ring || km_prefix64<W>(g.keys, v >> 1, g.k) != rm.prefix) continue;
+        uint32_t cur = atomicCAS(&ringmin[sl].vmin, NIL, v);
+        while (cur != NIL && cur != v && node_key_less<W>(g, v, cur)) {
+            const uint32_t prev = atomicCAS(&ringmin[sl].vmin, cur, v);
+            if (prev == cur) break;
+            cur = prev;
+        }
+    }
+}
+// per ring: the strand that holds its smallest k-mer in orientation 0 is the one spelled, starting there
+__global__ __launch_bounds__(256) void k_ring_rot(HeadRec *__restrict__ heads, const unsigned int *__restrict__ n_heads_p,
+                                                  const RingMin *__restrict__ ringmin, const uint2 *__restrict__ ol,
+                                                  const FinRec *__restrict__ fin, const unsigned int *__restrict__ n_cyc,
+                                                  uint32_t *__restrict__ flags) {
+    if (*n_cyc == 0) return;
+    const uint32_t n_heads = *n_heads_p;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_heads; i += gridDim.x * blockDim.x) {
+        const RingMin rm = ringmin[i];
+        if (!rm.is_ring) continue;
+        if (rm.vmin == NIL) { flags[0] = 3; continue; }             // (cannot happen: every ring has nodes)
+        const uint2 o = ol[rm.vmin];
+        heads[i].emit = (rm.vmin & 1u) ? 0u : 1u;
+        heads[i].rot = fin[o.x].base + o.y;
     }
 }
 

@@ -1060,7 +1060,7 @@ public:
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
         DevBuf<uint32_t> spl;
-        DevBuf<uint4> winfo; DevBuf<uint2> ol;
+        DevBuf<uint2> winfo, ol;
         DevBuf<SegRec> segs;
         if (int rc = winfo.alloc(total, err)) return rc;
         if (int rc = spl.alloc(total, err)) return rc;
@@ -1082,7 +1082,7 @@ public:
         {
             EvTimer t2(stream_);
             if (n_spl) {
-                hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, g, winfo.p,
+                hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
                                    spl.p, n_spl, ol.p, segs.p, split_mask);
             }
             hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
@@ -1092,14 +1092,15 @@ public:
         }
         // ---- rank the splitter list on the device: prefix sums by pointer jumping, rings in the same pass (collapse.h)
         DevBuf<RankRec> Ra, Rb; DevBuf<uint32_t> slot_of; DevBuf<FinRec> fin; DevBuf<EmitRec> d_off; DevBuf<HeadRec> d_heads;
-        DevBuf<char> d_out;
+        DevBuf<RingMin> ringmin; DevBuf<char> d_out;
         if (int rc = Ra.alloc(seg_cap, err)) return rc;
         if (int rc = Rb.alloc(seg_cap, err)) return rc;
         if (int rc = slot_of.alloc(seg_cap, err)) return rc;
         if (int rc = fin.alloc(seg_cap, err)) return rc;
         if (int rc = d_heads.alloc(seg_cap, err)) return rc;
-        // (the list may have grown by the orphan cycles: at most n_spl + what fits seg_cap; grids cover the n_spl the
-        // host knows plus a margin, the kernels loop to the device-side count)
+        if (int rc = ringmin.alloc(seg_cap, err)) return rc;
+        // (the list may have grown by the orphan cycles; grids cover the n_spl the host knows plus a margin, the
+        // kernels loop to the device-side count)
         const int gr = grid_for((uint64_t)n_spl + 65536u);
         int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)seg_cap) { reach *= RANK_HOPS; rounds++; } }
         EvTimer tr(stream_);
@@ -1107,17 +1108,23 @@ public:
         hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ra.p);
         RankRec *Ri = Ra.p, *Ro = Rb.p;
         for (int r = 0; r < rounds; r++) {
-            hipLaunchKernelGGL(k_rank_jump<W>, dim3(gr), dim3(256), 0, stream_, g, d_nspl, Ri, Ro);
+            hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, d_nspl, Ri, Ro);
             std::swap(Ri, Ro);
         }
-        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, ol.p, d_heads.p, slot_of.p,
+        const unsigned int *d_ncyc = (const unsigned int *)(ctl_.p + 7);
+        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, d_heads.p, slot_of.p, ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
         hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
+        // rings: their smallest k-mer (these three return at once when there is none)
+        hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
+        hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
+        hipLaunchKernelGGL(k_ring_rot, dim3(gr), dim3(256), 0, stream_, d_heads.p, (const unsigned int *)(ctl_.p + 6), ringmin.p, ol.p, fin.p,
+                           d_ncyc, (uint32_t *)(ctl_.p + 8));
         HIPCHK(hipGetLastError());
         unsigned long long hc[4];
         HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
         HIPCHK(stream_wait(stream_));
-        if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : "collapse: broken cycle"; return -6; }
+        if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
         times_.add("collapse_rank_device", tr.stop());

@@ -233,4 +233,4 @@ def test_circular_isolate_with_plasmid_full_size(torch_dev):
     best_c = min(run(d, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
     best_l = min(run(dl, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
     print("assemble (device, host clock) circular %.3f ms, linear %.3f ms, ratio %.3f" % (best_c, best_l, best_c / best_l))
-    assert best_c <= 1.35 * best_l
+    assert best_c <= 1.10 * best_l                         # within 10 % of the linear case
