@@ -181,6 +181,11 @@ const char *shk_get_timings(shk_handle *h);
 int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words /*W*/, int *orient);
 uint64_t shk_host_nthash(const char *seq, uint32_t k);   /* canonical ntHash of seq[0..k) */
 int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0 fit failed */
+/* the output writer alone (SPEC S10-S11: canonical strand, order, links, FASTA / DOT / GFA1 / GFA2, JSON) on
+ * unitigs handed in as text, any strand, any order: seqs = the spellings back to back, offsets[n+1] their
+ * bounds, kc[n] their k-mer count sums.  Returns a malloc'd NUL-terminated JSON (shk_host_free) or NULL. */
+char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k);
+void shk_host_free(void *p);
 
 /* Device buffers of freed handles are cached process-wide for the next handle (a handle lives
  * for one preprocess+assemble); this returns the cache to the driver.  SHK_NO_POOL=1 disables it. */

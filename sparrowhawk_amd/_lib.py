@@ -64,6 +64,8 @@ SIGNATURES = {
     "shk_host_canonical": (_int, [_cp, _u32, _vp, C.POINTER(_int)]),
     "shk_host_nthash": (_u64, [_cp, _u32]),
     "shk_host_fit": (_int, [_vp, C.POINTER(_u32)]),
+    "shk_host_assembly_json": (_vp, [_cp, _vp, _vp, _u64, _u32]),
+    "shk_host_free": (None, [_vp]),
     "shk_release_cached_memory": (None, []),
     "shk_measure_stream_read": (_int, [_sz, _int, C.POINTER(C.c_double)]),
     "shk_version": (_cp, []),

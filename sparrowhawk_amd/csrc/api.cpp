@@ -871,5 +871,24 @@ int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *or
 }
 uint64_t shk_host_nthash(const char *seq, uint32_t k) { return host_nthash(seq, k); }
 int shk_host_fit(const uint64_t *histo500, uint32_t *used) { return spectrum_fit(histo500, used) ? 1 : 0; }
+char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k) {
+    try {
+        if ((!seqs && n_contigs) || !offsets || (!kc && n_contigs)) return nullptr;
+        std::vector<RawContig> contigs((size_t)n_contigs);
+        for (uint64_t i = 0; i < n_contigs; i++) {
+            if (offsets[i + 1] < offsets[i] + k) return nullptr;            // a unitig spells at least one k-mer
+            contigs[i].ext = seqs + offsets[i]; contigs[i].ext_n = (size_t)(offsets[i + 1] - offsets[i]); contigs[i].kc = kc[i];
+        }
+        AssemblyText text;
+        build_assembly_text(contigs, k, text);
+        char *out = (char *)malloc(text.json.size() + 1);
+        if (!out) return nullptr;
+        memcpy(out, text.json.data(), text.json.size());
+        out[text.json.size()] = 0;
+        give_big_string(std::move(text.json));
+        return out;
+    } catch (...) { return nullptr; }
+}
+void shk_host_free(void *p) { free(p); }
 
 }  // extern "C"

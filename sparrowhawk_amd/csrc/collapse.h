@@ -366,20 +366,39 @@ __global__ __launch_bounds__(256) void k_ring_min2(Graph<W> g, const uint8_t *__
         }
     }
 }
-// per ring: the strand that holds its smallest k-mer in orientation 0 is the one spelled, starting there
-__global__ __launch_bounds__(256) void k_ring_rot(HeadRec *__restrict__ heads, const unsigned int *__restrict__ n_heads_p,
-                                                  const RingMin *__restrict__ ringmin, const uint2 *__restrict__ ol,
-                                                  const FinRec *__restrict__ fin, const unsigned int *__restrict__ n_cyc,
-                                                  uint32_t *__restrict__ flags) {
+// Per ring: SPEC S10 cuts it before its smallest k-mer x, i.e. it is spelled from the oriented node (x, 0) along that
+// node's strand, and the unitig is then emitted as min(spelling, revcomp(spelling)).  The reverse complement of that
+// spelling is the MIRROR ring spelled from the successor of (x, 1); which of the two is smaller is decided by their
+// first k-mers (two different oriented nodes spell two different k-mers), so the smaller one is emitted directly and
+// the host never has to reverse-complement a chromosome.  The ring whose smallest k-mer sits in orientation 0 decides
+// for both strands; its mirror's record is only written by it.
+template <int W>
+__global__ __launch_bounds__(256) void k_ring_rot(Graph<W> g, HeadRec *__restrict__ heads, const unsigned int *__restrict__ n_heads_p,
+                                                  const RingMin *__restrict__ ringmin, const uint2 *__restrict__ winfo,
+                                                  const uint2 *__restrict__ ol, const FinRec *__restrict__ fin,
+                                                  const unsigned int *__restrict__ n_cyc, uint32_t *__restrict__ flags) {
     if (*n_cyc == 0) return;
     const uint32_t n_heads = *n_heads_p;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_heads; i += gridDim.x * blockDim.x) {
         const RingMin rm = ringmin[i];
         if (!rm.is_ring) continue;
         if (rm.vmin == NIL) { flags[0] = 3; continue; }             // (cannot happen: every ring has nodes)
+        if (rm.vmin & 1u) continue;                                 // the mirror strand: decided by its partner
         const uint2 o = ol[rm.vmin];
-        heads[i].emit = (rm.vmin & 1u) ? 0u : 1u;
-        heads[i].rot = fin[o.x].base + o.y;
+        const uint32_t w = winfo[rm.vmin ^ 1u].x;                   // first node of the reverse-complement spelling
+        bool mirror = false;
+        uint2 ow; ow.x = NIL; ow.y = 0;
+        if (w != NIL) {
+            ow = ol[w];
+            mirror = ow.x != NIL && fin[ow.x].slot != NIL && fin[ow.x].slot != i && km_less<W>(g.seq(w), g.seq(rm.vmin));
+        }
+        if (mirror) {
+            const uint32_t j = fin[ow.x].slot;
+            heads[j].emit = 1; heads[j].rot = fin[ow.x].base + ow.y;
+            heads[i].emit = 0;
+        } else {
+            heads[i].emit = 1; heads[i].rot = fin[o.x].base + o.y;
+        }
     }
 }
 

@@ -7,20 +7,23 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <tuple>
-#include <unordered_map>
 
 namespace shk {
 
 static inline char comp(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A'; }
 
-static std::string revcomp(const char *s, size_t n) {
-    std::string r(n, 'A');
-    for (size_t i = 0; i < n; i++) r[i] = comp(s[n - 1 - i]);
-    return r;
+static void revcomp_range(const char *s, size_t n, char *r, size_t a, size_t b) {       // r[a..b) of the reverse complement
+    for (size_t i = a; i < b; i++) r[i] = comp(s[n - 1 - i]);
 }
+// (revcomp of a whole contig: defined below the worker pool — big ones are done in pieces)
 
 // is revcomp(s) < s ?  decided at the first differing position, without materialising it
 static bool revcomp_is_smaller(const char *s, size_t n) {
@@ -78,6 +81,7 @@ namespace {
 static inline size_t n_digits(uint64_t v) { size_t n = 1; while (v >= 10) { v /= 10; n++; } return n; }
 struct SizeSink {
     size_t n = 0;
+    void seq(const char *, size_t m) { n += m; }
     void nl() { n += 2; }
     void tab() { n += 2; }
     void quote() { n += 2; }
@@ -88,6 +92,16 @@ struct SizeSink {
 };
 struct PtrSink {
     char *p;
+    // a sequence of at least `big` bytes is not copied here: its place is skipped and the copy is queued, so that
+    // it can be done in pieces by all threads
+    size_t big = (size_t)-1;
+    std::vector<std::pair<char *, std::pair<const char *, size_t>>> *deferred = nullptr;
+    std::mutex *mu = nullptr;
+    void seq(const char *q, size_t m) {
+        if (m >= big && deferred) { std::lock_guard<std::mutex> lk(*mu); deferred->push_back({p, {q, m}}); }
+        else memcpy(p, q, m);
+        p += m;
+    }
     void nl() { *p++ = '\\'; *p++ = 'n'; }
     void tab() { *p++ = '\\'; *p++ = 't'; }
     void quote() { *p++ = '\\'; *p++ = '"'; }
@@ -98,20 +112,169 @@ struct PtrSink {
 };
 }  // namespace
 
+// ---- a small persistent worker pool -------------------------------------------------------------------
+// The writer's work is megabytes of memcpy (a 5 Mbp contig goes into FASTA, GFA1 and GFA2) or millions of small
+// records (a fragmented metagenome: 4 M contigs); a handle lives for one assembly, so threads are kept across
+// handles (spawning three per assembly cost ~0.1 ms of the 0.35 ms the writer took on the bench workload).
+namespace {
+class WorkPool {
+public:
+    static WorkPool &get() { static WorkPool *p = new WorkPool(); return *p; }     // never destroyed (process teardown order)
+    unsigned size() const { return (unsigned)n_workers_ + 1u; }                   // workers + the caller
+    // runs fn(task) for task in [0, n_tasks) on the pool and the calling thread; returns when all are done
+    template <typename F> void run(size_t n_tasks, F &&fn) {
+        if (n_tasks == 0) return;
+        // (a job started from inside a task of another job runs inline: the pool is not re-entrant)
+        if (n_tasks == 1 || n_workers_ == 0 || in_task()) { for (size_t i = 0; i < n_tasks; i++) fn(i); return; }
+        std::lock_guard<std::mutex> job_lock(job_mu_);                           // one job at a time (handles on several threads)
+        std::function<void(size_t)> f = [&fn](size_t i) { fn(i); };
+        uint64_t gen;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &f; n_tasks_ = n_tasks; next_ = 0; pending_ = n_tasks; failed_ = false; gen = ++gen_;
+        }
+        cv_.notify_all();
+        work(gen);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = nullptr;                                                           // (under mu_: no worker is inside this job any more)
+        if (failed_) throw std::bad_alloc();
+    }
+private:
+    WorkPool() {
+        unsigned hc = std::thread::hardware_concurrency();
+        if (hc == 0) hc = 4;
+        unsigned n = std::min(hc, 16u);
+        if (const char *v = getenv("SHK_WRITER_THREADS")) { const long t = strtol(v, nullptr, 10); if (t >= 1 && t <= 64) n = (unsigned)t; }
+        n_workers_ = n - 1;
+        for (unsigned i = 1; i < n; i++) std::thread([this] { loop(); }).detach();
+    }
+    // Tasks are claimed under the mutex together with the job's generation: a worker that wakes up late (or is still
+    // leaving the previous job) can never take a task index of one job and run it against another.  Tasks are coarse
+    // (tens to hundreds per job), so the lock is not a bottleneck.
+    void work(uint64_t gen) {
+        for (;;) {
+            size_t i; const std::function<void(size_t)> *f;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (gen_ != gen || next_ >= n_tasks_ || !fn_) return;
+                i = next_++; f = fn_;
+            }
+            bool threw = false;
+            in_task() = true;
+            try { (*f)(i); } catch (...) { threw = true; }        // (out of memory in a task: reported by run(), never a terminate)
+            in_task() = false;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (threw) failed_ = true;
+                if (--pending_ == 0) done_cv_.notify_all();
+            }
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+            }
+            work(seen);
+        }
+    }
+    static bool &in_task() { static thread_local bool f = false; return f; }
+    unsigned n_workers_ = 0;
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_tasks_ = 0, pending_ = 0, next_ = 0;
+    bool failed_ = false;
+    uint64_t gen_ = 0;
+};
+
+std::string revcomp(const char *s, size_t n) {
+    std::string r(n, 'A');
+    if (n < ((size_t)1 << 20)) { revcomp_range(s, n, &r[0], 0, n); return r; }
+    const size_t pieces = WorkPool::get().size() * 2;
+    WorkPool::get().run(pieces, [&](size_t t) { revcomp_range(s, n, &r[0], n * t / pieces, n * (t + 1) / pieces); });
+    return r;
+}
+
+// parallel loop over [0, n) in `pieces` contiguous ranges
+template <typename F> void par_ranges(size_t n, size_t min_per_piece, F &&fn) {
+    WorkPool &pool = WorkPool::get();
+    size_t pieces = std::min<size_t>(pool.size() * 4, n / std::max<size_t>(min_per_piece, 1));
+    if (pieces < 2) { fn(0, n); return; }
+    pool.run(pieces, [&](size_t t) { fn(n * t / pieces, n * (t + 1) / pieces); });
+}
+}  // namespace
+
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out) {
+    const char *pm = getenv("SHK_WRITER_PAR_MIN");          // (tests force the parallel paths on small outputs)
+    const size_t par_min = (pm && *pm) ? (size_t)strtoull(pm, nullptr, 10) : ((size_t)1 << 20);
+    const bool many = contigs.size() >= (par_min >= ((size_t)1 << 20) ? (size_t)20000 : (size_t)2);
+    const size_t grain = many && par_min < ((size_t)1 << 20) ? 1 : 2048;
     // SPEC S10: each unitig is emitted as min(seq, revcomp(seq))
-    for (auto &c : contigs)
-        if (revcomp_is_smaller(c.data(), c.size())) { c.own = revcomp(c.data(), c.size()); c.ext = nullptr; c.ext_n = 0; }
-    // SPEC S11: order by (length desc, sequence asc)
-    std::sort(contigs.begin(), contigs.end(), [](const RawContig &a, const RawContig &b) {
-        if (a.size() != b.size()) return a.size() > b.size();
-        return memcmp(a.data(), b.data(), a.size()) < 0;
-    });
+    auto canon = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            RawContig &c = contigs[i];
+            if (revcomp_is_smaller(c.data(), c.size())) { c.own = revcomp(c.data(), c.size()); c.ext = nullptr; c.ext_n = 0; }
+        }
+    };
+    if (many) par_ranges(contigs.size(), grain, canon); else canon(0, contigs.size());
+    // SPEC S11: order by (length desc, sequence asc).  An index is sorted, not the records; with many contigs the
+    // ranges are sorted in parallel and merged pairwise.
     const size_t nc = contigs.size();
+    // (sorted through 16-byte keys — length and the first 32 bases, 2-bit packed — so that the comparisons stay in one
+    // array; the sequences themselves are only touched on a tie)
+    struct SortKey { uint64_t prefix; uint32_t len, idx; };
+    std::vector<SortKey> order(nc);
+    auto make_keys = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            const RawContig &c = contigs[i];
+            const char *p = c.data(); const size_t n = c.size(), m = std::min<size_t>(n, 32);
+            uint64_t pf = 0;
+            for (size_t j = 0; j < m; j++) { const char ch = p[j]; pf = (pf << 2) | (uint64_t)(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3); }
+            pf <<= 2 * (32 - m);
+            order[i] = SortKey{pf, (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu), (uint32_t)i};
+        }
+    };
+    if (many) par_ranges(nc, grain, make_keys); else make_keys(0, nc);
+    auto before = [&](const SortKey &x, const SortKey &y) {
+        if (x.len != y.len) return x.len > y.len;
+        if (x.prefix != y.prefix) return x.prefix < y.prefix;
+        const RawContig &a = contigs[x.idx], &b = contigs[y.idx];
+        if (a.size() != b.size()) return a.size() > b.size();           // (lengths beyond 2^32 - 1)
+        const int c = memcmp(a.data(), b.data(), a.size());
+        return c != 0 ? c < 0 : x.idx < y.idx;                          // (equal spellings cannot occur; keeps the order total)
+    };
+    if (many && nc >= 4) {
+        WorkPool &pool = WorkPool::get();
+        size_t pieces = 1; while (pieces * 2 <= pool.size() * 2 && nc / (pieces * 2) >= grain) pieces *= 2;
+        std::vector<size_t> cut(pieces + 1);
+        for (size_t t = 0; t <= pieces; t++) cut[t] = nc * t / pieces;
+        pool.run(pieces, [&](size_t t) { std::sort(order.begin() + cut[t], order.begin() + cut[t + 1], before); });
+        std::vector<SortKey> tmp(nc);
+        for (size_t width = 1; width < pieces; width *= 2) {
+            const size_t n_merges = pieces / (2 * width);
+            pool.run(n_merges, [&](size_t j) {
+                const size_t a = cut[2 * width * j], m = cut[2 * width * j + width], b = cut[2 * width * (j + 1)];
+                std::merge(order.begin() + a, order.begin() + m, order.begin() + m, order.begin() + b, tmp.begin() + a, before);
+            });
+            order.swap(tmp);
+        }
+    } else std::sort(order.begin(), order.end(), before);
+    {
+        std::vector<RawContig> sorted(nc);
+        auto place = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) sorted[i] = std::move(contigs[order[i].idx]); };
+        if (many) par_ranges(nc, grain, place); else place(0, nc);
+        contigs.swap(sorted);
+    }
+    std::vector<SortKey>().swap(order);
     out.ncontigs = nc;
 
     // links: first k-mer of every (contig, orientation) -> id; '+' entries win over '-'.  K-mers are handled
-    // 2-bit packed (4 words hold k <= 127): a fragmented assembly has 10^4..10^6 contigs and this map is
+    // 2-bit packed (4 words hold k <= 127): a fragmented assembly has 10^4..10^7 contigs and this map is
     // the whole cost of the writer then.
     struct Key {
         uint64_t w[4];
@@ -146,128 +309,199 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         for (uint32_t i = 0; i < k; i++) { const uint32_t pos = 2 * i; x.w[pos >> 6] |= (3 - code(p[i])) << (pos & 63); }
         return x;
     };
-    // flat open-addressing table (the first entry of a key wins, like unordered_map::emplace)
+    // Flat open-addressing table, one 64-bit word per slot: fingerprint of the key (23 bits) | orientation | contig
+    // (40 bits).  The key of an entry is recomputed from its contig, but only when the fingerprints agree, so a probe
+    // is one cache miss; many threads fill the table with compare-and-swap.  Of several entries with one key the
+    // SMALLEST word survives — same key, same fingerprint: '+' before '-', then the smaller contig id — which is
+    // what "all '+' entries first, then all '-', the first one in wins" gave the serial writer, and is order-free.
     size_t cap = 16; while (cap < 4 * nc + 4) cap <<= 1;
-    std::vector<Key> hk(cap); std::vector<uint64_t> hv(cap, ~0ull);
+    std::unique_ptr<std::atomic<uint64_t>[]> hv(new std::atomic<uint64_t>[cap]);
+    par_ranges(cap, 1 << 16, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) hv[i].store(~0ull, std::memory_order_relaxed); });
     const KeyHash hasher;
-    auto put = [&](const Key &x, uint64_t v) {
-        size_t s = hasher(x) & (cap - 1);
-        while (hv[s] != ~0ull) { if (hk[s] == x) return; s = (s + 1) & (cap - 1); }
-        hk[s] = x; hv[s] = v;
+    auto dec_c = [](uint64_t v) { return (uint32_t)(v & ((1ull << 40) - 1)); };
+    auto dec_o = [](uint64_t v) { return (uint32_t)((v >> 40) & 1); };
+    auto key_of_enc = [&](uint64_t v) -> Key {
+        const RawContig &c = contigs[dec_c(v)];
+        return dec_o(v) ? pack_rc(c.data() + c.size() - k) : pack(c.data());
     };
-    auto get = [&](const Key &x) -> uint64_t {
-        size_t s = hasher(x) & (cap - 1);
-        while (hv[s] != ~0ull) { if (hk[s] == x) return hv[s]; s = (s + 1) & (cap - 1); }
-        return ~0ull;
-    };
-    std::vector<Key> tail_plus(nc), tail_minus(nc);
-    for (size_t i = 0; i < nc; i++) put(pack(contigs[i].data()), i * 2);
-    for (size_t i = 0; i < nc; i++) {
-        const char *first = contigs[i].data(), *last = contigs[i].data() + contigs[i].size() - k;
-        put(pack_rc(last), i * 2 + 1);                  // first k-mer of the '-' orientation
-        tail_plus[i] = pack(last);                      // last k-mer of '+'
-        tail_minus[i] = pack_rc(first);                 // last k-mer of '-'
-    }
-    typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> Link;
-    std::vector<Link> links;
-    for (size_t i = 0; i < nc; i++) for (uint32_t o = 0; o < 2; o++) {
-        Key cand = o ? tail_minus[i] : tail_plus[i];
-        shl2(cand, 0); mask_k(cand);                    // drop the first base, append A
-        for (uint64_t b = 0; b < 4; b++) {
-            cand.w[0] = (cand.w[0] & ~3ull) | b;
-            const uint64_t hit = get(cand);
-            if (hit == ~0ull) continue;
-            const uint32_t cj = (uint32_t)(hit >> 1), oj = (uint32_t)(hit & 1);
-            Link L((uint32_t)i + 1, o, cj + 1, oj), M(cj + 1, !oj, (uint32_t)i + 1, !o);
-            links.push_back(M < L ? M : L);
+    auto fp_of = [](size_t h) -> uint64_t { uint64_t f = (uint64_t)(h >> 41); return f == 0x7FFFFF ? 0x7FFFFE : f; };   // (all ones is "empty")
+    auto put2 = [&](const Key &x, uint64_t contig, uint64_t o) {
+        const size_t h = hasher(x);
+        const uint64_t v = (fp_of(h) << 41) | (o << 40) | contig;
+        size_t s = h & (cap - 1);
+        for (;;) {
+            uint64_t cur = hv[s].load(std::memory_order_acquire);
+            if (cur == ~0ull && hv[s].compare_exchange_strong(cur, v, std::memory_order_acq_rel)) return;
+            if ((cur >> 41) == (v >> 41) && key_of_enc(cur) == x) {
+                while (v < cur && !hv[s].compare_exchange_weak(cur, v, std::memory_order_acq_rel)) {}
+                return;
+            }
+            s = (s + 1) & (cap - 1);
         }
-    }
+    };
+    auto get2 = [&](const Key &x) -> uint64_t {
+        const size_t h = hasher(x);
+        const uint64_t f = fp_of(h);
+        size_t s = h & (cap - 1);
+        for (;;) {
+            const uint64_t cur = hv[s].load(std::memory_order_relaxed);
+            if (cur == ~0ull) return ~0ull;
+            if ((cur >> 41) == f && key_of_enc(cur) == x) return cur;
+            s = (s + 1) & (cap - 1);
+        }
+    };
+    auto fill = [&](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) {
+            put2(pack(contigs[i].data()), i, 0);
+            put2(pack_rc(contigs[i].data() + contigs[i].size() - k), i, 1);           // first k-mer of the '-' orientation
+        }
+    };
+    if (many) par_ranges(nc, grain, fill); else fill(0, nc);
+    typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> Link;
+    auto find_links = [&](size_t a, size_t b, std::vector<Link> &dst) {
+        for (size_t i = a; i < b; i++) for (uint32_t o = 0; o < 2; o++) {
+            // last k-mer of the orientation: of '+' the contig's last k-mer, of '-' the reverse complement of its first
+            Key cand = o ? pack_rc(contigs[i].data()) : pack(contigs[i].data() + contigs[i].size() - k);
+            shl2(cand, 0); mask_k(cand);                    // drop the first base, append A
+            for (uint64_t bb = 0; bb < 4; bb++) {
+                cand.w[0] = (cand.w[0] & ~3ull) | bb;
+                const uint64_t hit = get2(cand);
+                if (hit == ~0ull) continue;
+                const uint32_t cj = dec_c(hit), oj = dec_o(hit);
+                Link L((uint32_t)i + 1, o, cj + 1, oj), M(cj + 1, !oj, (uint32_t)i + 1, !o);
+                dst.push_back(M < L ? M : L);
+            }
+        }
+    };
+    std::vector<Link> links;
+    if (many) {
+        WorkPool &pool = WorkPool::get();
+        const size_t pieces = std::max<size_t>(1, std::min<size_t>(pool.size() * 4, nc / grain));
+        std::vector<std::vector<Link>> part(pieces);
+        pool.run(pieces, [&](size_t t) { find_links(nc * t / pieces, nc * (t + 1) / pieces, part[t]); });
+        size_t tot = 0; for (auto &v : part) tot += v.size();
+        links.reserve(tot);
+        for (auto &v : part) links.insert(links.end(), v.begin(), v.end());
+    } else find_links(0, nc, links);
     std::sort(links.begin(), links.end());
     links.erase(std::unique(links.begin(), links.end()), links.end());
 
     // Straight into the JSON text in key order (a 5 Mbp contig is copied three times — FASTA, GFA1, GFA2 —
-    // and never staged in per-format strings).
+    // and never staged in per-format strings).  Every record's size is known before a byte is written, so the
+    // records go to their places in one buffer from many threads: the big sequences in pieces, the many small
+    // records in ranges.
     size_t seq_bytes = 0;
     for (auto &c : contigs) seq_bytes += c.size();
-    std::vector<std::string> ids(nc), lens(nc), kcs(nc);
-    for (size_t i = 0; i < nc; i++) {
-        ids[i] = std::to_string(i + 1); lens[i] = std::to_string(contigs[i].size()); kcs[i] = std::to_string(contigs[i].kc);
-    }
     const std::string ov = std::to_string(k - 1);
-    auto sec_fasta = [&](auto &w) {
-        w.raw("{\"outfasta\":\"");
-        for (size_t i = 0; i < nc; i++) {
-            w.raw(">contig_"); w.raw(ids[i]); w.raw(" len="); w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.nl();
-            w.raw(contigs[i].data(), contigs[i].size()); w.nl();
-        }
-        w.raw("\",\"ncontigs\":"); w.num(nc);
+    // the per-contig and per-link records of each section, as functions of a sink
+    auto fasta_rec = [&](auto &w, size_t i) {
+        w.raw(">contig_"); w.num(i + 1); w.raw(" len="); w.num(contigs[i].size()); w.raw(" kc="); w.num(contigs[i].kc); w.nl();
+        w.seq(contigs[i].data(), contigs[i].size()); w.nl();
     };
-    auto sec_dot = [&](auto &w) {
-        w.raw(",\"outdot\":\"");
-        w.raw("digraph sparrowhawk {"); w.nl();
-        for (size_t i = 0; i < nc; i++) {
-            w.raw("  "); w.quote(); w.raw(ids[i]); w.quote(); w.raw(" [label="); w.quote(); w.raw(ids[i]); w.raw(" len=");
-            w.raw(lens[i]); w.raw(" kc="); w.raw(kcs[i]); w.quote(); w.raw("];"); w.nl();
-        }
-        for (const Link &L : links) {
-            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-            w.raw("  "); w.quote(); w.num(a); w.quote(); w.raw(" -> "); w.quote(); w.num(b); w.quote();
-            w.raw(" [label="); w.quote(); w.raw(ao ? "-" : "+"); w.raw(bo ? "-" : "+"); w.quote(); w.raw("];"); w.nl();
-        }
-        w.raw("}"); w.nl();
+    auto dot_node = [&](auto &w, size_t i) {
+        w.raw("  "); w.quote(); w.num(i + 1); w.quote(); w.raw(" [label="); w.quote(); w.num(i + 1); w.raw(" len=");
+        w.num(contigs[i].size()); w.raw(" kc="); w.num(contigs[i].kc); w.quote(); w.raw("];"); w.nl();
     };
-    auto sec_gfa1 = [&](auto &w) {
-        w.raw("\",\"outgfa\":\"");
-        w.raw("H"); w.tab(); w.raw("VN:Z:1.0"); w.nl();
-        for (size_t i = 0; i < nc; i++) {
-            w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab(); w.raw("LN:i:"); w.raw(lens[i]);
-            w.tab(); w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
-        }
-        for (const Link &L : links) {
-            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-            w.raw("L"); w.tab(); w.num(a); w.tab(); w.raw(ao ? "-" : "+"); w.tab(); w.num(b); w.tab();
-            w.raw(bo ? "-" : "+"); w.tab(); w.raw(ov); w.raw("M"); w.nl();
+    auto dot_link = [&](auto &w, size_t j) {
+        const Link &L = links[j];
+        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+        w.raw("  "); w.quote(); w.num(a); w.quote(); w.raw(" -> "); w.quote(); w.num(b); w.quote();
+        w.raw(" [label="); w.quote(); w.raw(ao ? "-" : "+"); w.raw(bo ? "-" : "+"); w.quote(); w.raw("];"); w.nl();
+    };
+    auto gfa1_seg = [&](auto &w, size_t i) {
+        w.raw("S"); w.tab(); w.num(i + 1); w.tab(); w.seq(contigs[i].data(), contigs[i].size()); w.tab(); w.raw("LN:i:"); w.num(contigs[i].size());
+        w.tab(); w.raw("KC:i:"); w.num(contigs[i].kc); w.nl();
+    };
+    auto gfa1_link = [&](auto &w, size_t j) {
+        const Link &L = links[j];
+        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+        w.raw("L"); w.tab(); w.num(a); w.tab(); w.raw(ao ? "-" : "+"); w.tab(); w.num(b); w.tab();
+        w.raw(bo ? "-" : "+"); w.tab(); w.raw(ov); w.raw("M"); w.nl();
+    };
+    auto gfa2_seg = [&](auto &w, size_t i) {
+        w.raw("S"); w.tab(); w.num(i + 1); w.tab(); w.num(contigs[i].size()); w.tab(); w.seq(contigs[i].data(), contigs[i].size()); w.tab();
+        w.raw("KC:i:"); w.num(contigs[i].kc); w.nl();
+    };
+    auto gfa2_link = [&](auto &w, size_t j) {
+        const Link &L = links[j];
+        const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
+        const uint64_t la = contigs[a - 1].size(), lb = contigs[b - 1].size();
+        w.raw("E"); w.tab(); w.raw("*"); w.tab(); w.num(a); w.raw(ao ? "-" : "+"); w.tab(); w.num(b);
+        w.raw(bo ? "-" : "+"); w.tab();
+        if (!ao) { w.num(la - (k - 1)); w.tab(); w.num(la); w.raw("$"); w.tab(); }
+        else { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == la) w.raw("$"); w.tab(); }
+        if (!bo) { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == lb) w.raw("$"); w.tab(); }
+        else { w.num(lb - (k - 1)); w.tab(); w.num(lb); w.raw("$"); w.tab(); }
+        w.raw(ov); w.raw("M"); w.nl();
+    };
+    // A "part" = a run of records of one kind, preceded by a literal: {literal, kind, count}.  The JSON is the
+    // concatenation of the parts; sizes are measured per record (prefix sums), then every range of records and
+    // every big sequence copy becomes a task.
+    enum Kind { NONE, FASTA, DOTN, DOTL, G1S, G1L, G2S, G2L };
+    struct Part { std::string lit; Kind kind; size_t count; };
+    std::vector<Part> parts;
+    parts.push_back({"{\"outfasta\":\"", FASTA, nc});
+    parts.push_back({"\",\"ncontigs\":" + std::to_string(nc) + ",\"outdot\":\"digraph sparrowhawk {\\n", DOTN, nc});
+    parts.push_back({"", DOTL, links.size()});
+    parts.push_back({"}\\n\",\"outgfa\":\"H\\tVN:Z:1.0\\n", G1S, nc});
+    parts.push_back({"", G1L, links.size()});
+    parts.push_back({"\",\"outgfav2\":\"H\\tVN:Z:2.0\\n", G2S, nc});
+    parts.push_back({"", G2L, links.size()});
+    parts.push_back({"\"}", NONE, 0});
+    auto emit_rec = [&](auto &w, Kind kd, size_t i) {
+        switch (kd) {
+            case FASTA: fasta_rec(w, i); break; case DOTN: dot_node(w, i); break; case DOTL: dot_link(w, i); break;
+            case G1S: gfa1_seg(w, i); break; case G1L: gfa1_link(w, i); break; case G2S: gfa2_seg(w, i); break;
+            case G2L: gfa2_link(w, i); break; default: break;
         }
     };
-    auto sec_gfa2 = [&](auto &w) {
-        w.raw("\",\"outgfav2\":\"");
-        w.raw("H"); w.tab(); w.raw("VN:Z:2.0"); w.nl();
-        for (size_t i = 0; i < nc; i++) {
-            w.raw("S"); w.tab(); w.raw(ids[i]); w.tab(); w.raw(lens[i]); w.tab(); w.raw(contigs[i].data(), contigs[i].size()); w.tab();
-            w.raw("KC:i:"); w.raw(kcs[i]); w.nl();
+    // every part is cut into ranges of records; a range is measured (SizeSink) and later written (PtrSink) by one
+    // task, so only the ranges' offsets are kept — no per-record tables for millions of contigs
+    struct Range { size_t part, a, b, bytes, off; };
+    std::vector<Range> ranges;
+    std::vector<size_t> part_off(parts.size() + 1, 0);
+    for (size_t p = 0; p < parts.size(); p++) {
+        const size_t cnt = parts[p].count;
+        if (!cnt) continue;
+        const size_t per = many ? std::max<size_t>(grain, cnt / (WorkPool::get().size() * 4) + 1) : cnt;
+        for (size_t a = 0; a < cnt; a += per) ranges.push_back(Range{p, a, std::min(cnt, a + per), 0, 0});
+    }
+    auto measure = [&](size_t r) { SizeSink z; for (size_t i = ranges[r].a; i < ranges[r].b; i++) emit_rec(z, parts[ranges[r].part].kind, i); ranges[r].bytes = z.n; };
+    if (many && ranges.size() > 1) WorkPool::get().run(ranges.size(), measure); else for (size_t r = 0; r < ranges.size(); r++) measure(r);
+    {
+        size_t at = 0, r = 0;
+        for (size_t p = 0; p < parts.size(); p++) {
+            part_off[p] = at; at += parts[p].lit.size();
+            for (; r < ranges.size() && ranges[r].part == p; r++) { ranges[r].off = at; at += ranges[r].bytes; }
         }
-        for (const Link &L : links) {
-            const uint32_t a = std::get<0>(L), ao = std::get<1>(L), b = std::get<2>(L), bo = std::get<3>(L);
-            const uint64_t la = contigs[a - 1].size(), lb = contigs[b - 1].size();
-            w.raw("E"); w.tab(); w.raw("*"); w.tab(); w.num(a); w.raw(ao ? "-" : "+"); w.tab(); w.num(b);
-            w.raw(bo ? "-" : "+"); w.tab();
-            if (!ao) { w.num(la - (k - 1)); w.tab(); w.num(la); w.raw("$"); w.tab(); }
-            else { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == la) w.raw("$"); w.tab(); }
-            if (!bo) { w.raw("0"); w.tab(); w.raw(ov); if ((uint64_t)(k - 1) == lb) w.raw("$"); w.tab(); }
-            else { w.num(lb - (k - 1)); w.tab(); w.num(lb); w.raw("$"); w.tab(); }
-            w.raw(ov); w.raw("M"); w.nl();
-        }
-        w.raw("\"}");
-    };
-    SizeSink z1, z2, z3, z4;
-    sec_fasta(z1); sec_dot(z2); sec_gfa1(z3); sec_gfa2(z4);
-    const size_t total = z1.n + z2.n + z3.n + z4.n;
+        part_off[parts.size()] = at;
+    }
+    const size_t total = part_off[parts.size()];
     // (a recycled string keeps its size: growing it is the only time its bytes are filled twice)
     std::string js = take_big_string();
     if (js.size() < total) js.resize(total);
     char *base = &js[0];
-    auto run = [&](int which) {
-        if (which == 0) { PtrSink w{base}; sec_fasta(w); PtrSink d{base + z1.n}; sec_dot(d); }
-        else if (which == 1) { PtrSink w{base + z1.n + z2.n}; sec_gfa1(w); }
-        else { PtrSink w{base + z1.n + z2.n + z3.n}; sec_gfa2(w); }
+    // sequences above `big` bytes are cut out of their record and copied in pieces by all threads
+    struct Copy { const char *src; char *dst; size_t n; };
+    const size_t big = std::max<size_t>(par_min / 4, 1);
+    const size_t piece = (size_t)256 << 10;
+    std::vector<std::pair<char *, std::pair<const char *, size_t>>> deferred;     // (filled by PtrSink::seq)
+    std::mutex deferred_mu;
+    for (size_t p = 0; p < parts.size(); p++) memcpy(base + part_off[p], parts[p].lit.data(), parts[p].lit.size());
+    auto write_range = [&](size_t r) {
+        PtrSink w{base + ranges[r].off};
+        w.big = seq_bytes >= par_min ? big : (size_t)-1; w.deferred = &deferred; w.mu = &deferred_mu;
+        for (size_t i = ranges[r].a; i < ranges[r].b; i++) emit_rec(w, parts[ranges[r].part].kind, i);
     };
-    const char *pm = getenv("SHK_WRITER_PAR_MIN");          // (tests force the threaded path on small outputs)
-    const size_t par_min = (pm && *pm) ? (size_t)strtoull(pm, nullptr, 10) : ((size_t)1 << 20);
-    if (seq_bytes >= par_min) {                             // three copies of megabytes: one thread each
-        std::thread t1(run, 1), t2(run, 2);
-        run(0);
-        t1.join(); t2.join();
-    } else { run(0); run(1); run(2); }
+    if (ranges.size() > 1 && (many || seq_bytes >= par_min)) WorkPool::get().run(ranges.size(), write_range);
+    else for (size_t r = 0; r < ranges.size(); r++) write_range(r);
+    if (!deferred.empty()) {
+        std::vector<Copy> copies;
+        for (auto &d : deferred)
+            for (size_t o = 0; o < d.second.second; o += piece)
+                copies.push_back(Copy{d.second.first + o, d.first + o, std::min(piece, d.second.second - o)});
+        WorkPool::get().run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
+    }
     js.resize(total);
     out.json = std::move(js);
     out.fasta.clear(); out.gfa1.clear(); out.gfa2.clear(); out.dot.clear();

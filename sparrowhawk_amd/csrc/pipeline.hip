@@ -1118,8 +1118,8 @@ public:
         // rings: their smallest k-mer (these three return at once when there is none)
         hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
         hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
-        hipLaunchKernelGGL(k_ring_rot, dim3(gr), dim3(256), 0, stream_, d_heads.p, (const unsigned int *)(ctl_.p + 6), ringmin.p, ol.p, fin.p,
-                           d_ncyc, (uint32_t *)(ctl_.p + 8));
+        hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, d_heads.p, (const unsigned int *)(ctl_.p + 6), ringmin.p,
+                           winfo.p, ol.p, fin.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
         HIPCHK(hipGetLastError());
         unsigned long long hc[4];
         HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));

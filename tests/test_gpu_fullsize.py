@@ -230,7 +230,12 @@ def test_circular_isolate_with_plasmid_full_size(torch_dev):
     assert h.get_assembly() == run(d, k, 5).get_assembly()
     # against the linear case of the same size (same reads machinery, linear sampling)
     dl = synth.device_sample_reads(torch, dev, genomes, goff, w, n_reads, L, k, 0xC1C, circular=False)
-    best_c = min(run(d, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
-    best_l = min(run(dl, k, 5).timings()["assemble_device_total_host_clock"] for _ in range(5))
-    print("assemble (device, host clock) circular %.3f ms, linear %.3f ms, ratio %.3f" % (best_c, best_l, best_c / best_l))
+    def asm_ms(dd):                                           # shk_assemble: device phases + the host writer
+        t = run(dd, k, 5).timings()
+        return t["assemble_device_total_host_clock"] + t["outputs_host_clock"], t
+    best_c, tc = min((asm_ms(d) for _ in range(6)), key=lambda x: x[0])
+    best_l, tl = min((asm_ms(dl) for _ in range(6)), key=lambda x: x[0])
+    print("circular", {a: round(b, 3) for a, b in tc.items()})
+    print("linear", {a: round(b, 3) for a, b in tl.items()})
+    print("assemble (device phases + writer, host clock) circular %.3f ms, linear %.3f ms, ratio %.3f" % (best_c, best_l, best_c / best_l))
     assert best_c <= 1.10 * best_l                         # within 10 % of the linear case

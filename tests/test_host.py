@@ -229,3 +229,56 @@ def test_packer_bgzf_blocks_are_inflated_in_parallel():
     with pytest.raises(ShkError) as ei:
         pack_fastq(bytes(broken), 21, 20)
     assert ei.value.code == -3
+
+
+def _writer_json(lib, contigs, k):
+    """contigs: list of (sequence str, kc) -> the product writer's JSON (host code only)."""
+    seqs = "".join(s for s, _ in contigs).encode()
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s, _ in contigs])
+    kc = np.array([c for _, c in contigs], dtype=np.uint64)
+    p = lib.shk_host_assembly_json(seqs, off.ctypes.data, kc.ctypes.data, len(contigs), k)
+    assert p
+    try:
+        return C.string_at(p).decode()
+    finally:
+        lib.shk_host_free(p)
+
+
+@pytest.mark.parametrize("k,err,threads_forced", [(31, 0.01, False), (31, 0.01, True), (51, 0.02, True), (21, 0.03, True)])
+def test_output_writer_equals_the_oracle_writer(lib, k, err, threads_forced, monkeypatch):
+    """a13 on the CPU: the oracle's unitigs, handed to the product's writer on a random strand and in a random
+    order, must come back as the oracle's JSON byte for byte — serial paths and the parallel ones (forced)."""
+    from util import run_oracle
+    if threads_forced:
+        monkeypatch.setenv("SHK_WRITER_PAR_MIN", "1")
+    g, fq = make_dataset(30000, 14, err=err, seed=900 + k)
+    o = run_oracle([fq], k=k, min_count=1, min_qual=0, no_bubble_collapse=True, no_dead_end_removal=True)     # (errors stay in, the graph stays branchy)
+    o.assemble()
+    cs, kcs = o.contigs(), o.contig_kc()
+    assert len(cs) > 20
+    rng = np.random.default_rng(k)
+    items = []
+    for i in rng.permutation(len(cs)):
+        items.append((revcomp(cs[i]) if rng.integers(0, 2) else cs[i], kcs[i]))
+    assert _writer_json(lib, items, k) == o.assembly_json()
+    assert _writer_json(lib, [], k) == '{"outfasta":"","ncontigs":0,"outdot":"digraph sparrowhawk {\\n}\\n","outgfa":"H\\tVN:Z:1.0\\n","outgfav2":"H\\tVN:Z:2.0\\n"}'
+
+
+def test_writer_pool_survives_many_back_to_back_jobs(lib, monkeypatch):
+    """The writer's persistent worker pool runs several short jobs per assembly (canonicalise, sort, fill, find,
+    measure, write): hundreds of assemblies in a row, with the parallel paths forced, must all give the same bytes
+    (a worker leaving one job must never take a task of the next)."""
+    monkeypatch.setenv("SHK_WRITER_PAR_MIN", "1")
+    rng = np.random.default_rng(3)
+    items = []
+    for i in range(300):
+        n = int(rng.integers(31, 200))
+        items.append(("".join("ACGT"[c] for c in rng.integers(0, 4, n)), int(rng.integers(1, 99))))
+    ref = _writer_json(lib, items, 31)
+    for rep in range(300):
+        assert _writer_json(lib, items, 31) == ref, rep
+    big = ("".join("ACGT"[c] for c in rng.integers(0, 4, 3_000_000)), 7)        # the big-sequence path: copies in pieces
+    ref = _writer_json(lib, [big] + items[:20], 31)
+    for rep in range(20):
+        assert _writer_json(lib, [big] + items[:20], 31) == ref, rep

@@ -20,5 +20,5 @@ for circ in (True, False):
     keys = sorted(ts[0])
     print("circular" if circ else "linear")
     for kk in keys:
-        if kk.startswith("collapse") or kk.startswith("assemble") or kk.startswith("correct") or kk.startswith("adj") or kk.startswith("graph"):
+        if kk.startswith("outputs") or kk.startswith("collapse") or kk.startswith("assemble") or kk.startswith("correct") or kk.startswith("adj") or kk.startswith("graph"):
             print("   %-40s %.4f" % (kk, min(t[kk] for t in ts)))
