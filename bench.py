@@ -58,26 +58,26 @@ def make_reads_on_device(torch, dev, genome_len, coverage, read_len, seed, read_
     return words, seg_off, n_reads, n_bases, genome
 
 
-def cpu_baseline(k, min_count, read_len, coverage):
-    """The oracle (CPU restatement, single thread) timed on a bounded sample of the same
-    workload: a 5x smaller isolate at the same coverage / read length / k."""
-    from oracle import Oracle
-    from sparrowhawk_amd import synth
-    genome_len = 1_000_000
-    g = synth.random_genome(genome_len, 0xEC02)
-    codes, quals = synth.sample_reads(g, genome_len * coverage // read_len, read_len, 0xEC02 + 1)
-    fq = synth.to_fastq(codes, quals)
-    o = Oracle(k=k, min_count=min_count, min_qual=20)
-    o.add_fastq(fq)
+def cpu_baseline(k, min_count, host_words, host_seg, n_bases, gpu_fasta):
+    """The multi-threaded CPU restatement (oracle/cpu_mt.cpp: std::thread over all host cores, hash tables) timed on
+    the FULL workload of this bench line — the same packed reads the GPU got — and cross-checked against the GPU's
+    contigs.  Build's CPU restatement, not upstream sparrowhawk-asm (its source is absent from the reference)."""
+    from oracle import CpuMt
+    m = CpuMt(k, 0)                                      # 0 = std::thread::hardware_concurrency()
     t0 = time.perf_counter()
-    o.count(naive=False)
-    o.assemble()
+    m.count(host_words, host_seg, emit_threshold=min_count)
+    t1 = time.perf_counter()
+    m.filter(min_count)
+    m.assemble()
     dt = time.perf_counter() - t0
-    nb = codes.size
-    return {"value": nb / dt / 1e9, "unit": "Gbases/s", "cores": 1, "kind": "port",
-            "sample": f"{genome_len} bp isolate, {coverage}x, {read_len} bp reads, k={k} "
-                      f"({nb / 1e6:.0f} Mbases; 1/5 of the GPU workload's genome), oracle count+assemble "
-                      f"{dt:.1f} s; build's CPU restatement, not upstream sparrowhawk-asm"}
+    fa = m.fasta()
+    return {"value": n_bases / dt / 1e9, "unit": "Gbases/s", "cores": int(m.threads), "kind": "port",
+            "hardware_concurrency": int(CpuMt.hardware_threads()),
+            "contigs_equal_gpu": bool(fa == gpu_fasta),
+            "sample": f"the full workload ({n_bases / 1e6:.0f} Mbases, the same packed reads), count {t1 - t0:.2f} s + "
+                      f"filter/graph/correct/collapse {dt - (t1 - t0):.2f} s on {m.threads} threads; multi-threaded hash-table "
+                      f"restatement (oracle/cpu_mt.cpp), checked against the single-threaded oracle in tests/test_cpu_mt.py; "
+                      f"build's CPU restatement, not upstream sparrowhawk-asm"}
 
 
 def main():
@@ -186,6 +186,29 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     out, _, _ = one_step(keep=True)                      # untimed: fetch the result for checking
+    # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
+    # strings on the host; the upload rides in front of pass 1 on the library's stream
+    host_leg = None
+    if world == 1 and args.err == 0:
+        hw = torch.empty(d_bases.numel(), dtype=torch.int32).pin_memory()
+        hs = torch.empty(d_seg.numel(), dtype=torch.int32).pin_memory()
+        hw.copy_(d_bases); hs.copy_(d_seg)
+        torch.cuda.synchronize()
+
+        def host_step():
+            h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+            h.preprocess_packed_host(hw.data_ptr(), hs.data_ptr(), n_reads, n_bases, n_reads)
+            h.assemble()
+            assert raw_get_assembly(h._h)
+            h.free()
+        for _ in range(max(1, args.warmup)):
+            host_step()
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        for _ in range(args.steps):
+            host_step()
+        torch.cuda.synchronize()
+        host_leg = (time.perf_counter() - th) / args.steps
     if world > 1:
         tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -213,10 +236,11 @@ def main():
     p_ms = sum(t.get("partition_kernel", 0.0) for t in all_t) / max(1, len(all_t))
     # the dominant kernel of the k-mer-count step (two kernels: partition, count)
     dom, k_ms = ("k_partition", p_ms) if p_ms > c_ms else ("k_count_partitions", c_ms)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_all = None, None, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-        traffic, traffic_src = tj["bytes_per_launch"].get(dom), tj["source"]
+        traffic_all = tj["bytes_per_launch"]
+        traffic, traffic_src = traffic_all.get(dom), tj["source"]
     except Exception:
         pass
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
@@ -243,6 +267,12 @@ def main():
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                     # what SURVEY.md 8(d) asks to report beside the algorithmic fraction: the kernel's MEASURED fabric
+                     # traffic (rocprofv3 PMC, profiles/traffic.json) over its live duration, against the same peak
+                     "measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_ms > 0) else None,
+                     "measured_frac_other_count_kernel": (lambda o, ms: (traffic_all[o] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                                          if (o in traffic_all and ms > 0) else None)(
+                         "k_partition" if dom == "k_count_partitions" else "k_count_partitions", p_ms if dom == "k_count_partitions" else c_ms),
                      "achievable_peak": stream_gbs, "frac_of_achievable": (achieved / stream_gbs) if stream_gbs else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                      "count_step_ms": c_ms + p_ms,
@@ -250,9 +280,15 @@ def main():
                      "note": "integer/hash path bound by instruction issue and LDS round trips, not by HBM: see DESIGN.md section 4"},
         "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
     }
+    if host_leg is not None:
+        line["value_host_pinned"] = n_bases / host_leg / 1e9
+        line["ms_per_step_host_pinned"] = host_leg * 1e3
+        line["host_pinned_note"] = ("packed reads in host pinned memory -> contigs on host (SURVEY.md 8d clock): one "
+                                    "hipMemcpyAsync of %.0f MB in front of pass 1, not yet overlapped with it" % ((d_bases.numel() + d_seg.numel()) * 4 / 1e6))
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, args.read_len, args.coverage)
+        if world == 1 and not args.no_cpu_baseline and args.k <= 63:
+            line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, d_bases.cpu().numpy().view("uint32"),
+                                                d_seg.cpu().numpy().view("uint32"), n_bases, res["outfasta"])
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

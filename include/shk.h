@@ -78,6 +78,12 @@ int shk_finish_reads(shk_handle *h);
 int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off,
                                  uint64_t n_seg, uint64_t n_bases, uint64_t n_reads);
 
+/* The same reads, packed, in HOST memory (pinned memory makes the upload run at the link's rate): uploaded on the
+ * handle's stream, then counted as shk_preprocess_packed_device does.  This is where SURVEY.md 8(d) starts the
+ * clock of the throughput metric ("packed reads resident in host pinned memory"). */
+int shk_preprocess_packed_host(shk_handle *h, const uint32_t *bases, const uint32_t *seg_off,
+                               uint64_t n_seg, uint64_t n_bases, uint64_t n_reads);
+
 /* AssemblyHelper::get_preprocessing_info() -> String                   Assembler.ts:36,110
  * JSON {"nkmers":int,"histo":[500 ints],"used_min_count":int}          Assembler.ts:1-5 */
 const char *shk_get_preprocessing_info(shk_handle *h);

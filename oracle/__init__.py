@@ -2,4 +2,4 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """
-from .binding import Oracle, build_oracle, oracle_fit  # noqa: F401
+from .binding import CpuMt, Oracle, build_oracle, oracle_fit  # noqa: F401

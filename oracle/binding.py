@@ -162,3 +162,88 @@ class Oracle:
     def dot(self): return self.L.shko_dot(self.h).decode()
     def assembly_json(self): return self.L.shko_assembly_json(self.h).decode()
     def preprocessing_json(self): return self.L.shko_preprocessing_json(self.h).decode()
+
+
+# ---- multi-threaded CPU baseline (oracle/cpu_mt.cpp): bench.py's cpu_baseline leg and tests/test_cpu_mt.py ----
+_MT = None
+
+
+def _mt():
+    global _MT
+    if _MT is None:
+        so = os.path.join(_HERE, "libshk_cpu_mt.so")
+        src = os.path.join(_HERE, "cpu_mt.cpp")
+        if not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+            subprocess.check_call(["make", "-C", _HERE, "libshk_cpu_mt.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        u64, u32, vp, cp = C.c_uint64, C.c_uint32, C.c_void_p, C.c_char_p
+        for name, (res, args) in {
+            "cpumt_hardware_threads": (C.c_uint, []), "cpumt_new": (vp, [u32, u32]), "cpumt_free": (None, [vp]),
+            "cpumt_threads": (u32, [vp]), "cpumt_count": (None, [vp, vp, vp, u64, u32]),
+            "cpumt_total_instances": (u64, [vp]), "cpumt_histo": (None, [vp, vp]), "cpumt_filter": (C.c_int, [vp, u32]),
+            "cpumt_n_solid": (u64, [vp]), "cpumt_get_solid": (None, [vp, vp, vp]),
+            "cpumt_assemble": (None, [vp, C.c_int, C.c_int]), "cpumt_n_contigs": (u64, [vp]), "cpumt_fasta": (cp, [vp]),
+        }.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _MT = L
+    return _MT
+
+
+class CpuMt:
+    """The multi-threaded CPU restatement (k <= 63): packed reads in, histogram / solid set / FASTA out."""
+
+    def __init__(self, k, threads=0):
+        self.L = _mt()
+        self.k, self.W = k, (2 * k + 63) // 64
+        self.h = self.L.cpumt_new(k, threads)
+        if not self.h:
+            raise ValueError("cpu_mt: k must be odd and within [15, 63]")
+        self.threads = self.L.cpumt_threads(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.cpumt_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def hardware_threads():
+        return _mt().cpumt_hardware_threads()
+
+    def count(self, bases, seg_off, emit_threshold=0):
+        """bases: uint32 words (2-bit packed, the device layout), seg_off: uint32[n_seg + 1]"""
+        b = np.ascontiguousarray(bases, dtype=np.uint32)
+        s = np.ascontiguousarray(seg_off, dtype=np.uint32)
+        self._keep = (b, s)
+        self.L.cpumt_count(self.h, b.ctypes.data, s.ctypes.data, len(s) - 1, emit_threshold)
+
+    @property
+    def total_instances(self): return self.L.cpumt_total_instances(self.h)
+
+    def histo(self):
+        h = np.zeros(500, dtype=np.uint64)
+        self.L.cpumt_histo(self.h, h.ctypes.data)
+        return h
+
+    def filter(self, threshold):
+        if self.L.cpumt_filter(self.h, threshold) != 0:
+            raise ValueError("threshold below the emit threshold")
+
+    def solid(self):
+        n = self.L.cpumt_n_solid(self.h)
+        keys = np.zeros((n, self.W), dtype=np.uint64)
+        cnt = np.zeros(n, dtype=np.uint32)
+        if n:
+            self.L.cpumt_get_solid(self.h, keys.ctypes.data, cnt.ctypes.data)
+        return keys, cnt
+
+    def assemble(self, no_bubble_collapse=False, no_dead_end_removal=False):
+        self.L.cpumt_assemble(self.h, int(no_bubble_collapse), int(no_dead_end_removal))
+
+    @property
+    def n_contigs(self): return self.L.cpumt_n_contigs(self.h)
+
+    def fasta(self): return self.L.cpumt_fasta(self.h).decode()

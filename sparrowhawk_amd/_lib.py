@@ -31,6 +31,7 @@ SIGNATURES = {
     "shk_push_reads": (_int, [_vp, _cp, _sz]),
     "shk_finish_reads": (_int, [_vp]),
     "shk_preprocess_packed_device": (_int, [_vp, _vp, _vp, _u64, _u64, _u64]),
+    "shk_preprocess_packed_host": (_int, [_vp, _vp, _vp, _u64, _u64, _u64]),
     "shk_get_preprocessing_info": (_cp, [_vp]),
     "shk_assemble": (_int, [_vp]),
     "shk_get_assembly": (_cp, [_vp]),

@@ -506,6 +506,34 @@ static int preprocess_packed_device_impl(shk_handle *h, const void *d_bases, con
     return run_counting(h, (const uint32_t *)d_bases, (const uint32_t *)d_seg_off, n_seg, n_bases);
 }
 
+static int preprocess_packed_host_impl(shk_handle *h, const uint32_t *bases, const uint32_t *seg_off, uint64_t n_seg,
+                                       uint64_t n_bases, uint64_t n_reads) {
+    if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used");
+    if (!bases || !seg_off) return fail(h, SHK_E_PARAM, "null host pointer");
+    if (n_bases >= 0xFFFFFFFFull || n_seg >= 0xFFFFFFFFull) return fail(h, SHK_E_PARAM, "batch too large (>= 2^32 bases)");
+    std::string err;
+    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } db, ds;
+    db.bytes = (size_t)((n_bases + 15) / 16 + 1) * 4; ds.bytes = (size_t)(n_seg + 1) * 4;
+    const size_t want_b = db.bytes, want_s = ds.bytes;
+    db.p = device_pool_alloc(db.bytes); ds.p = device_pool_alloc(ds.bytes);
+    if (!db.p || !ds.p) return fail(h, SHK_E_OOM, "preprocess: device memory for the packed reads");
+    const double t0 = now_ms();
+    void *st = h->pipe->stream();
+    // (the stream orders the upload in front of pass 1: no host wait in between)
+    if (device_copy_h2d_async(db.p, bases, want_b, st, err) || device_copy_h2d_async(ds.p, seg_off, want_s, st, err)) {
+        (void)device_stream_sync(st, err);
+        return fail(h, SHK_E_DEVICE, err);
+    }
+    h->post("preprocess:start"); h->post_mode("start"); h->post_loop_edge("loop:start");
+    h->n_reads = n_reads;
+    h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
+    const int rc = run_counting(h, (const uint32_t *)db.p, (const uint32_t *)ds.p, n_seg, n_bases);
+    { std::string e2; (void)device_stream_sync(st, e2); }      // the blocks go back to the pool idle, also after a failure
+    h->pipe->times().add("h2d_packed_reads_MB", (double)(want_b + want_s) / 1e6);
+    h->pipe->times().add("preprocess_from_host_total_host_clock", now_ms() - t0);
+    return rc;
+}
+
 // ---- shard layer: the single-GPU preprocess cut at its two exchange points ----------------------
 static uint32_t emit_threshold_of(const shk_handle *h) {
     return h->do_fit ? (h->min_count < 1u ? h->min_count : 1u) : h->min_count;
@@ -831,6 +859,10 @@ int shk_finish_reads(shk_handle *h) {
 int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
                                  uint64_t n_bases, uint64_t n_reads) {
     return guarded(h, Poison::AfterFirstBatch, [&] { return preprocess_packed_device_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads); });
+}
+int shk_preprocess_packed_host(shk_handle *h, const uint32_t *bases, const uint32_t *seg_off, uint64_t n_seg, uint64_t n_bases,
+                               uint64_t n_reads) {
+    return guarded(h, Poison::AfterFirstBatch, [&] { return preprocess_packed_host_impl(h, bases, seg_off, n_seg, n_bases, n_reads); });
 }
 int shk_shard_partition(shk_handle *h, const void *d_bases, const void *d_seg_off, uint64_t n_seg, uint64_t n_bases,
                         uint64_t n_reads, uint32_t n_partitions, uint64_t *part_records) {

@@ -1231,6 +1231,10 @@ int device_upload(const void *host, size_t bytes, void **dptr, std::string &err)
 }
 void device_free(void *dptr) { if (dptr) (void)hipFree(dptr); }
 int device_stream_sync(void *stream, std::string &err) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+int device_copy_h2d_async(void *dst, const void *src, size_t bytes, void *stream, std::string &err) {
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return 0;
+}
 
 // ---- host-side self-test helpers (same arithmetic as the kernels) ---------------------------
 template <int W> static int host_canon_t(const char *seq, uint32_t k, uint64_t *out, int *orient) {

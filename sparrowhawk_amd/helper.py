@@ -109,6 +109,9 @@ class AssemblyHelper:
         self._check(self._L.shk_preprocess_packed_device(self._h, d_bases_ptr, d_seg_off_ptr, n_seg,
                                                          n_bases, n_reads))
 
+    def preprocess_packed_host(self, bases_ptr, seg_off_ptr, n_seg, n_bases, n_reads=0):
+        self._check(self._L.shk_preprocess_packed_host(self._h, bases_ptr, seg_off_ptr, n_seg, n_bases, n_reads))
+
     # ---- stage inspection -------------------------------------------------------------------
     @property
     def key_words(self): return self._L.shk_key_words(self._h)

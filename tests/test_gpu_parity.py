@@ -616,3 +616,19 @@ def test_counts_saturate_at_u32_max():
     eh = np.zeros(500, dtype=np.uint64)
     np.add.at(eh, np.minimum(expect.astype(np.int64), 500) - 1, 1)
     assert np.array_equal(histo, eh)
+
+
+def test_packed_reads_in_host_memory_entry_point():
+    """shk_preprocess_packed_host (where SURVEY.md 8d starts the metric's clock): the packer's output handed over
+    from host memory gives the same bytes as the FASTQ entry point and the oracle."""
+    from sparrowhawk_amd import pack_fastq
+    for k, err in ((31, 0.01), (51, 0.0)):
+        g, fq = make_dataset(30000, 30, err=err, seed=640 + k)
+        bases, seg, nb, nr = pack_fastq(fq, k, 20)
+        h = AssemblyHelper.new(k, True, 3, 20, 0, False, False, False, False)
+        h.preprocess_packed_host(bases.ctypes.data, seg.ctypes.data, len(seg) - 1, nb, nr)
+        h.assemble()
+        compare_all(h, run_oracle([fq], k=k, min_count=3))
+        assert "h2d_packed_reads_MB" in h.timings()
+        with pytest.raises(ShkError):
+            h.preprocess_packed_host(bases.ctypes.data, seg.ctypes.data, len(seg) - 1, nb, nr)
