@@ -597,7 +597,8 @@ __device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtlCore &ctl, 
                                            unsigned long long *__restrict__ histo, KeyArr<W> out_keys,
                                            uint32_t *__restrict__ out_cnt, unsigned long long out_cap,
                                            unsigned long long *__restrict__ out_cursor, LT *list, uint32_t dbg_arg = 0,
-                                           uint32_t *hist_accum = nullptr /* LDS: the round's histogram is added here instead of to `histo` */) {
+                                           uint32_t *hist_accum = nullptr /* LDS: the round's histogram is added here instead of to `histo` */,
+                                           uint32_t bias = 0 /* Bloom mode: the occurrence that only set the filter's bits */) {
     const uint32_t dbg = SHK_DBG(dbg_arg);
     constexpr uint32_t S = KmerTable<W>::S;
     const int lane = threadIdx.x & 63;
@@ -607,7 +608,8 @@ __device__ __forceinline__ void table_emit(KmerTable<W> &tb, CountCtlCore &ctl, 
     for (uint32_t s = threadIdx.x; s < S; s += COUNT_THREADS) {
         // (S is a multiple of 64: whole waves.)  Singletons — nearly every slot when the reads carry
         // errors — go in with one LDS atomic per wave instead of 64 serialised ones on one address
-        const uint32_t c = tb.cnt[s];
+        uint32_t c = tb.cnt[s];
+        if (bias && c) { c = c > 0xFFFFFFFFu - bias ? 0xFFFFFFFFu : c + bias; tb.cnt[s] = c; }     // (rows are written from tb.cnt below)
         const unsigned long long m1 = __ballot(c == 1u);
         if (lane == 0 && m1) atomicAdd(&ctl.histo[0], (uint32_t)__popcll(m1));
         if (c > 1u) atomicAdd(&ctl.histo[c >= 500 ? 499 : c - 1], 1u);
@@ -1048,13 +1050,30 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
 
 // k-mer-level repartition of one overflowed partition: every canonical k-mer of its records goes to
 // bucket (hash bits 12..) of the item's region; cursors live in LDS, the fills are published at the end
-template <int W>
+// BLOOM (do_bloom, docs/src/assembly.md:18: "allowing for some degree of overcounting"): a blocked Bloom filter over
+// the partition's k-mers lives in LDS — one 32-bit word per k-mer, two bits in it, set and tested by ONE atomic OR,
+// so of several simultaneous first sightings of a k-mer exactly one sees "new".  A k-mer sighted as new only sets
+// its bits; every later sighting goes to the buckets as before.  Singletons — most of what an error-rich read set
+// holds — therefore never reach HBM or a table; the counts of the others lack their first sighting, which the
+// emit adds back (table_emit's bias).  A false positive sends a first sighting to the buckets too: that k-mer is
+// counted one too high — over, never under.  new_count[item] = sightings taken as new (distinct k-mers, less the
+// false positives).
+static constexpr uint32_t BLOOM_WORDS = 24576;           // 96 KB of LDS: 786 k bits per partition
+template <int W, bool BLOOM>
 __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, const OvfItem *__restrict__ items,
                                                                uint64_t *__restrict__ kmers,
-                                                               uint32_t *__restrict__ bucket_fill) {
+                                                               uint32_t *__restrict__ bucket_fill,
+                                                               uint32_t *__restrict__ new_count) {
     constexpr int RW = 2 * W;
     __shared__ uint32_t pre[257];
     __shared__ uint32_t cursor[OVF_MAX_F];
+    __shared__ uint32_t bloom[BLOOM ? BLOOM_WORDS : 1];
+    __shared__ uint32_t n_new;
+    if constexpr (BLOOM) {
+        for (uint32_t i = threadIdx.x; i < BLOOM_WORDS; i += COUNT_THREADS) bloom[i] = 0;
+        if (threadIdx.x == 0) n_new = 0;
+    }
+    uint32_t my_new = 0;
     const OvfItem it = items[blockIdx.x];
     const uint32_t p = it.p, S_runs = rvw.S;
     const int lane = threadIdx.x & 63;
@@ -1103,8 +1122,17 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
             Kmer<W> c;
 #pragma unroll
             for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
+            const uint32_t hk = km_mix32<W>(c);
+            if constexpr (BLOOM) {
+                const uint32_t h2 = mix32(hk ^ 0xC2B2AE35u);
+                const uint32_t word = (uint32_t)(((uint64_t)h2 * BLOOM_WORDS) >> 32);
+                const uint32_t b0 = hk & 31u, b1 = (hk >> 5) & 31u;
+                const uint32_t bits = (1u << b0) | (1u << (b1 == b0 ? (b0 + 1u) & 31u : b1));
+                const uint32_t old = atomicOr(&bloom[word], bits);
+                if ((old & bits) != bits) { my_new++; continue; }        // first sighting: only the filter learns of it
+            }
             // (any F: multiply-high of a second mix of the key hash, independent of the table slot and residue bits)
-            const uint32_t b = (uint32_t)(((uint64_t)mix32(km_mix32<W>(c) ^ 0x85EBCA6Bu) * F) >> 32);
+            const uint32_t b = (uint32_t)(((uint64_t)mix32(hk ^ 0x85EBCA6Bu) * F) >> 32);
             const uint32_t pos = atomicAdd(&cursor[b], 1u);
             if (pos < it.cap) {
                 uint64_t *dst = kmers + (it.base + (unsigned long long)b * it.cap + pos) * W;
@@ -1113,8 +1141,13 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_ovf_scatter(RunView rvw, cons
             }
         }
     }
+    if constexpr (BLOOM) {
+        for (int o = 32; o > 0; o >>= 1) my_new += __shfl_down(my_new, o);
+        if (lane == 0 && my_new) atomicAdd(&n_new, my_new);
+    }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < OVF_MAX_F; b += COUNT_THREADS) bucket_fill[(uint64_t)blockIdx.x * OVF_MAX_F + b] = cursor[b];
+    if constexpr (BLOOM) { if (threadIdx.x == 0) new_count[blockIdx.x] = n_new; }
 }
 
 // one non-empty bucket of a scattered partition: nb canonical k-mers from k-mer index `first`
@@ -1124,15 +1157,17 @@ struct BucketRef { unsigned long long first; uint32_t nb, pad; };
 // k_count_buckets (an item whose bucket region overflowed is scattered again by the host with the room it needs)
 __global__ __launch_bounds__(256) void k_ovf_check(const OvfItem *__restrict__ items, const uint32_t *__restrict__ bucket_fill,
                                                    uint32_t n_items, uint32_t *__restrict__ max_fill,
-                                                   BucketRef *__restrict__ list, uint32_t *__restrict__ list_n) {
+                                                   BucketRef *__restrict__ list, uint32_t *__restrict__ list_n,
+                                                   unsigned long long *__restrict__ sum_fill /* [n_items]: k-mers the item wrote */) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
         uint32_t mx = 0, ne = 0;
+        unsigned long long sm = 0;
         const OvfItem it = items[i];
         for (uint32_t b = 0; b < it.F; b++) {
             const uint32_t f = bucket_fill[(uint64_t)i * OVF_MAX_F + b];
-            mx = max(mx, f); ne += f != 0;
+            mx = max(mx, f); ne += f != 0; sm += f;
         }
-        max_fill[i] = mx;
+        max_fill[i] = mx; sum_fill[i] = sm;
         if (mx > it.cap || !ne) continue;
         uint32_t at = atomicAdd(list_n, ne);
         for (uint32_t b = 0; b < it.F; b++) {
@@ -1154,7 +1189,8 @@ __global__ __launch_bounds__(COUNT_THREADS, 8) void k_count_buckets(   // 8 wave
     const BucketRef *__restrict__ list, uint32_t n_list, const uint64_t *__restrict__ kmers,
     uint32_t threshold, unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
-    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg_arg /* timing experiments (ABLATE builds) */) {
+    unsigned long long *__restrict__ n_inst, uint32_t *__restrict__ flags, uint32_t dbg_arg /* timing experiments (ABLATE builds) */,
+    uint32_t bias /* Bloom mode: 1 */, unsigned long long *__restrict__ n_keys /* Bloom mode: distinct k-mers that reached a table */) {
     const uint32_t dbg = SHK_DBG(dbg_arg);
     constexpr uint32_t S = KmerTable<W>::S;
     // k-mers per thread that travel in registers: covers the bucket size the host aims for (<= 1.1 S, binomial
@@ -1187,9 +1223,11 @@ __global__ __launch_bounds__(COUNT_THREADS, 8) void k_count_buckets(   // 8 wave
             }
         }
     };
+    unsigned long long my_keys = 0;                      // (thread 0: table keys over all buckets of this workgroup)
     auto emit = [&](unsigned long long mine) {
-        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, dbg, whist);
-        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, dbg, whist);   // (the state words are not read after counting)
+        if (bias && threadIdx.x == 0) my_keys += ctl.n_used;
+        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, dbg, whist, bias);
+        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, dbg, whist, bias);   // (the state words are not read after counting)
     };
     uint32_t e = blockIdx.x;
     BucketRef ref = load_ref(e), ref_n = load_ref(e + gridDim.x);
@@ -1306,6 +1344,7 @@ __global__ __launch_bounds__(COUNT_THREADS, 8) void k_count_buckets(   // 8 wave
     for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
         if (whist[b]) atomicAdd(&histo[b], (unsigned long long)whist[b]);
     if (threadIdx.x == 0 && ctl.n_inst && dbg != 8) atomicAdd(n_inst, ctl.n_inst);
+    if (threadIdx.x == 0 && bias && my_keys) atomicAdd(n_keys, my_keys);
 }
 
 }  // namespace shk

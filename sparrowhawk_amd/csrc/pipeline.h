@@ -31,6 +31,9 @@ public:
                             uint64_t n_bases, std::string &err) = 0;
     // more batches will follow the first one (chunked / streamed input of unknown size): partition for the worst case
     virtual void expect_more_batches() = 0;
+    // do_bloom (docs/src/assembly.md:18): partitions that go through the k-mer-level repartition pass a Bloom
+    // pre-filter first, so their singletons are never stored; counts may then be one too high, never too low
+    virtual void set_bloom(bool on) = 0;
     // spectrum histogram (SPEC S5).  Rows with count <= emit_threshold will never be asked for
     // by filter(): the counting pass may drop them as soon as they are histogrammed.
     virtual int histogram(uint64_t histo[500], uint32_t emit_threshold, std::string &err) = 0;

@@ -525,6 +525,7 @@ public:
         have_parts_ = true;
         return 0;
     }
+    void set_bloom(bool on) override { bloom_ = on; }
     void expect_more_batches() override { if (!forced_P_ && batches_.empty() && !have_parts_) forced_P_ = (uint32_t)PART_MAX_P; }
 
     // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying.
@@ -538,11 +539,14 @@ public:
         constexpr uint32_t S = CountShared<W>::S;
         const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0;
         DevBuf<unsigned long long> dh;
-        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill; DevBuf<uint64_t> d_kmers; DevBuf<BucketRef> d_blist;
+        DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill, d_new; DevBuf<uint64_t> d_kmers; DevBuf<BucketRef> d_blist; DevBuf<unsigned long long> d_sumfill;
+        const bool bloom = bloom_ && !bloom_off_once_;          // (do_bloom: Bloom pre-filter in the k-mer-level repartition)
+        unsigned long long bloom_new = 0, bloom_kmer_bytes = 0, bloom_kmer_bytes_exact = 0;
         if (int rc = dh.alloc(500, err)) return rc;
         if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
         uint64_t cap = cap_hint;
         for (int attempt = 0; attempt < 2; attempt++) {
+            bloom_new = 0; bloom_kmer_bytes = 0; bloom_kmer_bytes_exact = 0;
             for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
             if (int rc = cnt.alloc(cap, err)) return rc;
             HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
@@ -583,7 +587,9 @@ public:
                     const unsigned long long per = (unsigned long long)S * env_u64("SHK_OVF_FILL_PCT", 110) / 100;
                     const uint32_t F = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>((ov[i].instances + per - 1) / per, 2ull), OVF_MAX_F);
                     if (ov[i].est_distinct == 0) n_untried++;
-                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", 150) / (100ull * F) + 256;   // 50 % slack
+                    // (Bloom mode: at least one sighting per distinct k-mer never reaches the buckets — error-rich
+                    // partitions are mostly singletons — so the regions start at the instance count, not 1.5 x it)
+                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", bloom ? 100 : 150) / (100ull * F) + 256;   // 50 % slack
                     items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
                     items[i].pad = 0; items[i].base = 0;
                 }
@@ -600,25 +606,40 @@ public:
                     if (int rc = d_fill.alloc((size_t)ni * OVF_MAX_F, err)) return rc;
                     if (int rc = d_kmers.alloc(tot * W, err)) return rc;
                     HIPCHK(hipMemcpyAsync(d_items.p, items.data(), (size_t)ni * sizeof(OvfItem), hipMemcpyHostToDevice, stream_));
-                    hipLaunchKernelGGL(k_ovf_scatter<W>, dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p);
+                    if (bloom) {
+                        if (int rc = d_new.alloc(ni, err)) return rc;
+                        hipLaunchKernelGGL((k_ovf_scatter<W, true>), dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p, d_new.p);
+                    } else {
+                        hipLaunchKernelGGL((k_ovf_scatter<W, false>), dim3(ni), dim3(COUNT_THREADS), 0, stream_, rv, d_items.p, d_kmers.p, d_fill.p, (uint32_t *)nullptr);
+                    }
                     HIPCHK(hipGetLastError());
                     if (int rc = d_maxfill.alloc(ni, err)) return rc;
                     unsigned long long n_buckets_ub = 0;
                     for (auto &it : items) n_buckets_ub += it.F;
                     if (int rc = d_blist.alloc(n_buckets_ub, err)) return rc;
                     HIPCHK(hipMemsetAsync(ctl_.p + 4, 0, sizeof(unsigned long long), stream_));
+                    if (int rc = d_sumfill.alloc(ni, err)) return rc;
                     hipLaunchKernelGGL(k_ovf_check, dim3(grid_for(ni)), dim3(256), 0, stream_, d_items.p, d_fill.p, ni, d_maxfill.p,
-                                       d_blist.p, (uint32_t *)(ctl_.p + 4));
+                                       d_blist.p, (uint32_t *)(ctl_.p + 4), d_sumfill.p);
                     HIPCHK(hipGetLastError());
-                    std::vector<uint32_t> mxf(ni);
+                    std::vector<uint32_t> mxf(ni), newc(bloom ? ni : 0);
+                    std::vector<unsigned long long> smf(ni);
                     unsigned long long n_list = 0;
+                    HIPCHK(hipMemcpyAsync(smf.data(), d_sumfill.p, (size_t)ni * 8, hipMemcpyDeviceToHost, stream_));
+                    if (bloom) HIPCHK(hipMemcpyAsync(newc.data(), d_new.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipMemcpyAsync(mxf.data(), d_maxfill.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipMemcpyAsync(&n_list, ctl_.p + 4, sizeof n_list, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(stream_wait(stream_));
                     std::vector<OvfItem> again;
                     uint32_t n_good = 0;
                     for (uint32_t i = 0; i < ni; i++) {
-                        if (mxf[i] <= items[i].cap) n_good++;
+                        if (mxf[i] <= items[i].cap) {
+                            n_good++;
+                            if (bloom) {                               // (statistics + the histogram's singleton bin)
+                                bloom_new += newc[i];
+                                bloom_kmer_bytes += smf[i] * 8ull * W;       // k-mer instances that still went to HBM
+                            }
+                        }
                         else if (pass + 1 < max_passes && (unsigned long long)mxf[i] + 256 < 0xFFFFFFF0ull) {
                             OvfItem it = items[i]; it.cap = mxf[i] + 256; again.push_back(it);       // the exact need is known now
                         } else bad.push_back(items[i].p);
@@ -628,7 +649,8 @@ public:
                         const uint32_t bgrid = (uint32_t)std::min<unsigned long long>(n_list, 2ull * (unsigned long long)n_cus_);
                         hipLaunchKernelGGL(k_count_buckets<W>, dim3(bgrid), dim3(COUNT_THREADS), 0, stream_,
                                            d_blist.p, (uint32_t)n_list, d_kmers.p, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
-                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), env_dbg("SHK_DEBUG_B"));
+                                           ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), env_dbg("SHK_DEBUG_B"),
+                                           bloom ? 1u : 0u, ctl_.p + 9);
                         HIPCHK(hipGetLastError());
                         HIPCHK(stream_wait(stream_));      // d_items / d_kmers are reused by the next pass
                     }
@@ -651,6 +673,21 @@ public:
                 HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(stream_wait(stream_));
                 times_.add("count_bucket_splits_x1", (double)(h[2] >> 32));
+                if (bloom) {
+                    // k-mers the filter took as new: each is one distinct k-mer (less the false positives) and one
+                    // instance that never reached a table.  Those that came back later sit in the tables (n_keys);
+                    // the rest were seen once: the histogram's first bin (SPEC S4/S5, Bloom mode: statistical)
+                    unsigned long long n_keys = 0;
+                    HIPCHK(hipMemcpy(&n_keys, ctl_.p + 9, 8, hipMemcpyDeviceToHost));
+                    const unsigned long long singles = bloom_new > n_keys ? bloom_new - n_keys : 0ull;
+                    hist_out[0] += singles;
+                    h[1] += bloom_new;
+                    for (uint32_t i = 0; i < n_ovf; i++) bloom_kmer_bytes_exact += ov[i].instances * 8ull * W;
+                    times_.add("bloom_new_kmers_x1e-6", (double)bloom_new * 1e-6);
+                    times_.add("bloom_singletons_never_stored_x1e-6", (double)singles * 1e-6);
+                    times_.add("bloom_kmer_instances_MB_written", (double)bloom_kmer_bytes / 1e6);
+                    times_.add("bloom_kmer_instances_MB_without_filter", (double)bloom_kmer_bytes_exact / 1e6);
+                }
             }
             if ((uint32_t)h[2]) { err = "partition too large for the LDS table even after 4096-way residue splitting"; return -6; }
             n_rows = h[0]; inst_out = h[1];
@@ -780,7 +817,12 @@ public:
             // stage inspection: run the counting pass again keeping every row
             if (!have_parts_ || (!recs_.p && batches_.empty())) { err = "partition buffers already released"; return -2; }
             uint64_t rows = 0, hist[500], inst = 0; double ms = 0;
-            if (int rc = run_count_partitions(run_view_, n_count_parts_, 0, dk, dc, rows, hist, inst, n_distinct_, ms, err)) return rc;
+            // (Bloom mode never stores its singletons: the inspection runs the exact counter and reports exact counts)
+            bloom_off_once_ = true;
+            const int rc = run_count_partitions(run_view_, n_count_parts_, 0, dk, dc, rows, hist, inst, n_distinct_, ms, err);
+            bloom_off_once_ = false;
+            if (rc) return rc;
+            if (bloom_) { if (cap < rows) { err = "buffer too small"; return -1; } return copy_out(dk, dc, rows, keys, counts, err); }
             if (rows != n_distinct_) { err = "distinct row count mismatch"; return -6; }
         }
         return copy_out(dk, dc, n_distinct_, keys, counts, err);
@@ -1178,6 +1220,7 @@ private:
     uint64_t histo_[500] = {0};
     // partitioned counting
     bool global_mode_ = env_u64("SHK_COUNT_MODE_GLOBAL", 0) != 0;
+    bool bloom_ = false, bloom_off_once_ = false;
     bool have_parts_ = false;
     PartParams pp_{};
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;

@@ -239,3 +239,52 @@ def test_circular_isolate_with_plasmid_full_size(torch_dev):
     print("linear", {a: round(b, 3) for a, b in tl.items()})
     print("assemble (device phases + writer, host clock) circular %.3f ms, linear %.3f ms, ratio %.3f" % (best_c, best_l, best_c / best_l))
     assert best_c <= 1.10 * best_l                         # within 10 % of the linear case
+
+
+def test_config2_bloom_mode_errors_left_in(torch_dev):
+    """configs[2] with the errors left in (132 M distinct 51-mers, most of them singletons) in Bloom mode: the same
+    contigs as the exact mode at min_count >= 3, counts never below the closed form, and the k-mer buffer of the
+    repartition measured with and without the filter."""
+    torch, dev = torch_dev
+    k = 51
+    n_reads = (G * COV + L - 1) // L
+    d = synth.device_reads(torch, dev, G, n_reads, L, k, 0xEC03, err=0.01, keep_meta=True)
+
+    def run_mode(bloom):
+        h = AssemblyHelper.new(k, True, 5, 20, 0, bloom, False, False, False)
+        h.preprocess_packed_device(d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads)
+        h.assemble()
+        return h
+    e, b = run_mode(False), run_mode(True)
+    te, tb = e.timings(), b.timings()
+    assert b.total_instances == e.total_instances == d.instances
+    assert sorted(contigs_of(b)) == sorted(contigs_of(e))
+    he, hb = e.histo().astype(np.int64), b.histo().astype(np.int64)
+    assert abs(int(hb.sum()) - int(he.sum())) <= 0.02 * he.sum()
+    assert b.n_solid >= e.n_solid and b.n_solid - e.n_solid <= 0.001 * e.n_solid
+    # exact counts of sampled genome k-mers: Bloom counts are the closed form or one more
+    keys, cnt = b.solid()
+    order = np.lexsort([keys[:, j] for j in range(keys.shape[1])])
+    sk, sc = keys[order], cnt[order]
+    gs = genome_str(d)
+    cs = torch.zeros((d.err_fwd.shape[0], L + 1), dtype=torch.int16, device=dev)
+    cs[:, 1:] = torch.cumsum(d.err_fwd.to(torch.int16), 1)
+    rng = np.random.default_rng(11)
+    n_plus = 0
+    for p in rng.integers(200, G - 200 - k, size=200).tolist():
+        sel = torch.nonzero((d.starts >= p + k - L) & (d.starts <= p)).flatten()
+        off = p - d.starts[sel]
+        expect = int(((cs[sel, off + k] - cs[sel, off]) == 0).sum().item())
+        w = canonical_words(gs[p:p + k], 2)
+        lo, hi = 0, len(sc)
+        for j in (1, 0):
+            col = sk[lo:hi, j]
+            a_, b_ = np.searchsorted(col, np.uint64(w[j]), "left"), np.searchsorted(col, np.uint64(w[j]), "right")
+            lo, hi = lo + a_, lo + b_
+        if expect > 5:
+            assert hi - lo == 1 and int(sc[lo]) in (expect, expect + 1), (p, int(sc[lo]) if hi > lo else None, expect)
+            n_plus += int(sc[lo]) == expect + 1
+    assert n_plus <= 100
+    print("configs[2] errors left in: exact count %.2f ms, bloom count %.2f ms; k-mer instances written to HBM %.0f MB with the filter, %.0f MB without; "
+          "%.1f M singletons never stored" % (te["count_kernel"], tb["count_kernel"], tb["bloom_kmer_instances_MB_written"],
+                                              tb["bloom_kmer_instances_MB_without_filter"], tb["bloom_singletons_never_stored_x1e-6"]))
