@@ -1,4 +1,7 @@
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+#!/bin/bash
+set -euo pipefail
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?}"
 mkdir -p gpurun_out/gap
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gap/prof -o s -- python bench.py --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/gap/prof.log 2>&1
 python tools/gap_report.py $(find gpurun_out/gap/prof -name "*kernel_trace.csv" | head -1)

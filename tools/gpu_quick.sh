@@ -1,6 +1,7 @@
 #!/bin/bash
 # quick GPU check: parity tests (optional) + one bench line.  Usage: bash tools/gpu_quick.sh <tag> [tests|notests] [bench args...]
-set -e
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?}"
 TAG=${1:-quick}; TESTS=${2:-tests}; shift; shift || true
 OUT=$PWD/gpurun_out/$TAG; mkdir -p "$OUT"
 if [ "$TESTS" = tests ]; then

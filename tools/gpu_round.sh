@@ -2,7 +2,8 @@
 # One GPU-box call: parity tests, bench line, rocprofv3 kernel stats, PMC passes (HBM bytes, SQ).
 # Usage (via gpurun): bash tools/gpu_round.sh <tag> [tests|notests]
 # Everything lands under gpurun_out/<tag>/; copy what should be judged into profiles/<tag>/.
-set -e
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?}"
 TAG=${1:-run}
 TESTS=${2:-tests}
 OUT=$PWD/gpurun_out/$TAG
