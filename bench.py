@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--mask-errors", action="store_true", help="erroneous bases carry a low quality and are masked "
                     "(min_qual): reads are cut into error-free segments before they reach the device entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed leg (packed reads in host pinned memory)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a one-GPU box together with --one-gpu)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -189,7 +190,7 @@ def main():
     # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
     # strings on the host; the upload rides in front of pass 1 on the library's stream
     host_leg = None
-    if world == 1 and args.err == 0:
+    if world == 1 and args.err == 0 and not args.no_host_leg:
         hw = torch.empty(d_bases.numel(), dtype=torch.int32).pin_memory()
         hs = torch.empty(d_seg.numel(), dtype=torch.int32).pin_memory()
         hw.copy_(d_bases); hs.copy_(d_seg)

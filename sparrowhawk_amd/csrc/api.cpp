@@ -631,6 +631,7 @@ static int assemble_impl(shk_handle *h) {
     rc = h->pipe->correct(!h->no_deadend, !h->no_bubble, err);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
     h->post("assembly:collapse_graph");
+    if (h->pipe->n_solid() >= (1u << 20)) writer_prewarm(3000);     // megabases of output in about a millisecond
     std::vector<RawContig> contigs;
     rc = h->pipe->collapse(contigs, err);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);

@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <memory>
@@ -132,6 +133,7 @@ public:
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = &f; n_tasks_ = n_tasks; next_ = 0; pending_ = n_tasks; failed_ = false; gen = ++gen_;
+            gen_atomic_.store(gen_, std::memory_order_release);
         }
         cv_.notify_all();
         work(gen);
@@ -172,11 +174,22 @@ private:
         }
     }
     void loop() {
-        uint64_t seen = 0;
+        uint64_t seen = 0, seen_warm = 0;
+        auto until = std::chrono::steady_clock::now();               // end of the current warm window
         for (;;) {
-            {
+            if (std::chrono::steady_clock::now() >= until) {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
+                cv_.wait(lk, [&] { return gen_ != seen || warm_gen_ != seen_warm; });
+                if (warm_gen_ != seen_warm) { seen_warm = warm_gen_; until = std::chrono::steady_clock::now() + std::chrono::microseconds(warm_us_.load()); }
+                if (gen_ == seen) continue;                          // woken to stay warm: spin below on the next turn
+                seen = gen_;
+            } else {
+                // a job is about to come, or another one of the same assembly (WorkPool::prewarm): stay awake for it
+                // instead of paying the wake-up latency of a sleeping thread (tens to hundreds of microseconds)
+                while (gen_atomic_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+                std::lock_guard<std::mutex> lk(mu_);
+                if (warm_gen_ != seen_warm) { seen_warm = warm_gen_; until = std::chrono::steady_clock::now() + std::chrono::microseconds(warm_us_.load()); }
+                if (gen_ == seen) continue;
                 seen = gen_;
             }
             work(seen);
@@ -189,7 +202,16 @@ private:
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_tasks_ = 0, pending_ = 0, next_ = 0;
     bool failed_ = false;
-    uint64_t gen_ = 0;
+    uint64_t gen_ = 0, warm_gen_ = 0;
+    std::atomic<uint64_t> gen_atomic_{0};
+    std::atomic<long> warm_us_{0};
+public:
+    // tells the workers that a job will arrive within about `us` microseconds: they wake up now and spin until then
+    void prewarm(long us) {
+        if (n_workers_ == 0) return;
+        { std::lock_guard<std::mutex> lk(mu_); warm_us_.store(us); warm_gen_++; }
+        cv_.notify_all();
+    }
 };
 
 std::string revcomp(const char *s, size_t n) {
@@ -208,6 +230,8 @@ template <typename F> void par_ranges(size_t n, size_t min_per_piece, F &&fn) {
     pool.run(pieces, [&](size_t t) { fn(n * t / pieces, n * (t + 1) / pieces); });
 }
 }  // namespace
+
+void writer_prewarm(long microseconds) { WorkPool::get().prewarm(microseconds); }
 
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out) {
     const char *pm = getenv("SHK_WRITER_PAR_MIN");          // (tests force the parallel paths on small outputs)

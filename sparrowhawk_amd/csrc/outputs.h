@@ -16,6 +16,9 @@ struct AssemblyText {
 };
 
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out);
+// the writer's worker threads will be needed within about this long: they wake up now (shk_assemble calls this when
+// the graph phases of a megabase assembly start, so that the copies of the contigs do not wait for sleeping threads)
+void writer_prewarm(long microseconds);
 std::string preprocessing_json(uint64_t nkmers, const uint64_t *histo500, uint32_t used_min_count);
 void json_escape_into(std::string &dst, const std::string &s);
 std::string take_big_string();

@@ -1144,7 +1144,8 @@ public:
         // (the list may have grown by the orphan cycles; grids cover the n_spl the host knows plus a margin, the
         // kernels loop to the device-side count)
         const int gr = grid_for((uint64_t)n_spl + 65536u);
-        int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)seg_cap) { reach *= RANK_HOPS; rounds++; } }
+        // (a chain has at most n_spl splitters: the ones k_orphan_cycles appends are chains of their own)
+        int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl + 1u) { reach *= RANK_HOPS; rounds++; } }
         EvTimer tr(stream_);
         HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
         hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ra.p);
