@@ -520,15 +520,14 @@ static int preprocess_packed_host_impl(shk_handle *h, const uint32_t *bases, con
     if (!db.p || !ds.p) return fail(h, SHK_E_OOM, "preprocess: device memory for the packed reads");
     const double t0 = now_ms();
     void *st = h->pipe->stream();
-    // (the stream orders the upload in front of pass 1: no host wait in between)
-    if (device_copy_h2d_async(db.p, bases, want_b, st, err) || device_copy_h2d_async(ds.p, seg_off, want_s, st, err)) {
-        (void)device_stream_sync(st, err);
-        return fail(h, SHK_E_DEVICE, err);
-    }
     h->post("preprocess:start"); h->post_mode("start"); h->post_loop_edge("loop:start");
     h->n_reads = n_reads;
     h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
-    const int rc = run_counting(h, (const uint32_t *)db.p, (const uint32_t *)ds.p, n_seg, n_bases);
+    // upload and pass 1 overlap piece by piece (Pipeline::count_batch_host), then histogram / fit / filter as usual
+    h->batches_started++;
+    int rc = h->pipe->count_batch_host((uint32_t *)db.p, (uint32_t *)ds.p, bases, seg_off, n_seg, n_bases, err);
+    if (rc) rc = fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
+    else rc = finish_counting(h);
     { std::string e2; (void)device_stream_sync(st, e2); }      // the blocks go back to the pool idle, also after a failure
     h->pipe->times().add("h2d_packed_reads_MB", (double)(want_b + want_s) / 1e6);
     h->pipe->times().add("preprocess_from_host_total_host_clock", now_ms() - t0);

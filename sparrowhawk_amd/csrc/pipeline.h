@@ -29,6 +29,9 @@ public:
     // counting (SPEC S4): may be called once per batch of packed segments
     virtual int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
                             uint64_t n_bases, std::string &err) = 0;
+    // the same batch with the packed reads still in host memory (h_*): uploaded into d_* piece by piece, overlapped with pass 1
+    virtual int count_batch_host(uint32_t *d_bases, uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
+                                 uint64_t n_seg, uint64_t n_bases, std::string &err) = 0;
     // more batches will follow the first one (chunked / streamed input of unknown size): partition for the worst case
     virtual void expect_more_batches() = 0;
     // do_bloom (docs/src/assembly.md:18): partitions that go through the k-mer-level repartition pass a Bloom

@@ -285,7 +285,11 @@ static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
 template <int W> class Pipeline : public IPipeline {
 public:
     explicit Pipeline(int k) : k_(k) {}
-    ~Pipeline() override { EvTimer::resolve(pending_timers_, times_); if (stream_) stream_pool_put(stream_dev_, stream_); }
+    ~Pipeline() override {
+        EvTimer::resolve(pending_timers_, times_);
+        if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+        if (stream_) stream_pool_put(stream_dev_, stream_);
+    }
     int init(std::string &err) {
         HIPCHK(hipGetDevice(&stream_dev_));
         { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, stream_dev_); n_cus_ = cus > 0 ? cus : 256; }
@@ -365,6 +369,21 @@ public:
 
     int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg, uint64_t n_bases,
                     std::string &err) override {
+        return count_batch_impl(d_bases, d_seg_off, nullptr, nullptr, n_seg, n_bases, err);
+    }
+    // the packed reads are still in HOST memory: they are uploaded in a few pieces on a second stream, and pass 1 of
+    // piece i runs while piece i+1 travels (the pieces append to the same slices: k_partition continues its cursors)
+    int count_batch_host(uint32_t *d_bases, uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
+                         uint64_t n_seg, uint64_t n_bases, std::string &err) override {
+        return count_batch_impl(d_bases, d_seg_off, h_bases, h_seg_off, n_seg, n_bases, err);
+    }
+    int count_batch_impl(const uint32_t *d_bases, const uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
+                         uint64_t n_seg, uint64_t n_bases, std::string &err) {
+        if (h_bases && (global_mode_ || n_seg == 0)) {            // (nothing to overlap: plain upload first)
+            HIPCHK(hipMemcpyAsync((void *)d_bases, h_bases, ((n_bases + 15) / 16 + 1) * 4, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync((void *)d_seg_off, h_seg_off, (n_seg + 1) * 4, hipMemcpyHostToDevice, stream_));
+            h_bases = nullptr;
+        }
         if (global_mode_) return count_batch_global(d_bases, d_seg_off, n_seg, n_bases, err);
         if (n_seg >= 0xFFFFFFFFull || n_bases >= 0xFFFFFFFFull) { err = "batch too large (>= 2^32 bases)"; return -1; }
         if (n_seg == 0) return 0;
@@ -406,6 +425,43 @@ public:
             HIPCHK(hipMemsetAsync(fill_.p, 0, n_slices * 4, stream_));
             HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
             EvTimer t(stream_);
+            if (h_bases && attempt == 0) {
+                // ---- upload and pass 1, piece by piece
+                uint64_t C = env_u64("SHK_H2D_PIECES", 4);
+                if (C < 1) C = 1;
+                while (C > 1 && n_seg / C < (uint64_t)PART_THREADS * pp_.G) C--;          // every piece fills the chip
+                if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+                const uint64_t n_words = (n_bases + 15) / 16 + 1;
+                std::vector<hipEvent_t> evs((size_t)C, nullptr);
+                struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto e : v) if (e) (void)hipEventDestroy(e); } } evg{evs};
+                for (uint64_t c = 0; c < C; c++) {
+                    const uint64_t s0 = n_seg * c / C, s1 = n_seg * (c + 1) / C;
+                    const uint64_t w0 = h_seg_off[s0] >> 4, w1 = std::min<uint64_t>(n_words, (((uint64_t)h_seg_off[s1] + 15) >> 4) + 1);
+                    HIPCHK(hipMemcpyAsync((void *)(d_seg_off + s0), h_seg_off + s0, (s1 - s0 + 1) * 4, hipMemcpyHostToDevice, copy_stream_));
+                    HIPCHK(hipMemcpyAsync((void *)(d_bases + w0), h_bases + w0, (w1 - w0) * 4, hipMemcpyHostToDevice, copy_stream_));
+                    HIPCHK(hipEventCreateWithFlags(&evs[c], hipEventDisableTiming));
+                    HIPCHK(hipEventRecord(evs[c], copy_stream_));
+                    HIPCHK(hipStreamWaitEvent(stream_, evs[c], 0));
+                    if (wblk == 16) launch_partition<16>(d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
+                    else launch_partition<8>(d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
+                }
+                HIPCHK(hipGetLastError());
+                t.mark();
+                unsigned long long h[2];
+                HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(stream_wait(stream_));
+                times_.add("h2d_pieces_x1", (double)C);
+                const uint32_t *fl = (const uint32_t *)&h[0];
+                if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
+                if ((uint32_t)h[1] <= cap) {
+                    times_.add("partition_with_upload", t.elapsed());
+                    if (int rc = finish_partition(n_slices, err)) return rc;
+                    return 0;
+                }
+                times_.add("partition_retry", t.elapsed());
+                cap = (uint64_t)(uint32_t)h[1] + 8;               // (the reads are on the device now: the retry is one launch)
+                continue;
+            }
             if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
             else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
             HIPCHK(hipGetLastError());
@@ -419,15 +475,7 @@ public:
             const uint32_t max_fill = (uint32_t)h[1];
             if (max_fill <= cap) {
                 times_.add("partition_kernel", ms);
-                have_parts_ = true;
-                // run table of the local layout: one run per (partition, producer workgroup)
-                if (int rc = run_off_.alloc(n_slices, err)) return rc;
-                if (int rc = run_cnt_.alloc(n_slices, err)) return rc;
-                hipLaunchKernelGGL(k_make_runs, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, pp_, recs_.p,
-                                   (uint32_t)RW, run_off_.p, run_cnt_.p);
-                HIPCHK(hipGetLastError());
-                run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
-                run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = env_dbg("SHK_DEBUG_P2");
+                if (int rc = finish_partition(n_slices, err)) return rc;
                 return 0;
             }
             times_.add("partition_retry", ms);
@@ -435,6 +483,20 @@ public:
         }
         err = "partition slices overflowed twice";
         return -6;
+    }
+
+    // pass 1 is done: run table of the local layout, one run per (partition, producer workgroup)
+    int finish_partition(uint64_t n_slices, std::string &err) {
+        constexpr int RW = 2 * W;
+        have_parts_ = true;
+        if (int rc = run_off_.alloc(n_slices, err)) return rc;
+        if (int rc = run_cnt_.alloc(n_slices, err)) return rc;
+        hipLaunchKernelGGL(k_make_runs, dim3(grid_for(n_slices)), dim3(256), 0, stream_, fill_.p, pp_, recs_.p,
+                           (uint32_t)RW, run_off_.p, run_cnt_.p);
+        HIPCHK(hipGetLastError());
+        run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
+        run_view_.S = pp_.G; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = env_dbg("SHK_DEBUG_P2");
+        return 0;
     }
 
     // ---- batches ---------------------------------------------------------------------------------
@@ -1209,6 +1271,7 @@ public:
 private:
     int k_;
     hipStream_t stream_ = nullptr; int stream_dev_ = 0;
+    hipStream_t copy_stream_ = nullptr;              // uploads that overlap pass 1 (count_batch_host)
     StageTimes times_;
     std::vector<EvTimer::Pending> pending_timers_;
     int n_cus_ = 256;
