@@ -186,7 +186,8 @@ private:
             } else {
                 // a job is about to come, or another one of the same assembly (WorkPool::prewarm): stay awake for it
                 // instead of paying the wake-up latency of a sleeping thread (tens to hundreds of microseconds)
-                while (gen_atomic_.load(std::memory_order_acquire) == seen && std::chrono::steady_clock::now() < until) std::this_thread::yield();
+                while (gen_atomic_.load(std::memory_order_acquire) == seen && warm_atomic_.load(std::memory_order_acquire) == seen_warm &&
+                       std::chrono::steady_clock::now() < until) std::this_thread::yield();
                 std::lock_guard<std::mutex> lk(mu_);
                 if (warm_gen_ != seen_warm) { seen_warm = warm_gen_; until = std::chrono::steady_clock::now() + std::chrono::microseconds(warm_us_.load()); }
                 if (gen_ == seen) continue;
@@ -203,13 +204,13 @@ private:
     size_t n_tasks_ = 0, pending_ = 0, next_ = 0;
     bool failed_ = false;
     uint64_t gen_ = 0, warm_gen_ = 0;
-    std::atomic<uint64_t> gen_atomic_{0};
+    std::atomic<uint64_t> gen_atomic_{0}, warm_atomic_{0};
     std::atomic<long> warm_us_{0};
 public:
     // tells the workers that a job will arrive within about `us` microseconds: they wake up now and spin until then
     void prewarm(long us) {
         if (n_workers_ == 0) return;
-        { std::lock_guard<std::mutex> lk(mu_); warm_us_.store(us); warm_gen_++; }
+        { std::lock_guard<std::mutex> lk(mu_); warm_us_.store(us); warm_gen_++; warm_atomic_.store(warm_gen_, std::memory_order_release); }
         cv_.notify_all();
     }
 };
@@ -526,6 +527,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
                 copies.push_back(Copy{d.second.first + o, d.first + o, std::min(piece, d.second.second - o)});
         WorkPool::get().run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
     }
+    WorkPool::get().prewarm(0);                         // the writer is done: the workers go back to sleep
     js.resize(total);
     out.json = std::move(js);
     out.fasta.clear(); out.gfa1.clear(); out.gfa2.clear(); out.dot.clear();

@@ -1227,14 +1227,20 @@ public:
                            winfo.p, ol.p, fin.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
         HIPCHK(hipGetLastError());
         unsigned long long hc[4];
+        // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
+        // round trip just for them is 30-40 us of idle GPU)
+        constexpr unsigned int HEADS_SPEC = 512;
+        std::vector<HeadRec> heads(HEADS_SPEC);
         HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(heads.data(), d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
         HIPCHK(stream_wait(stream_));
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
         times_.add("collapse_rank_device", tr.stop());
-        std::vector<HeadRec> heads(n_heads);
-        if (n_heads) HIPCHK(hipMemcpy(heads.data(), d_heads.p, (size_t)n_heads * sizeof(HeadRec), hipMemcpyDeviceToHost));
+        heads.resize(n_heads);
+        if (n_heads > HEADS_SPEC)
+            HIPCHK(hipMemcpy(heads.data() + HEADS_SPEC, d_heads.p + HEADS_SPEC, (size_t)(n_heads - HEADS_SPEC) * sizeof(HeadRec), hipMemcpyDeviceToHost));
         // each unitig exists on both strands: keep the canonical one (decided on the device)
         std::vector<EmitRec> head_off(heads.size());
         std::vector<uint32_t> emitted;

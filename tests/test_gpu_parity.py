@@ -687,3 +687,30 @@ def test_bloom_mode_overcounts_by_at_most_one_and_never_undercounts(k, mode):
     assert len(ch ^ ce) <= 6 * slipped + 2, (len(ch ^ ce), slipped)
     if mode == "rescatter":
         assert t.get("count_repartitioned_x1", 0) > 0
+
+
+def test_a_failure_after_counted_batches_poisons_the_handle():
+    """A malformed record in a later chunk arrives after earlier batches went into the tables: the handle must not
+    accept a second attempt (it would double-count them); every later call reports SHK_E_STATE until shk_free.
+    A failure before anything was counted leaves the handle usable."""
+    g, fq = make_dataset(20000, 20, seed=77)
+    recs = fq.decode().split("@r")[1:]
+    good = ("@r" + "@r".join(recs[:600])).encode()
+    h = AssemblyHelper.new(31, True, 2, 20, 100, False, False, False, False)        # chunked: a batch every 100 reads
+    h.push_reads(good)
+    with pytest.raises(ShkError) as e:
+        h.push_reads(b"@bad\nACGT\n+\nII\n")                                        # sequence / quality lengths differ
+    assert e.value.code == -3
+    for call in (lambda: h.push_reads(good), h.finish_reads, h.assemble):
+        with pytest.raises(ShkError) as e2:
+            call()
+        assert e2.value.code == -2 and "failed earlier" in str(e2.value)
+    h.free()
+    # nothing counted yet: the same parse error leaves the handle fresh
+    h = AssemblyHelper.new(31, True, 2, 20, 0, False, False, False, False)
+    with pytest.raises(ShkError) as e:
+        h.preprocess(b"@bad\nACGT\n+\nII\n")
+    assert e.value.code == -3
+    h.preprocess(fq)
+    h.assemble()
+    compare_all(h, run_oracle([fq], k=31, min_count=2))
