@@ -47,10 +47,13 @@ template <int W>
 __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *__restrict__ alive,
                                                     uint2 *__restrict__ winfo, uint32_t *__restrict__ spl,
                                                     uint2 *__restrict__ ol, unsigned int *__restrict__ n_spl,
-                                                    uint32_t split_mask) {
+                                                    uint32_t split_mask, unsigned long long *__restrict__ n_alive /* += alive oriented nodes */) {
     __shared__ uint32_t wtot[SS_ITEMS * 4];
     __shared__ uint32_t woff[SS_ITEMS * 4];
-    __shared__ uint32_t blk_base;
+    __shared__ uint32_t blk_base, blk_alive;
+    if (threadIdx.x == 0) blk_alive = 0;
+    __syncthreads();
+    uint32_t my_alive = 0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const uint32_t total = g.n * 2;
     const uint32_t base = blockIdx.x * (256u * SS_ITEMS);          // even: v and v^1 sit in adjacent lanes
@@ -70,13 +73,17 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
             }
             uint2 w; w.x = s; w.y = c; winfo[v] = w;
         }
+        my_alive += al ? 1u : 0u;
         const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node
         const bool p = al && (sp == NIL || node_sampled(v, split_mask));   // head or sampled
         const unsigned long long m = __ballot(p);
         if (lane == 0) wtot[it * 4 + wid] = (uint32_t)__popcll(m);
         pbits |= (p ? 1u : 0u) << it;
     }
+    for (int o = 32; o > 0; o >>= 1) my_alive += __shfl_down(my_alive, o);
+    if (lane == 0 && my_alive) atomicAdd(&blk_alive, my_alive);
     __syncthreads();
+    if (threadIdx.x == 0 && blk_alive) atomicAdd(n_alive, (unsigned long long)blk_alive);
     if (threadIdx.x < 64) {                                        // exclusive scan of the 64 wave totals
         const uint32_t t = threadIdx.x < SS_ITEMS * 4 ? wtot[threadIdx.x] : 0u;
         uint32_t incl = t;
@@ -109,7 +116,8 @@ template <int W>
 __global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__ winfo,
                                                        const uint32_t *__restrict__ spl, uint32_t n_spl,
                                                        uint2 *__restrict__ ol, SegRec *__restrict__ segs,
-                                                       uint32_t split_mask) {
+                                                       uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */) {
+    unsigned long long my_cov = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
         uint32_t cur = s, len = 0, nxt;
@@ -127,7 +135,10 @@ __global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__
         r.next_spl = (nxt == NIL) ? NIL : ol[nxt].x;       // splitters got their owner in k_succ_split
         r.head = winfo[s ^ 1u].x == NIL ? HEAD_LINEAR : 0u;
         segs[i] = r;
+        my_cov += len;
     }
+    for (int o = 32; o > 0; o >>= 1) my_cov += __shfl_down(my_cov, o);
+    if ((threadIdx.x & 63) == 0 && my_cov) atomicAdd(n_covered, my_cov);
 }
 
 // A circular unitig that holds no sampled node (short ones: the chance is (31/32)^n) is owned by no walker: its
@@ -140,7 +151,10 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
                                                        const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
                                                        uint32_t *__restrict__ spl, SegRec *__restrict__ segs,
                                                        unsigned int *__restrict__ n_spl,
-                                                       uint32_t seg_cap, uint32_t *__restrict__ flags) {
+                                                       uint32_t seg_cap, uint32_t *__restrict__ flags,
+                                                       const unsigned long long *__restrict__ n_alive,
+                                                       const unsigned long long *__restrict__ n_covered) {
+    if (*n_alive == *n_covered) return;                    // every alive node has an owner: no such ring (the usual case)
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1] || ol[v].x != NIL) continue;

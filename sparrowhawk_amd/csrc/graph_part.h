@@ -172,30 +172,40 @@ __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, in
 __global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ gp_cnt, uint32_t GP,
                                                   unsigned long long *__restrict__ off, uint32_t *__restrict__ msk,
                                                   uint32_t *__restrict__ roff, unsigned long long *__restrict__ total) {
-    // tiles of 1024 partitions, one per thread (coalesced), block scan per tile with a running carry
+    // one pass: every thread owns a run of consecutive partitions (GP / 1024 of them, <= 128), sums them, the 1024
+    // thread sums are scanned across the block, then the thread writes its run (the tiled version took 16 tiles
+    // of two barriers each for GP = 16384: 38 us of one workgroup's latency on the critical path)
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t rsum[16];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned long long carry = 0; uint32_t rcarry = 0;
-    for (uint32_t p0 = 0; p0 < GP; p0 += 1024) {
-        const uint32_t p = p0 + threadIdx.x;
-        const uint32_t c = p < GP ? gp_cnt[p] : 0u;
-        uint32_t sz = 0;
-        if (p < GP) { sz = 8; const uint32_t want = 2u * c; while (sz < want) sz <<= 1; msk[p] = sz - 1u; }
-        unsigned long long incl = sz; uint32_t rincl = c;
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned long long u = __shfl_up(incl, o); const uint32_t ru = (uint32_t)__shfl_up((int)rincl, o);
-            if (lane >= o) { incl += u; rincl += ru; }
-        }
-        if (lane == 63) { wsum[wid] = incl; rsum[wid] = rincl; }
-        __syncthreads();
-        unsigned long long base = carry; uint32_t rbase = rcarry;
-        for (int w = 0; w < wid; w++) { base += wsum[w]; rbase += rsum[w]; }
-        if (p < GP) { off[p] = base + incl - sz; roff[p] = rbase + rincl - c; }
-        for (int w = 0; w < 16; w++) { carry += wsum[w]; rcarry += rsum[w]; }
-        __syncthreads();                                   // wsum / rsum are rewritten by the next tile
+    const uint32_t per = (GP + 1023u) / 1024u;
+    const uint32_t p0 = threadIdx.x * per, p1 = min(GP, p0 + per);
+    unsigned long long my = 0; uint32_t myr = 0;
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t c = gp_cnt[p];
+        uint32_t sz = 8; const uint32_t want = 2u * c; while (sz < want) sz <<= 1;
+        my += sz; myr += c;
     }
-    if (threadIdx.x == 0) { *total = carry; roff[GP] = rcarry; }
+    unsigned long long incl = my; uint32_t rincl = myr;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(incl, o); const uint32_t ru = (uint32_t)__shfl_up((int)rincl, o);
+        if (lane >= o) { incl += u; rincl += ru; }
+    }
+    if (lane == 63) { wsum[wid] = incl; rsum[wid] = rincl; }
+    __syncthreads();
+    unsigned long long base = incl - my; uint32_t rbase = rincl - myr;
+    for (int w = 0; w < wid; w++) { base += wsum[w]; rbase += rsum[w]; }
+    for (uint32_t p = p0; p < p1; p++) {
+        const uint32_t c = gp_cnt[p];
+        uint32_t sz = 8; const uint32_t want = 2u * c; while (sz < want) sz <<= 1;
+        off[p] = base; msk[p] = sz - 1u; roff[p] = rbase;
+        base += sz; rbase += c;
+    }
+    if (threadIdx.x == 1023) {
+        unsigned long long t = 0; uint32_t rt = 0;
+        for (int w = 0; w < 16; w++) { t += wsum[w]; rt += rsum[w]; }
+        *total = t; roff[GP] = rt;
+    }
 }
 
 // row list per graph partition: rows[roff[p] .. roff[p+1]) (order inside a partition is arbitrary)

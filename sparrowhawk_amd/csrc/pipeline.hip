@@ -1169,11 +1169,11 @@ public:
         if (int rc = winfo.alloc(total, err)) return rc;
         if (int rc = spl.alloc(total, err)) return rc;
         if (int rc = ol.alloc(total, err)) return rc;
-        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 4 * 8, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 .. 8 as above, 9 = alive oriented nodes, 10 = nodes walked
         const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
-                           alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask);
+                           alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1187,10 +1187,10 @@ public:
             EvTimer t2(stream_);
             if (n_spl) {
                 hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
-                                   spl.p, n_spl, ol.p, segs.p, split_mask);
+                                   spl.p, n_spl, ol.p, segs.p, split_mask, ctl_.p + 10);
             }
             hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
-                               spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8));
+                               spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
             HIPCHK(hipGetLastError());
             t2.stop_later("collapse_walk", pending_timers_);
         }
