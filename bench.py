@@ -103,6 +103,8 @@ def main():
                          "holds an equal share of its reads, k-mer space partitioned across ranks with one RCCL "
                          "pairwise exchange inside libshk_hip.so (shk_shard_preprocess); 'isolates' = every rank "
                          "assembles its own isolate (independent objects, no data-path collective) — the comparison point")
+    ap.add_argument("--force-sharded", action="store_true", help="N=1: run the sharded path with a one-rank RCCL communicator "
+                    "(what the exchange machinery costs when nothing has to leave the GPU)")
     ap.add_argument("--collectives", choices=["lib", "torch"], default="lib",
                     help="sharded mode: 'lib' = RCCL inside the library (production); 'torch' = the same shk_shard_* "
                          "pieces driven by torch.distributed collectives (rehearsal with --backend gloo --one-gpu)")
@@ -133,7 +135,7 @@ def main():
     L = _lib.load()
     raw_get_assembly = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)(("shk_get_assembly", L))
 
-    sharded = world > 1 and args.mode == "sharded"
+    sharded = (world > 1 or args.force_sharded) and args.mode == "sharded"
     if sharded:
         # one pooled sample: N isolates, every rank holds an equal share of reads drawn from all of them
         from sparrowhawk_amd.dist import Comm, LibComm, sharded_preprocess, sharded_preprocess_rccl
@@ -190,7 +192,7 @@ def main():
     # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
     # strings on the host; the upload rides in front of pass 1 on the library's stream
     host_leg = None
-    if world == 1 and args.err == 0 and not args.no_host_leg:
+    if world == 1 and args.err == 0 and not args.no_host_leg and not sharded:
         hw = torch.empty(d_bases.numel(), dtype=torch.int32).pin_memory()
         hs = torch.empty(d_seg.numel(), dtype=torch.int32).pin_memory()
         hw.copy_(d_bases); hs.copy_(d_seg)
