@@ -293,6 +293,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, d_bases.cpu().numpy().view("uint32"),
                                                 d_seg.cpu().numpy().view("uint32"), n_bases, res["outfasta"])
         print(json.dumps(line), flush=True)
+    if sharded and hasattr(comm, "free"):
+        comm.free()                                      # the library's RCCL communicator goes before torch's group
     if world > 1:
         dist.destroy_process_group()
 
