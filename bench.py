@@ -136,10 +136,32 @@ def main():
     raw_get_assembly = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p)(("shk_get_assembly", L))
 
     sharded = (world > 1 or args.force_sharded) and args.mode == "sharded"
+    lib_error = None
     if sharded:
         # one pooled sample: N isolates, every rank holds an equal share of reads drawn from all of them
         from sparrowhawk_amd.dist import Comm, LibComm, sharded_preprocess, sharded_preprocess_rccl
-        comm = Comm(device=dev) if args.collectives == "torch" else LibComm(rank, world)
+        comm, lib_error = None, None
+        if args.collectives == "lib":
+            try:
+                comm = LibComm(rank, world)
+            except Exception as e:                       # (e.g. an RCCL that refuses the topology)
+                lib_error = repr(e)
+            if world > 1:
+                # every rank must take the same path: agree on whether ALL communicators came up
+                flag = torch.tensor([0 if comm is not None else 1], device=dev if args.backend == "nccl" else "cpu")
+                dist.all_reduce(flag)
+                if int(flag.item()) and comm is not None:
+                    comm.free(); comm = None
+                    lib_error = "another rank could not create the library's communicator"
+            if comm is None:
+                # LOUD second path, recorded in the JSON line: the same shk_shard_* pieces, collectives by torch.distributed
+                print(f"[bench rank {rank}] libshk's RCCL communicator failed ({lib_error}); collectives by torch.distributed",
+                      file=sys.stderr, flush=True)
+                if world == 1:
+                    raise SystemExit("the library's RCCL communicator could not be created: " + str(lib_error))
+                args.collectives = "torch"
+        if comm is None:
+            comm = Comm(device=dev)
         d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
             torch, dev, args.genome * world, args.coverage, args.read_len, 0xEC02, read_seed=0x5EED + rank,
             n_reads=(args.genome * args.coverage + args.read_len - 1) // args.read_len)
@@ -265,7 +287,8 @@ def main():
                    "parallelism": ("single GPU" if world == 1 else
                                    ("one pooled sample, k-mer space sharded by minimiser partition, one RCCL pairwise exchange "
                                     "inside the library (shk_shard_preprocess), graph phases replicated" if args.collectives == "lib"
-                                    else "one pooled sample, sharded, collectives by torch.distributed (" + args.backend + ")")
+                                    else "one pooled sample, sharded, collectives by torch.distributed (" + args.backend + ")" +
+                                         ("" if not lib_error else " — SECOND PATH: the library's RCCL communicator failed: " + str(lib_error)))
                                    if sharded else "one isolate per rank (batch of isolates), no data-path collective"),
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,

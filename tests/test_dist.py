@@ -170,3 +170,48 @@ def test_rccl_inside_the_library_two_ranks():
     o.assemble()
     assert res[0]["asm"] == res[1]["asm"] == o.assembly_json()
     assert res[0]["pre"] == res[1]["pre"] == o.preprocessing_json()
+
+
+@pytest.mark.gpu
+def test_torch_nccl_collectives_branch_world_1():
+    """The rehearsal layer's nccl branch (dist.Comm with a non-staged backend: device tensors straight into
+    all_to_all_single / all_gather_into_tensor, library-owned rows wrapped by _ptr_tensor) with a one-rank nccl
+    (= RCCL) process group — in a child process, so that the test runner itself never joins a process group."""
+    code = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["SHK_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SHK_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29741")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+from sparrowhawk_amd import AssemblyHelper, pack_fastq
+from sparrowhawk_amd.dist import Comm, sharded_preprocess
+from util import make_dataset, run_oracle
+g, fq = make_dataset(40000, 40, err=0.01, seed=4242)
+comm = Comm(device=dev)
+assert not comm.staged
+out = {}
+for k, fit in ((31, False), (51, True)):
+    bases, seg, nb, nr = pack_fastq(fq, k, 20)
+    d_bases = torch.from_numpy(bases.view(np.int32)).to(dev); d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+    h = AssemblyHelper.new(k, True, 3, 20, 0, False, fit, False, False)
+    sharded_preprocess(h, d_bases, d_seg, len(seg) - 1, nb, nr, comm)
+    h.assemble()
+    o = run_oracle([fq], k=k, min_count=3, min_qual=20, do_fit=fit); o.assemble()
+    out[str(k)] = bool(h.get_assembly() == o.assembly_json() and h.get_preprocessing_info() == o.preprocessing_json())
+dist.destroy_process_group()
+print("RESULT " + json.dumps(out))
+'''
+    env = dict(os.environ, SHK_ROOT=ROOT, OMP_NUM_THREADS="1")
+    pr = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env,
+                          start_new_session=True)
+    try:
+        out, errs = pr.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(pr.pid, signal.SIGKILL)
+        out, errs = pr.communicate()
+        raise AssertionError("timed out\n" + errs[-2000:])
+    assert pr.returncode == 0, out[-2000:] + errs[-3000:]
+    res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res == {"31": True, "51": True}
