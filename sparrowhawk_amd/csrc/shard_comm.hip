@@ -7,6 +7,7 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <mutex>
+#include <stdlib.h>
 #include <string.h>
 
 #include "shard_comm.h"
@@ -39,10 +40,17 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        // by soname first: a copy that is already mapped (torch ships one) is shared, not doubled
+        // by soname first: a copy that is already mapped (torch ships one) is shared, not doubled.
+        // SHK_RCCL_LIBRARY names another library with the same entry points (a site's own RCCL build; the tests'
+        // shared-memory stand-in, tests/mock_rccl, which lets several ranks share the one GPU of a test box)
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         void *h = nullptr;
-        for (const char *n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        const char *over = getenv("SHK_RCCL_LIBRARY");
+        if (over && *over) {
+            h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+            if (!h) { r.why = std::string("SHK_RCCL_LIBRARY: ") + (dlerror() ? dlerror() : "cannot be loaded"); return; }
+        }
+        for (const char *n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
         if (!h) { r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
         auto sym = [&](const char *n) -> void * { void *p = dlsym(h, n); if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");

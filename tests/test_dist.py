@@ -215,3 +215,46 @@ print("RESULT " + json.dumps(out))
     assert pr.returncode == 0, out[-2000:] + errs[-3000:]
     res = json.loads([l for l in out.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res == {"31": True, "51": True}
+
+
+MOCK_DIR = os.path.join(ROOT, "tests", "mock_rccl")
+
+
+def mock_rccl_library():
+    """tests/mock_rccl/libmockrccl.so: the RCCL entry points over POSIX shared memory (built on demand)."""
+    so, src = os.path.join(MOCK_DIR, "libmockrccl.so"), os.path.join(MOCK_DIR, "mock_rccl.cpp")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-x", "hip",
+                               src, "-o", so, "-lrt", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return so
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,k,do_fit,P", [(2, 31, False, 0), (3, 51, True, 64), (4, 31, False, 128)])
+def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P):
+    """shk_shard_preprocess with 2, 3 and 4 ranks on the one GPU: the library's own multi-rank code (size exchange,
+    plan, pack, the pairwise exchange with its offsets, histogram all-reduce, gather of the solid rows) runs exactly
+    as on a node, only the bytes travel through tests/mock_rccl instead of RCCL (which refuses two ranks on one
+    device).  Every rank must end with the oracle's bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset, run_oracle
+    g, fq = make_dataset(60000, 40, err=0.01, seed=900 + world)
+    os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fqp = os.path.join(d, "reads.fq")
+            open(fqp, "wb").write(fq)
+            cfgp = os.path.join(d, "cfg.json")
+            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P}, open(cfgp, "w"))
+            out = os.path.join(d, "res")
+            launch(world, ["rccl", out, cfgp], 29760 + world, timeout=300)
+            res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    finally:
+        os.environ.pop("SHK_RCCL_LIBRARY", None)
+    assert not any("skipped" in r for r in res), res
+    o = run_oracle([fq], k=k, min_count=3, min_qual=20, do_fit=do_fit)
+    o.assemble()
+    for r in res:
+        assert r["pre"] == o.preprocessing_json() and r["asm"] == o.assembly_json()
+        assert r["total_instances"] == o.total_instances
+        assert r["timings"]["shard_exchange_sent_MB"] > 0
