@@ -211,6 +211,30 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     out, _, _ = one_step(keep=True)                      # untimed: fetch the result for checking
+    # ---- comparison point (N > 1, sharded): the same ranks, every one assembling an isolate of its own — independent
+    # objects, no data-path collective.  Timed the same way, reported beside `value`, never as it.
+    iso_leg = None
+    if sharded and world > 1 and args.err == 0:
+        ib, iseg, inr, inb, _g = make_reads_on_device(torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
+
+        def iso_step():
+            h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+            h.preprocess_packed_device(ib.data_ptr(), iseg.data_ptr(), inr, inb, inr)
+            h.assemble()
+            assert raw_get_assembly(h._h)
+            h.free()
+        for _ in range(max(1, args.warmup)):
+            iso_step()
+        barrier()
+        ti = time.perf_counter()
+        for _ in range(args.steps):
+            iso_step()
+        barrier()
+        iso_dt = time.perf_counter() - ti
+        tt = torch.tensor([iso_dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        iso_leg = float(tt.item()) / args.steps
+        del ib, iseg
     # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
     # strings on the host; the upload rides in front of pass 1 on the library's stream
     host_leg = None
@@ -306,6 +330,11 @@ def main():
                      "note": "integer/hash path bound by instruction issue and LDS round trips, not by HBM: see DESIGN.md section 4"},
         "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
     }
+    if iso_leg is not None:
+        line["value_isolates_mode"] = n_bases * world / iso_leg / 1e9
+        line["ms_per_step_isolates_mode"] = iso_leg * 1e3
+        line["isolates_mode_note"] = ("comparison point: every rank assembles an isolate of its own (no data-path collective); "
+                                      "`value` is the sharded path, whose graph phases are replicated on every rank (DESIGN.md section 6)")
     if host_leg is not None:
         line["value_host_pinned"] = n_bases / host_leg / 1e9
         line["ms_per_step_host_pinned"] = host_leg * 1e3
