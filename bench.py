@@ -338,8 +338,9 @@ def main():
     if host_leg is not None:
         line["value_host_pinned"] = n_bases / host_leg / 1e9
         line["ms_per_step_host_pinned"] = host_leg * 1e3
-        line["host_pinned_note"] = ("packed reads in host pinned memory -> contigs on host (SURVEY.md 8d clock): one "
-                                    "hipMemcpyAsync of %.0f MB in front of pass 1, not yet overlapped with it" % ((d_bases.numel() + d_seg.numel()) * 4 / 1e6))
+        line["host_pinned_note"] = ("packed reads in host pinned memory -> contigs on host (SURVEY.md 8d clock): %.0f MB uploaded in "
+                                    "pieces on a copy stream, pass 1 of a piece under the upload of the next (shk_preprocess_packed_host)"
+                                    % ((d_bases.numel() + d_seg.numel()) * 4 / 1e6))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and args.k <= 63:
             line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, d_bases.cpu().numpy().view("uint32"),
