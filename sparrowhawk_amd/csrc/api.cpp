@@ -753,6 +753,9 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     for (uint32_t r = 0; r < world; r++) { n_send += plan.send_counts[r]; n_recv += plan.recv_counts[r]; }
     // ---- pack (destination-major) and exchange
     struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, gk[4], gc;
+    // (declared after the blocks, so it runs before they go back to the pool: on every way out — errors included —
+    // the stream is drained first; the pool has no stream-ordering bookkeeping)
+    struct DrainOnExit { void *st; ~DrainOnExit() { std::string e; (void)device_stream_sync(st, e); } } drain{st};
     send.bytes = (size_t)(n_send * rec_bytes + 64); send.p = device_pool_alloc(send.bytes);
     recv.bytes = (size_t)(n_recv * rec_bytes + 64); recv.p = device_pool_alloc(recv.bytes);
     if (!send.p || !recv.p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
