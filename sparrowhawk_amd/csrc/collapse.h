@@ -41,6 +41,38 @@ template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g
     return a < b;
 }
 
+// ---- fragments: the part of the walk that stays inside a tile of node ids is done in LDS ---------------------------
+// The solid rows arrive grouped by minimiser partition, and ~90 % of the simple links join two k-mers of one
+// partition (neighbouring k-mers share their minimiser), so most successors of a node sit within a few thousand
+// ids of it.  k_local_frag works on tiles of LF_TILE oriented nodes: winfo of the tile is read once (coalesced),
+// the successors go to LDS, and every FRAGMENT HEAD — a splitter, or a node whose predecessor lies outside the
+// tile — walks its fragment there (until the chain ends, leaves the tile or reaches a splitter).  To HBM go
+//   ol[v]   = {head of v's fragment, position in the fragment}       (coalesced)
+//   frag[h] = {next node after the fragment, nodes, last node, sum of counts, owner splitter, nodes before it in the
+//              owner's segment}                                       (one 32-byte record per fragment head)
+// and the walkers of k_walk_frags hop from fragment to fragment (one random 32-byte read and one 8-byte write per
+// fragment instead of one of each per node).  After the ranking k_tile_final turns ol[v] into {chain record,
+// position in the chain}: the per-fragment lookups (owner -> chain, offsets) are done once per fragment head and
+// handed to the fragment's nodes through LDS, and the kernels behind it (rings, emission) read ol alone.
+// Correct for any row order — a tile that holds no neighbours just makes one-node fragments — fast for the order
+// the counting pass produces.
+struct FragRec { uint32_t next, len, last, pad; unsigned long long sum; uint32_t owner, base; };
+static_assert(sizeof(FragRec) == 32, "FragRec is one 32-byte record");
+static constexpr int LF_THREADS = 1024, LF_ITEMS = 8;
+static constexpr uint32_t LF_TILE = LF_THREADS * LF_ITEMS;        // 8192 oriented nodes: 64 KB of LDS, two workgroups per CU
+static constexpr uint16_t LF_STOP = 0xFFFFu, LF_DONE = 0xFFFEu;
+
+// v -> (owner splitter, position in its segment); false: no walker owns v (dead, or on a circular unitig without a splitter)
+__device__ __forceinline__ bool owner_of(const uint2 *__restrict__ ol, const FragRec *__restrict__ frag, uint32_t v,
+                                         uint32_t &owner, uint32_t &pos) {
+    const uint2 t = ol[v];
+    if (t.x == NIL) return false;
+    const uint2 ob = *reinterpret_cast<const uint2 *>(&frag[t.x].owner);
+    if (ob.x == NIL) return false;
+    owner = ob.x; pos = ob.y + t.y;
+    return true;
+}
+
 static constexpr int SS_ITEMS = 16;            // oriented nodes per thread of k_succ_split
 
 template <int W>
@@ -98,12 +130,73 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
         const uint32_t v = base + (uint32_t)it * 256u + threadIdx.x;
         const bool p = (pbits >> it) & 1u;
         const unsigned long long m = __ballot(p);
-        uint2 o; o.x = NIL; o.y = 0;
-        if (p) {
+        if (p) {                                                   // (the other entries of ol are written by k_local_frag)
             const uint32_t i = blk_base + woff[it * 4 + wid] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            spl[i] = v; o.x = i;
+            spl[i] = v;
+            uint2 o; o.x = i; o.y = 0; ol[v] = o;
         }
-        if (v < total) ol[v] = o;
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t total, const uint8_t *__restrict__ alive,
+                                                           const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
+                                                           FragRec *__restrict__ frag, uint32_t split_mask) {
+    __shared__ uint16_t l_succ[LF_TILE];       // local index of the successor; LF_STOP: the fragment ends here; LF_DONE: a walker has passed
+    __shared__ uint32_t l_cnt[LF_TILE];        // count; once passed: (local head << 13) | position in the fragment
+    __shared__ uint16_t l_heads[LF_TILE];
+    __shared__ uint32_t n_heads;
+    if (threadIdx.x == 0) n_heads = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t base = blockIdx.x * LF_TILE;                    // even: v and v^1 sit in adjacent lanes
+#pragma unroll 2
+    for (int it = 0; it < LF_ITEMS; it++) {
+        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+        const uint32_t v = base + j;
+        uint2 w; w.x = NIL; w.y = 0; bool al = false;
+        if (v < total) { w = winfo[v]; al = alive[v >> 1] != 0; }
+        const uint32_t s = w.x;
+        const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node: its mirror is v's predecessor
+        const bool p = al && (sp == NIL || node_sampled(v, split_mask));             // a splitter (head or sampled)
+        const bool head = al && (p || ((sp ^ 1u) - base) >= LF_TILE);                // ... or entered from another tile
+        l_succ[j] = (s != NIL && (s - base) < LF_TILE && !node_sampled(s, split_mask)) ? (uint16_t)(s - base) : LF_STOP;
+        l_cnt[j] = w.y;
+        const unsigned long long m = __ballot(head);
+        uint32_t off = 0;
+        if (lane == 0 && m) off = atomicAdd(&n_heads, (uint32_t)__popcll(m));
+        off = (uint32_t)__shfl((int)off, 0);
+        if (head) l_heads[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
+    }
+    __syncthreads();
+    const uint32_t nh = n_heads;
+    for (uint32_t h = threadIdx.x; h < nh; h += LF_THREADS) {      // every fragment head walks its fragment in LDS
+        const uint32_t j = l_heads[h];
+        uint32_t cur = j, pos = 0;
+        unsigned long long sum = 0;
+        for (;;) {
+            const uint32_t nx = l_succ[cur];
+            sum += l_cnt[cur];
+            l_cnt[cur] = (j << 13) | pos;
+            l_succ[cur] = LF_DONE;
+            pos++;
+            if (nx >= LF_TILE || pos >= LF_TILE) break;            // LF_STOP (or, never: a fragment longer than the tile)
+            cur = nx;
+        }
+        const uint32_t v = base + j;
+        FragRec f; f.next = winfo[base + cur].x; f.len = pos; f.last = base + cur; f.pad = 0; f.sum = sum; f.base = 0;
+        f.owner = (winfo[v ^ 1u].x == NIL || node_sampled(v, split_mask)) ? ol[v].x : NIL;   // a splitter's index (k_succ_split)
+        frag[v] = f;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int it = 0; it < LF_ITEMS; it++) {
+        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+        const uint32_t v = base + j;
+        if (v >= total) break;
+        uint2 o; o.x = NIL; o.y = 0;
+        if (l_succ[j] == LF_DONE) { const uint32_t e = l_cnt[j]; o.x = base + (e >> 13); o.y = e & (LF_TILE - 1u); }
+        ol[v] = o;
     }
 }
 
@@ -112,27 +205,28 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
 struct SegRec { uint32_t node, next_spl, len, last; unsigned long long sum; uint32_t head, pad; };
 static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 
+// one walker per splitter: from fragment to fragment until the next splitter (a fragment that starts at a splitter
+// got its owner in k_succ_split; the others get theirs here)
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_segments(const uint2 *__restrict__ winfo,
-                                                       const uint32_t *__restrict__ spl, uint32_t n_spl,
-                                                       uint2 *__restrict__ ol, SegRec *__restrict__ segs,
-                                                       uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */) {
+__global__ __launch_bounds__(256) void k_walk_frags(const uint2 *__restrict__ winfo,
+                                                    const uint32_t *__restrict__ spl, uint32_t n_spl,
+                                                    FragRec *__restrict__ frag, SegRec *__restrict__ segs,
+                                                    uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */) {
     unsigned long long my_cov = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
-        uint32_t cur = s, len = 0, nxt;
+        uint32_t cur = s, len = 0, nxt, last;
         unsigned long long sum = 0;
         for (;;) {
-            const uint2 w = winfo[cur];
-            if (cur != s) { uint2 o; o.x = i; o.y = len; ol[cur] = o; }
-            sum += w.y;
-            len++;
-            nxt = w.x;
+            const uint4 a = *reinterpret_cast<const uint4 *>(&frag[cur]);            // next, len, last, pad
+            const unsigned long long fs = frag[cur].sum;
+            if (cur != s) { uint2 ob; ob.x = i; ob.y = len; *reinterpret_cast<uint2 *>(&frag[cur].owner) = ob; }
+            sum += fs; len += a.y; last = a.z; nxt = a.x;
             if (nxt == NIL || node_sampled(nxt, split_mask)) break;
             cur = nxt;
         }
-        SegRec r; r.node = s; r.len = len; r.last = cur; r.sum = sum; r.pad = 0;
-        r.next_spl = (nxt == NIL) ? NIL : ol[nxt].x;       // splitters got their owner in k_succ_split
+        SegRec r; r.node = s; r.len = len; r.last = last; r.sum = sum; r.pad = 0;
+        r.next_spl = (nxt == NIL) ? NIL : frag[nxt].owner;       // a splitter's own fragment got its owner in k_succ_split
         r.head = winfo[s ^ 1u].x == NIL ? HEAD_LINEAR : 0u;
         segs[i] = r;
         my_cov += len;
@@ -149,6 +243,7 @@ static constexpr uint32_t ORPHAN_MAX = 1u << 16;          // (no sampled node am
 template <int W>
 __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t *__restrict__ alive,
                                                        const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
+                                                       FragRec *__restrict__ frag,
                                                        uint32_t *__restrict__ spl, SegRec *__restrict__ segs,
                                                        unsigned int *__restrict__ n_spl,
                                                        uint32_t seg_cap, uint32_t *__restrict__ flags,
@@ -157,7 +252,8 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
     if (*n_alive == *n_covered) return;                    // every alive node has an owner: no such ring (the usual case)
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
-        if (!alive[v >> 1] || ol[v].x != NIL) continue;
+        if (!alive[v >> 1]) continue;
+        { uint32_t o_, p_; if (owner_of(ol, frag, v, o_, p_)) continue; }
         const uint2 w0 = winfo[v];
         uint32_t best = v, n = 1, cur = w0.x, last = v;
         unsigned long long sum = w0.y;
@@ -174,7 +270,11 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
         if (idx >= seg_cap) { flags[0] = 2; continue; }
         spl[idx] = v;
         cur = v;
-        for (uint32_t j = 0; j < n; j++) { uint2 o; o.x = idx; o.y = j; ol[cur] = o; cur = winfo[cur].x; }
+        for (uint32_t j = 0; j < n; j++) {                     // every node a fragment of its own, owned by the new splitter
+            uint2 o; o.x = cur; o.y = 0; ol[cur] = o;
+            uint2 ob; ob.x = idx; ob.y = j; *reinterpret_cast<uint2 *>(&frag[cur].owner) = ob;
+            cur = winfo[cur].x;
+        }
         SegRec r; r.node = v; r.next_spl = NIL; r.len = n; r.last = last; r.sum = sum; r.head = HEAD_ORPHAN; r.pad = 0;
         segs[idx] = r;
     }
@@ -292,6 +392,41 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
     }
 }
 
+// ol[v]: {fragment head, position in the fragment} -> {chain record (NIL: none), position in the chain}.  Same tiles as
+// k_local_frag (a fragment never leaves its tile); nodes that k_orphan_cycles re-homed are fragments of their own.
+__global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t total, uint2 *__restrict__ ol, const FragRec *__restrict__ frag,
+                                                           const FinRec *__restrict__ fin) {
+    __shared__ uint2 l_chain[LF_TILE];         // per local fragment head: {chain record, nodes of the chain before the fragment}
+    const uint32_t base = blockIdx.x * LF_TILE;
+    uint2 t[LF_ITEMS];
+#pragma unroll
+    for (int it = 0; it < LF_ITEMS; it++) {
+        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+        const uint32_t v = base + j;
+        t[it].x = NIL; t[it].y = 0;
+        if (v < total) t[it] = ol[v];
+        if (t[it].x == v) {                                        // a fragment head
+            uint2 e; e.x = NIL; e.y = 0;
+            const uint2 ob = *reinterpret_cast<const uint2 *>(&frag[v].owner);
+            if (ob.x != NIL) { const FinRec f = fin[ob.x]; e.x = f.slot; e.y = f.base + ob.y; }
+            l_chain[j] = e;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < LF_ITEMS; it++) {
+        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+        const uint32_t v = base + j;
+        if (v >= total) break;
+        uint2 o; o.x = NIL; o.y = 0;
+        if (t[it].x != NIL) {
+            const uint2 e = l_chain[t[it].x - base];
+            if (e.x != NIL) { o.x = e.x; o.y = e.y + t[it].y; }
+        }
+        ol[v] = o;
+    }
+}
+
 // ---- the smallest k-mer of every ring (where SPEC S10 cuts it): two streaming passes over the oriented nodes.
 // Both return at once when the graph holds no ring (*n_cyc == 0).  Pass 1: the smallest 64-bit key prefix per ring
 // (the lanes of a wave nearly always sit on the same ring: one shuffle reduction and one atomic per wave and ring).
@@ -299,7 +434,7 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
 // exact minimum among themselves by compare-and-swap.
 template <int W>
 __global__ __launch_bounds__(256) void k_ring_min1(Graph<W> g, const uint8_t *__restrict__ alive, const uint2 *__restrict__ ol,
-                                                   const FinRec *__restrict__ fin, RingMin *__restrict__ ringmin,
+                                                   RingMin *__restrict__ ringmin,
                                                    const unsigned int *__restrict__ n_cyc) {
     if (*n_cyc == 0) return;
     // block-level table ring -> smallest prefix seen by this block: the global atomics are one per block and ring
@@ -325,9 +460,7 @@ __global__ __launch_bounds__(256) void k_ring_min1(Graph<W> g, const uint8_t *__
     uint32_t cs0 = NIL, cs1 = NIL; unsigned long long cm0 = ~0ull, cm1 = ~0ull;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += stride) {
         if (!alive[v >> 1]) continue;
-        const uint32_t s = ol[v].x;
-        if (s == NIL) continue;
-        const uint32_t sl = fin[s].slot;
+        const uint32_t sl = ol[v].x;
         if (sl == NIL || !ringmin[sl].is_ring) continue;
         const unsigned long long pf = km_prefix64<W>(g.keys, v >> 1, g.k);
         if (sl == cs0) { if (pf < cm0) cm0 = pf; }
@@ -360,15 +493,13 @@ __global__ __launch_bounds__(256) void k_ring_min1(Graph<W> g, const uint8_t *__
 }
 template <int W>
 __global__ __launch_bounds__(256) void k_ring_min2(Graph<W> g, const uint8_t *__restrict__ alive, const uint2 *__restrict__ ol,
-                                                   const FinRec *__restrict__ fin, RingMin *__restrict__ ringmin,
+                                                   RingMin *__restrict__ ringmin,
                                                    const unsigned int *__restrict__ n_cyc) {
     if (*n_cyc == 0) return;
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1]) continue;
-        const uint32_t s = ol[v].x;
-        if (s == NIL) continue;
-        const uint32_t sl = fin[s].slot;
+        const uint32_t sl = ol[v].x;
         if (sl == NIL) continue;
         const RingMin rm = ringmin[sl];
         if (!rm.is_ring || km_prefix64<W>(g.keys, v >> 1, g.k) != rm.prefix) continue;
@@ -389,7 +520,7 @@ __global__ __launch_bounds__(256) void k_ring_min2(Graph<W> g, const uint8_t *__
 template <int W>
 __global__ __launch_bounds__(256) void k_ring_rot(Graph<W> g, HeadRec *__restrict__ heads, const unsigned int *__restrict__ n_heads_p,
                                                   const RingMin *__restrict__ ringmin, const uint2 *__restrict__ winfo,
-                                                  const uint2 *__restrict__ ol, const FinRec *__restrict__ fin,
+                                                  const uint2 *__restrict__ ol,
                                                   const unsigned int *__restrict__ n_cyc, uint32_t *__restrict__ flags) {
     if (*n_cyc == 0) return;
     const uint32_t n_heads = *n_heads_p;
@@ -398,42 +529,38 @@ __global__ __launch_bounds__(256) void k_ring_rot(Graph<W> g, HeadRec *__restric
         if (!rm.is_ring) continue;
         if (rm.vmin == NIL) { flags[0] = 3; continue; }             // (cannot happen: every ring has nodes)
         if (rm.vmin & 1u) continue;                                 // the mirror strand: decided by its partner
-        const uint2 o = ol[rm.vmin];
+        const uint2 o = ol[rm.vmin];                                // {this ring's record, position of its smallest k-mer}
         const uint32_t w = winfo[rm.vmin ^ 1u].x;                   // first node of the reverse-complement spelling
         bool mirror = false;
         uint2 ow; ow.x = NIL; ow.y = 0;
         if (w != NIL) {
             ow = ol[w];
-            mirror = ow.x != NIL && fin[ow.x].slot != NIL && fin[ow.x].slot != i && km_less<W>(g.seq(w), g.seq(rm.vmin));
+            mirror = ow.x != NIL && ow.x != i && km_less<W>(g.seq(w), g.seq(rm.vmin));
         }
         if (mirror) {
-            const uint32_t j = fin[ow.x].slot;
-            heads[j].emit = 1; heads[j].rot = fin[ow.x].base + ow.y;
+            heads[ow.x].emit = 1; heads[ow.x].rot = ow.y;
             heads[i].emit = 0;
         } else {
-            heads[i].emit = 1; heads[i].rot = fin[o.x].base + o.y;
+            heads[i].emit = 1; heads[i].rot = o.y;
         }
     }
 }
 
-// per node: splitter -> chain record -> output offset (~0 = chain not emitted)
+// per node: chain record -> output offset (~0 = chain not emitted)
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
-                                              const uint2 *__restrict__ ol, const FinRec *__restrict__ fin,
+                                              const uint2 *__restrict__ ol,
                                               const EmitRec *__restrict__ head_off,
                                               char *__restrict__ out) {
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1]) continue;
-        const uint2 own = ol[v];
-        const uint32_t s = own.x;
-        if (s == NIL) continue;
-        const FinRec f = fin[s];
-        if (f.slot == NIL) continue;
-        const EmitRec er = head_off[f.slot];
+        const uint2 own = ol[v];                           // {chain record, position in the chain} (k_tile_final)
+        if (own.x == NIL) continue;
+        const EmitRec er = head_off[own.x];
         const unsigned long long off = er.off;
         if (off == ~0ull) continue;
-        uint32_t pos = f.base + own.y;
+        uint32_t pos = own.y;
         if (er.rot) pos = pos >= er.rot ? pos - er.rot : pos + er.len - er.rot;    // a circular unitig starts at its smallest k-mer
         const Kmer<W> x = g.seq(v);
         char *dst = out + off;

@@ -8,7 +8,7 @@
 //   a6/a8  histo, :filtering      -> fused into k_count_partitions (k_compact_rows when the fit raises the threshold)
 //   a10    assembly:create_graph  -> graph_part.h   k_gp_*, k_graph_local, k_graph_remote
 //   a11    assembly:correct_graph -> graph_part.h   k_tip_*, k_bubble, k_apply_removed
-//   a12    assembly:collapse_graph-> collapse.h     k_succ_split, k_walk_segments, k_rank_*, k_emit
+//   a12    assembly:collapse_graph-> collapse.h     k_succ_split, k_walk_frags, k_rank_*, k_emit
 //   (count_global.h: the first, global-atomic counting path, kept as a cross-check)
 // Integer/hash work only: no MFMA anywhere on this path.
 #include <hip/hip_runtime.h>
@@ -1166,7 +1166,9 @@ public:
         DevBuf<uint32_t> spl;
         DevBuf<uint2> winfo, ol;
         DevBuf<SegRec> segs;
+        DevBuf<FragRec> frag;                                            // indexed by node id, written at fragment heads only
         if (int rc = winfo.alloc(total, err)) return rc;
+        if (int rc = frag.alloc(total, err)) return rc;
         if (int rc = spl.alloc(total, err)) return rc;
         if (int rc = ol.alloc(total, err)) return rc;
         HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 .. 8 as above, 9 = alive oriented nodes, 10 = nodes walked
@@ -1174,6 +1176,8 @@ public:
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
                            alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
+        const int lf_grid = (int)((total + LF_TILE - 1) / LF_TILE);
+        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, total, alive_.p, winfo.p, ol.p, frag.p, split_mask);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1186,11 +1190,11 @@ public:
         {
             EvTimer t2(stream_);
             if (n_spl) {
-                hipLaunchKernelGGL(k_walk_segments<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
-                                   spl.p, n_spl, ol.p, segs.p, split_mask, ctl_.p + 10);
+                hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
+                                   spl.p, n_spl, frag.p, segs.p, split_mask, ctl_.p + 10);
             }
             hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
-                               spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
+                               frag.p, spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
             HIPCHK(hipGetLastError());
             t2.stop_later("collapse_walk", pending_timers_);
         }
@@ -1220,11 +1224,12 @@ public:
         hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, d_heads.p, slot_of.p, ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
         hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
+        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, total, ol.p, frag.p, fin.p);
         // rings: their smallest k-mer (these three return at once when there is none)
-        hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
-        hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, ringmin.p, d_ncyc);
+        hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
+        hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
         hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, d_heads.p, (const unsigned int *)(ctl_.p + 6), ringmin.p,
-                           winfo.p, ol.p, fin.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
+                           winfo.p, ol.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
         HIPCHK(hipGetLastError());
         unsigned long long hc[4];
         // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
@@ -1257,7 +1262,7 @@ public:
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
             HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * sizeof(EmitRec), hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
-            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p, fin.p, d_off.p, d_out.p);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
