@@ -44,7 +44,7 @@ template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g
 // ---- fragments: the part of the walk that stays inside a tile of node ids is done in LDS ---------------------------
 // The solid rows arrive grouped by minimiser partition, and ~90 % of the simple links join two k-mers of one
 // partition (neighbouring k-mers share their minimiser), so most successors of a node sit within a few thousand
-// ids of it.  k_local_frag works on tiles of LF_TILE oriented nodes: winfo of the tile is read once (coalesced),
+// ids of it.  k_local_frag works on tiles of up to LF_TILE oriented nodes: winfo of the tile is read once (coalesced),
 // the successors go to LDS, and every FRAGMENT HEAD — a splitter, or a node whose predecessor lies outside the
 // tile — walks its fragment there (until the chain ends, leaves the tile or reaches a splitter).  To HBM go
 //   ol[v]   = {head of v's fragment, position in the fragment}       (coalesced)
@@ -56,7 +56,7 @@ template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g
 // handed to the fragment's nodes through LDS, and the kernels behind it (rings, emission) read ol alone.
 // Correct for any row order — a tile that holds no neighbours just makes one-node fragments — fast for the order
 // the counting pass produces.
-struct FragRec { uint32_t next, len, last, pad; unsigned long long sum; uint32_t owner, base; };
+struct FragRec { uint32_t next, len, last, pad /* 1: the head of a linear chain */; unsigned long long sum; uint32_t owner, base; };
 static_assert(sizeof(FragRec) == 32, "FragRec is one 32-byte record");
 static constexpr int LF_THREADS = 1024, LF_ITEMS = 8;
 static constexpr uint32_t LF_TILE = LF_THREADS * LF_ITEMS;        // 8192 oriented nodes: 64 KB of LDS, two workgroups per CU
@@ -138,65 +138,116 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
     }
 }
 
+// Tiles: nominally LF_ROWS rows, each edge moved forward to the next row that starts a group of rows (row_starts:
+// one bit per row, set where the low bits of the minimiser hash change — k_row_starts), so that a tile holds whole
+// minimiser partitions when the rows arrive grouped.  Only a hint: any cut is correct.  A tile that ends up
+// larger than the LDS arrays is worked off in chunks.
+static constexpr uint32_t LF_ROWS = 2560;
+__device__ __forceinline__ uint32_t next_row_start(const uint32_t *__restrict__ bits, uint32_t n_rows, uint32_t r0, int lane) {
+    // wave-wide: the first row >= r0 whose start bit is set, looking 64 words (2048 rows) ahead; r0 if there is none
+    if (r0 == 0u || r0 >= n_rows) return r0 < n_rows ? r0 : n_rows;
+    const uint32_t nw = (n_rows + 31u) >> 5;
+    const uint32_t w = (r0 >> 5) + (uint32_t)lane;
+    uint32_t x = w < nw ? bits[w] : 0u;
+    if (lane == 0) x &= 0xFFFFFFFFu << (r0 & 31u);
+    const unsigned long long m = __ballot(x != 0u);
+    if (!m) return r0;
+    const int L = __ffsll((long long)m) - 1;
+    const uint32_t xl = (uint32_t)__shfl((int)x, L);
+    const uint32_t r = (((r0 >> 5) + (uint32_t)L) << 5) + (uint32_t)(__ffs((int)xl) - 1);
+    return r < n_rows ? r : n_rows;
+}
+// (first wave of the workgroup; the caller synchronises)
+__device__ __forceinline__ void tile_bounds(const uint32_t *__restrict__ bits, uint32_t n_rows, uint32_t *lo, uint32_t *hi) {
+    if (threadIdx.x < 64) {
+        const int lane = (int)threadIdx.x;
+        const uint32_t a = next_row_start(bits, n_rows, blockIdx.x * LF_ROWS, lane);
+        const uint32_t b = blockIdx.x + 1u == gridDim.x ? n_rows : next_row_start(bits, n_rows, (blockIdx.x + 1u) * LF_ROWS, lane);
+        if (lane == 0) { *lo = a; *hi = b; }
+    }
+}
+__global__ __launch_bounds__(256) void k_row_starts(const uint32_t *__restrict__ gp_of, uint32_t n, uint32_t lowmask,
+                                                    uint32_t *__restrict__ bits) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t n_round = (n + 63u) & ~63u;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        const bool st = i < n && (i == 0u || ((gp_of[i] ^ gp_of[i - 1u]) & lowmask) != 0u);
+        const unsigned long long m = __ballot(st);
+        if ((threadIdx.x & 63) == 0) { bits[i >> 5] = (uint32_t)m; bits[(i >> 5) + 1u] = (uint32_t)(m >> 32); }
+    }
+}
+
 template <int W>
-__global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t total, const uint8_t *__restrict__ alive,
+__global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, const uint32_t *__restrict__ row_starts,
+                                                           const uint8_t *__restrict__ alive,
                                                            const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
                                                            FragRec *__restrict__ frag, uint32_t split_mask) {
     __shared__ uint16_t l_succ[LF_TILE];       // local index of the successor; LF_STOP: the fragment ends here; LF_DONE: a walker has passed
     __shared__ uint32_t l_cnt[LF_TILE];        // count; once passed: (local head << 13) | position in the fragment
     __shared__ uint16_t l_heads[LF_TILE];
-    __shared__ uint32_t n_heads;
-    if (threadIdx.x == 0) n_heads = 0;
+    __shared__ uint32_t n_heads, t_lo, t_hi;
+    tile_bounds(row_starts, n_rows, &t_lo, &t_hi);
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const uint32_t base = blockIdx.x * LF_TILE;                    // even: v and v^1 sit in adjacent lanes
+    const uint32_t hi = t_hi;
+    for (uint32_t c = t_lo; c < hi; c += LF_TILE / 2u) {
+        const uint32_t base = 2u * c;                                  // even: v and v^1 sit in adjacent lanes
+        const uint32_t size = 2u * (min(c + LF_TILE / 2u, hi) - c);   // oriented nodes of this chunk (<= LF_TILE)
+        if (threadIdx.x == 0) n_heads = 0;
+        __syncthreads();
 #pragma unroll 2
-    for (int it = 0; it < LF_ITEMS; it++) {
-        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
-        const uint32_t v = base + j;
-        uint2 w; w.x = NIL; w.y = 0; bool al = false;
-        if (v < total) { w = winfo[v]; al = alive[v >> 1] != 0; }
-        const uint32_t s = w.x;
-        const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node: its mirror is v's predecessor
-        const bool p = al && (sp == NIL || node_sampled(v, split_mask));             // a splitter (head or sampled)
-        const bool head = al && (p || ((sp ^ 1u) - base) >= LF_TILE);                // ... or entered from another tile
-        l_succ[j] = (s != NIL && (s - base) < LF_TILE && !node_sampled(s, split_mask)) ? (uint16_t)(s - base) : LF_STOP;
-        l_cnt[j] = w.y;
-        const unsigned long long m = __ballot(head);
-        uint32_t off = 0;
-        if (lane == 0 && m) off = atomicAdd(&n_heads, (uint32_t)__popcll(m));
-        off = (uint32_t)__shfl((int)off, 0);
-        if (head) l_heads[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
-    }
-    __syncthreads();
-    const uint32_t nh = n_heads;
-    for (uint32_t h = threadIdx.x; h < nh; h += LF_THREADS) {      // every fragment head walks its fragment in LDS
-        const uint32_t j = l_heads[h];
-        uint32_t cur = j, pos = 0;
-        unsigned long long sum = 0;
-        for (;;) {
-            const uint32_t nx = l_succ[cur];
-            sum += l_cnt[cur];
-            l_cnt[cur] = (j << 13) | pos;
-            l_succ[cur] = LF_DONE;
-            pos++;
-            if (nx >= LF_TILE || pos >= LF_TILE) break;            // LF_STOP (or, never: a fragment longer than the tile)
-            cur = nx;
+        for (int it = 0; it < LF_ITEMS; it++) {
+            const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+            if ((uint32_t)it * LF_THREADS >= size) break;              // (uniform)
+            const uint32_t v = base + j;
+            uint2 w; w.x = NIL; w.y = 0; bool al = false;
+            if (j < size) { w = winfo[v]; al = alive[v >> 1] != 0; }
+            const uint32_t s = w.x;
+            const uint32_t sp = (uint32_t)__shfl_xor((int)s, 1);       // succ of the mirror node: its mirror is v's predecessor
+            const bool p = al && (sp == NIL || node_sampled(v, split_mask));         // a splitter (head or sampled)
+            const bool head = al && (p || ((sp ^ 1u) - base) >= size);               // ... or entered from outside
+            if (j < size) {
+                l_succ[j] = (s != NIL && (s - base) < size && !node_sampled(s, split_mask)) ? (uint16_t)(s - base) : LF_STOP;
+                l_cnt[j] = w.y;
+            }
+            const unsigned long long m = __ballot(head);
+            uint32_t off = 0;
+            if (lane == 0 && m) off = atomicAdd(&n_heads, (uint32_t)__popcll(m));
+            off = (uint32_t)__shfl((int)off, 0);
+            if (head) l_heads[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)j;
         }
-        const uint32_t v = base + j;
-        FragRec f; f.next = winfo[base + cur].x; f.len = pos; f.last = base + cur; f.pad = 0; f.sum = sum; f.base = 0;
-        f.owner = (winfo[v ^ 1u].x == NIL || node_sampled(v, split_mask)) ? ol[v].x : NIL;   // a splitter's index (k_succ_split)
-        frag[v] = f;
-    }
-    __syncthreads();
+        __syncthreads();
+        const uint32_t nh = n_heads;
+        for (uint32_t h = threadIdx.x; h < nh; h += LF_THREADS) {      // every fragment head walks its fragment in LDS
+            const uint32_t j = l_heads[h];
+            uint32_t cur = j, pos = 0;
+            unsigned long long sum = 0;
+            for (;;) {
+                const uint32_t nx = l_succ[cur];
+                sum += l_cnt[cur];
+                l_cnt[cur] = (j << 13) | pos;
+                l_succ[cur] = LF_DONE;
+                pos++;
+                if (nx >= LF_TILE || pos >= LF_TILE) break;            // LF_STOP (or, never: a fragment longer than the tile)
+                cur = nx;
+            }
+            const uint32_t v = base + j;
+            FragRec f; f.next = winfo[base + cur].x; f.len = pos; f.last = base + cur; f.sum = sum; f.base = 0;
+            const bool chain_head = winfo[v ^ 1u].x == NIL;            // no simple predecessor: the first node of a linear chain
+            f.pad = chain_head ? 1u : 0u;
+            f.owner = (chain_head || node_sampled(v, split_mask)) ? ol[v].x : NIL;   // a splitter's index (k_succ_split)
+            frag[v] = f;
+        }
+        __syncthreads();
 #pragma unroll 2
-    for (int it = 0; it < LF_ITEMS; it++) {
-        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
-        const uint32_t v = base + j;
-        if (v >= total) break;
-        uint2 o; o.x = NIL; o.y = 0;
-        if (l_succ[j] == LF_DONE) { const uint32_t e = l_cnt[j]; o.x = base + (e >> 13); o.y = e & (LF_TILE - 1u); }
-        ol[v] = o;
+        for (int it = 0; it < LF_ITEMS; it++) {
+            const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+            if (j >= size) break;
+            uint2 o; o.x = NIL; o.y = 0;
+            if (l_succ[j] == LF_DONE) { const uint32_t e = l_cnt[j]; o.x = base + (e >> 13); o.y = e & (LF_TILE - 1u); }
+            ol[base + j] = o;
+        }
+        __syncthreads();                                               // (the arrays are reused by the next chunk)
     }
 }
 
@@ -208,17 +259,17 @@ static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 // one walker per splitter: from fragment to fragment until the next splitter (a fragment that starts at a splitter
 // got its owner in k_succ_split; the others get theirs here)
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_frags(const uint2 *__restrict__ winfo,
-                                                    const uint32_t *__restrict__ spl, uint32_t n_spl,
+__global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__ spl, uint32_t n_spl,
                                                     FragRec *__restrict__ frag, SegRec *__restrict__ segs,
                                                     uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */) {
     unsigned long long my_cov = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
-        uint32_t cur = s, len = 0, nxt, last;
+        uint32_t cur = s, len = 0, nxt, last, is_head = 0;
         unsigned long long sum = 0;
         for (;;) {
             const uint4 a = *reinterpret_cast<const uint4 *>(&frag[cur]);            // next, len, last, pad
+            if (cur == s) is_head = a.w;
             const unsigned long long fs = frag[cur].sum;
             if (cur != s) { uint2 ob; ob.x = i; ob.y = len; *reinterpret_cast<uint2 *>(&frag[cur].owner) = ob; }
             sum += fs; len += a.y; last = a.z; nxt = a.x;
@@ -227,7 +278,7 @@ __global__ __launch_bounds__(256) void k_walk_frags(const uint2 *__restrict__ wi
         }
         SegRec r; r.node = s; r.len = len; r.last = last; r.sum = sum; r.pad = 0;
         r.next_spl = (nxt == NIL) ? NIL : frag[nxt].owner;       // a splitter's own fragment got its owner in k_succ_split
-        r.head = winfo[s ^ 1u].x == NIL ? HEAD_LINEAR : 0u;
+        r.head = is_head ? HEAD_LINEAR : 0u;
         segs[i] = r;
         my_cov += len;
     }
@@ -392,38 +443,49 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
     }
 }
 
-// ol[v]: {fragment head, position in the fragment} -> {chain record (NIL: none), position in the chain}.  Same tiles as
-// k_local_frag (a fragment never leaves its tile); nodes that k_orphan_cycles re-homed are fragments of their own.
-__global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t total, uint2 *__restrict__ ol, const FragRec *__restrict__ frag,
+// ol[v]: {fragment head, position in the fragment} -> {chain record (NIL: none), position in the chain}.  Same tiles and
+// chunks as k_local_frag (a fragment never leaves its chunk); nodes that k_orphan_cycles re-homed are fragments of their own.
+__global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t n_rows, const uint32_t *__restrict__ row_starts,
+                                                           uint2 *__restrict__ ol, const FragRec *__restrict__ frag,
                                                            const FinRec *__restrict__ fin) {
     __shared__ uint2 l_chain[LF_TILE];         // per local fragment head: {chain record, nodes of the chain before the fragment}
-    const uint32_t base = blockIdx.x * LF_TILE;
-    uint2 t[LF_ITEMS];
-#pragma unroll
-    for (int it = 0; it < LF_ITEMS; it++) {
-        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
-        const uint32_t v = base + j;
-        t[it].x = NIL; t[it].y = 0;
-        if (v < total) t[it] = ol[v];
-        if (t[it].x == v) {                                        // a fragment head
-            uint2 e; e.x = NIL; e.y = 0;
-            const uint2 ob = *reinterpret_cast<const uint2 *>(&frag[v].owner);
-            if (ob.x != NIL) { const FinRec f = fin[ob.x]; e.x = f.slot; e.y = f.base + ob.y; }
-            l_chain[j] = e;
-        }
-    }
+    __shared__ uint32_t t_lo, t_hi;
+    tile_bounds(row_starts, n_rows, &t_lo, &t_hi);
     __syncthreads();
+    const uint32_t hi = t_hi;
+    for (uint32_t c = t_lo; c < hi; c += LF_TILE / 2u) {
+        const uint32_t base = 2u * c;
+        const uint32_t size = 2u * (min(c + LF_TILE / 2u, hi) - c);
+        uint2 t[LF_ITEMS];
 #pragma unroll
-    for (int it = 0; it < LF_ITEMS; it++) {
-        const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
-        const uint32_t v = base + j;
-        if (v >= total) break;
-        uint2 o; o.x = NIL; o.y = 0;
-        if (t[it].x != NIL) {
-            const uint2 e = l_chain[t[it].x - base];
-            if (e.x != NIL) { o.x = e.x; o.y = e.y + t[it].y; }
+        for (int it = 0; it < LF_ITEMS; it++) {
+            const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+            const uint32_t v = base + j;
+            t[it].x = NIL; t[it].y = 0;
+            if (j < size) {
+                t[it] = ol[v];
+                if (t[it].x == v) {                                    // a fragment head
+                    uint2 e; e.x = NIL; e.y = 0;
+                    const uint2 ob = *reinterpret_cast<const uint2 *>(&frag[v].owner);
+                    if (ob.x != NIL) { const FinRec f = fin[ob.x]; e.x = f.slot; e.y = f.base + ob.y; }
+                    l_chain[j] = e;
+                }
+            }
         }
-        ol[v] = o;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < LF_ITEMS; it++) {
+            const uint32_t j = (uint32_t)it * LF_THREADS + threadIdx.x;
+            if (j < size) {
+                uint2 o; o.x = NIL; o.y = 0;
+                if (t[it].x != NIL) {
+                    const uint2 e = l_chain[t[it].x - base];
+                    if (e.x != NIL) { o.x = e.x; o.y = e.y + t[it].y; }
+                }
+                ol[base + j] = o;
+            }
+        }
+        __syncthreads();
     }
 }
 

@@ -41,7 +41,7 @@ namespace shk {
 static constexpr uint32_t NIL = 0xFFFFFFFFu;
 static constexpr uint64_t EMPTY64 = ~0ull;
 static constexpr int MAX_PROBE = 4096;
-static constexpr int SPLIT_LOG_DEFAULT = 5;    // one sampled splitter every ~32 oriented nodes
+static constexpr int SPLIT_LOG_DEFAULT = 6;    // one sampled splitter every ~64 oriented nodes (the walk hops over LDS-built fragments: 5 -> 6 measured best)
 
 // ------------------------------------------------------------------------------------------
 // device-side views
@@ -607,7 +607,9 @@ public:
         if (int rc = dh.alloc(500, err)) return rc;
         if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
         uint64_t cap = cap_hint;
-        for (int attempt = 0; attempt < 2; attempt++) {
+        // (exact modes: the second attempt knows the row count.  Bloom mode is not repeatable to the row — which
+        // k-mers a false positive lifts over the threshold depends on the order of arrival — so its retries get slack)
+        for (int attempt = 0; attempt < (bloom ? 4 : 2); attempt++) {
             bloom_new = 0; bloom_kmer_bytes = 0; bloom_kmer_bytes_exact = 0;
             for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
             if (int rc = cnt.alloc(cap, err)) return rc;
@@ -756,7 +758,7 @@ public:
             if (n_rows <= cap) {
                 return 0;
             }
-            cap = n_rows;                                 // exact; run again
+            cap = bloom ? n_rows + n_rows / 16 + 4096 : n_rows;   // exact (Bloom mode: see above); run again
         }
         err = "row buffer overflowed twice";
         return -6;
@@ -1032,6 +1034,7 @@ public:
         if (int rc = adj0_.alloc(n, err)) return rc;
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
+        if (int rc = row_starts_.alloc(((n + 63) / 64) * 2 + 2, err)) return rc;
         HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));   // (the mini tables are initialised by their builders)
         HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
         HIPCHK(hipMemsetAsync(alive_.p, 1, n ? n : 1, stream_));
@@ -1043,6 +1046,9 @@ public:
                                gp_of.p, gp_cnt.p);
             hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, gp_roff.p,
                                ctl_.p + 2);
+            // where a group of rows with the same low minimiser-hash bits starts: the tile edges of the collapse (collapse.h)
+            hipLaunchKernelGGL(k_row_starts, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, std::min<uint32_t>(gp_, 256u) - 1u,
+                               row_starts_.p);
             HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
@@ -1176,8 +1182,8 @@ public:
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
                            alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
-        const int lf_grid = (int)((total + LF_TILE - 1) / LF_TILE);
-        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, total, alive_.p, winfo.p, ol.p, frag.p, split_mask);
+        const int lf_grid = (int)((n + LF_ROWS - 1) / LF_ROWS);
+        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, alive_.p, winfo.p, ol.p, frag.p, split_mask);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1190,7 +1196,7 @@ public:
         {
             EvTimer t2(stream_);
             if (n_spl) {
-                hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_, winfo.p,
+                hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_,
                                    spl.p, n_spl, frag.p, segs.p, split_mask, ctl_.p + 10);
             }
             hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
@@ -1224,7 +1230,7 @@ public:
         hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, d_heads.p, slot_of.p, ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
         hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
-        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, total, ol.p, frag.p, fin.p);
+        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, ol.p, frag.p, fin.p);
         // rings: their smallest k-mer (these three return at once when there is none)
         hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
         hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
@@ -1310,6 +1316,7 @@ private:
     DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
     DevBuf<unsigned long long> gt_off_; DevBuf<uint32_t> gt_msk_;
     DevBuf<uint8_t> adj_, adj0_, alive_;
+    DevBuf<uint32_t> row_starts_;                    // one bit per solid row: a group of rows of one minimiser partition starts here (k_row_starts)
     PinnedBuf hout_;                  // contigs as downloaded; RawContig::ext points into it
     DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;
