@@ -3,11 +3,12 @@
 #pragma once
 
 // ------------------------------------------------------------------------------------------
-// a12: collapse (SPEC S10).  Simple links over oriented nodes, splitters = all heads plus a 1/32
-// sample, one walker per splitter, the splitter list ranked by pointer jumping, then every node
+// a12: collapse (SPEC S10).  Simple links over oriented nodes, splitters = all heads plus a 1/64
+// sample; the nodes between two splitters are first contracted into fragments inside LDS tiles (k_local_frag, below),
+// one walker per splitter hops over the fragments, the splitter list is ranked by pointer jumping, then every node
 // scatters its base into the contig buffer.
-//   winfo[v] = {succ(v) or NIL, count(v>>1)}   one 8-byte read per walker step
-//   ol[v]    = {owner splitter, position in its segment}
+//   winfo[v] = {succ(v) or NIL, count(v>>1)}
+//   ol[v]    = {head of v's fragment, position in it}; after k_tile_final {chain record, position in the chain}
 // A node is sampled by a hash of its ID: a walker decides "is my successor a splitter" from the id it
 // just read, without touching the successor (heads are never reached through a simple link: a node
 // with a simple predecessor is not a head).
@@ -286,11 +287,11 @@ __global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__
     if ((threadIdx.x & 63) == 0 && my_cov) atomicAdd(n_covered, my_cov);
 }
 
-// A circular unitig that holds no sampled node (short ones: the chance is (31/32)^n) is owned by no walker: its
+// A circular unitig that holds no sampled node (short ones: the chance is (63/64)^n) is owned by no walker: its
 // nodes are the alive nodes without an owner.  Every such node walks its cycle; the one that IS the cycle's smallest
 // k-mer acts: in orientation 0 it becomes a head splitter whose one segment is the whole cycle spelled from itself
 // (exactly SPEC S10's cut); in orientation 1 it is the mirror strand and nothing is emitted for it.
-static constexpr uint32_t ORPHAN_MAX = 1u << 16;          // (no sampled node among n: (31/32)^n; 65536 never happens)
+static constexpr uint32_t ORPHAN_MAX = 1u << 16;          // (no sampled node among n: (63/64)^n; 65536 never happens)
 template <int W>
 __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t *__restrict__ alive,
                                                        const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
