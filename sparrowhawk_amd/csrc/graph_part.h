@@ -169,43 +169,73 @@ __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, in
 
 // table sizes (power of two >= 2 x rows, at least 8) and their exclusive prefix sum, plus the
 // exclusive prefix sum of the row counts (row list offsets); one workgroup
+// slots of a partition's mini table: the power of two >= 2 x rows, at least 8 (no loop: this sits 32 times in every thread of
+// the one workgroup of k_gp_scan, where a shift loop cost 20 us)
+__device__ __forceinline__ uint32_t gp_table_size(uint32_t rows) {
+    const uint32_t want = 2u * rows;
+    return want <= 8u ? 8u : 1u << (32 - __clz((int)(want - 1u)));
+}
 __global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ gp_cnt, uint32_t GP,
                                                   unsigned long long *__restrict__ off, uint32_t *__restrict__ msk,
                                                   uint32_t *__restrict__ roff, unsigned long long *__restrict__ total) {
-    // one pass: every thread owns a run of consecutive partitions (GP / 1024 of them, <= 128), sums them, the 1024
-    // thread sums are scanned across the block, then the thread writes its run (the tiled version took 16 tiles
-    // of two barriers each for GP = 16384: 38 us of one workgroup's latency on the critical path)
+    // One workgroup on the critical path: what counts is the number of DEPENDENT memory round trips.  Chunks of
+    // 16384 partitions: 16 independent coalesced loads per thread into LDS (padded: thread t then reads its run of
+    // 16 consecutive counts from 16 different banks), thread sums scanned across the block, the run written out.
+    // (A loop of dependent loads per thread took 43 us for GP = 16384, the 16-tile version before it 38 us.)
+    constexpr uint32_t PER = 16, CH = 1024 * PER;
+    __shared__ uint32_t lc[CH + CH / PER];
+    __shared__ unsigned long long run_off[1024];
+    __shared__ uint32_t run_roff[1024];
     __shared__ unsigned long long wsum[16];
     __shared__ uint32_t rsum[16];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint32_t per = (GP + 1023u) / 1024u;
-    const uint32_t p0 = threadIdx.x * per, p1 = min(GP, p0 + per);
-    unsigned long long my = 0; uint32_t myr = 0;
-    for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t c = gp_cnt[p];
-        uint32_t sz = 8; const uint32_t want = 2u * c; while (sz < want) sz <<= 1;
-        my += sz; myr += c;
+    unsigned long long carry = 0; uint32_t rcarry = 0;
+    for (uint32_t c0 = 0; c0 < GP; c0 += CH) {
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t e = j * 1024u + threadIdx.x, p = c0 + e;
+            lc[e + (e >> 4)] = p < GP ? gp_cnt[p] : 0u;
+        }
+        __syncthreads();
+        unsigned long long my = 0; uint32_t myr = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t c = lc[threadIdx.x * (PER + 1u) + j];
+            uint32_t sz = gp_table_size(c);
+            if (c0 + threadIdx.x * PER + j >= GP) sz = 0;  // (past the last partition)
+            my += sz; myr += c;
+        }
+        unsigned long long incl = my; uint32_t rincl = myr;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long u = __shfl_up(incl, o); const uint32_t ru = (uint32_t)__shfl_up((int)rincl, o);
+            if (lane >= o) { incl += u; rincl += ru; }
+        }
+        if (lane == 63) { wsum[wid] = incl; rsum[wid] = rincl; }
+        __syncthreads();
+        unsigned long long base = carry + incl - my; uint32_t rbase = rcarry + rincl - myr;
+        for (int w = 0; w < wid; w++) { base += wsum[w]; rbase += rsum[w]; }
+        run_off[threadIdx.x] = base; run_roff[threadIdx.x] = rbase;     // where run t (16 partitions) starts
+        __syncthreads();
+        // the outputs, coalesced: element e of the chunk belongs to run e / 16; its offset inside the run is a scan over
+        // the 16 lanes of its run (four runs per wave)
+#pragma unroll 4
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t e = j * 1024u + threadIdx.x, p = c0 + e;
+            const uint32_t c = lc[e + (e >> 4)];
+            uint32_t sz = gp_table_size(c);
+            if (p >= GP) sz = 0;
+            uint32_t si = sz, ci = c;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                const uint32_t u = (uint32_t)__shfl_up((int)si, o), v = (uint32_t)__shfl_up((int)ci, o);
+                if ((lane & 15) >= o) { si += u; ci += v; }
+            }
+            if (p < GP) { off[p] = run_off[e >> 4] + (si - sz); msk[p] = sz - 1u; roff[p] = run_roff[e >> 4] + (ci - c); }
+        }
+        for (int w = 0; w < 16; w++) { carry += wsum[w]; rcarry += rsum[w]; }
+        __syncthreads();                                   // (lc, wsum, rsum, run_* are reused by the next chunk)
     }
-    unsigned long long incl = my; uint32_t rincl = myr;
-    for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long u = __shfl_up(incl, o); const uint32_t ru = (uint32_t)__shfl_up((int)rincl, o);
-        if (lane >= o) { incl += u; rincl += ru; }
-    }
-    if (lane == 63) { wsum[wid] = incl; rsum[wid] = rincl; }
-    __syncthreads();
-    unsigned long long base = incl - my; uint32_t rbase = rincl - myr;
-    for (int w = 0; w < wid; w++) { base += wsum[w]; rbase += rsum[w]; }
-    for (uint32_t p = p0; p < p1; p++) {
-        const uint32_t c = gp_cnt[p];
-        uint32_t sz = 8; const uint32_t want = 2u * c; while (sz < want) sz <<= 1;
-        off[p] = base; msk[p] = sz - 1u; roff[p] = rbase;
-        base += sz; rbase += c;
-    }
-    if (threadIdx.x == 1023) {
-        unsigned long long t = 0; uint32_t rt = 0;
-        for (int w = 0; w < 16; w++) { t += wsum[w]; rt += rsum[w]; }
-        *total = t; roff[GP] = rt;
-    }
+    if (threadIdx.x == 0) { *total = carry; roff[GP] = rcarry; }
 }
 
 // row list per graph partition: rows[roff[p] .. roff[p+1]) (order inside a partition is arbitrary)
@@ -217,17 +247,23 @@ __global__ __launch_bounds__(256) void k_gp_rows(const uint32_t *__restrict__ gp
     const uint32_t n_round = (n + stride - 1) / stride * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const uint32_t p = i < n ? gp_of[i] : 0xFFFFFFFFu;
-        unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
+        const bool valid = p != 0xFFFFFFFFu;
+        // the lanes' partitions (a handful of distinct ones: the rows arrive grouped): leader lane, rank and size of
+        // every lane's group first — registers only — then ALL leaders reserve with one atomic instruction (one
+        // memory round trip per wave instead of one per distinct partition)
+        unsigned long long todo = __ballot(valid);
+        int my_leader = lane; uint32_t rank = 0, gsize = 0;
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t lp = (uint32_t)__shfl((int)p, leader);
             const unsigned long long same = __ballot(p == lp) & todo;
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&cursor[lp], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, leader);
-            if (p == lp) rows[roff[lp] + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = i;
+            if (valid && p == lp) { my_leader = leader; rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); gsize = (uint32_t)__popcll(same); }
             todo &= ~same;
         }
+        uint32_t base = 0;
+        if (valid && lane == my_leader) base = atomicAdd(&cursor[p], gsize);
+        base = (uint32_t)__shfl((int)base, my_leader);
+        if (valid) rows[roff[p] + base + rank] = i;
     }
 }
 
@@ -513,12 +549,18 @@ __global__ __launch_bounds__(256) void k_tip_walk(Graph<W> g, const uint32_t *__
         const uint32_t v = cand[c];
         uint32_t cur = v, len = 1, J = NIL;
         unsigned long long sum = g.cnt[v >> 1];
+        // one memory round trip per step: everything the next iteration needs of node n (adjacency byte, unique
+        // out-neighbour, count) is requested as soon as n is known — a dead end of an error-free genome walks the
+        // full 2k steps on the critical path (two dependent reads per step: 70 us; one: 40 us)
+        uint32_t a_cur = g.adj[cur >> 1], nb_cur = g.nb[cur];
         for (;;) {
-            if (g.outdeg(cur) != 1) break;
-            const uint32_t n = g.only_out(cur);
+            const uint32_t om = outmask_of(a_cur, cur & 1u);
+            if (__popc(om) != 1) break;
+            const uint32_t n = nb_cur < NB_MULTI ? nb_cur : g.follow(cur, (uint32_t)__ffs((int)om) - 1u);
             if (n == NIL) break;                           // cannot happen with consistent adjacency
-            if (g.indeg(n) >= 2) { J = n; break; }
-            len++; sum += g.cnt[n >> 1]; cur = n;
+            const uint32_t a_n = g.adj[n >> 1], nb_n = g.nb[n], c_n = g.cnt[n >> 1];
+            if (__popc(outmask_of(a_n, (n & 1u) ^ 1u)) >= 2) { J = n; break; }
+            len++; sum += c_n; cur = n; a_cur = a_n; nb_cur = nb_n;
             if (len > T_TIP) break;
         }
         if (J == NIL || len > T_TIP) continue;
