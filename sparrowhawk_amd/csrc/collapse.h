@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
 // one bit per row, set where the low bits of the minimiser hash change — k_row_starts), so that a tile holds whole
 // minimiser partitions when the rows arrive grouped.  Only a hint: any cut is correct.  A tile that ends up
 // larger than the LDS arrays is worked off in chunks.
-static constexpr uint32_t LF_ROWS = 2560;
+static constexpr uint32_t LF_ROWS = 2560;                 // nominal rows per tile (SHK_TILE_ROWS overrides it: the tests cut small graphs into many tiles)
 __device__ __forceinline__ uint32_t next_row_start(const uint32_t *__restrict__ bits, uint32_t n_rows, uint32_t r0, int lane) {
     // wave-wide: the first row >= r0 whose start bit is set, looking 64 words (2048 rows) ahead; r0 if there is none
     if (r0 == 0u || r0 >= n_rows) return r0 < n_rows ? r0 : n_rows;
@@ -159,11 +159,11 @@ __device__ __forceinline__ uint32_t next_row_start(const uint32_t *__restrict__ 
     return r < n_rows ? r : n_rows;
 }
 // (first wave of the workgroup; the caller synchronises)
-__device__ __forceinline__ void tile_bounds(const uint32_t *__restrict__ bits, uint32_t n_rows, uint32_t *lo, uint32_t *hi) {
+__device__ __forceinline__ void tile_bounds(const uint32_t *__restrict__ bits, uint32_t n_rows, uint32_t tile_rows, uint32_t *lo, uint32_t *hi) {
     if (threadIdx.x < 64) {
         const int lane = (int)threadIdx.x;
-        const uint32_t a = next_row_start(bits, n_rows, blockIdx.x * LF_ROWS, lane);
-        const uint32_t b = blockIdx.x + 1u == gridDim.x ? n_rows : next_row_start(bits, n_rows, (blockIdx.x + 1u) * LF_ROWS, lane);
+        const uint32_t a = next_row_start(bits, n_rows, blockIdx.x * tile_rows, lane);
+        const uint32_t b = blockIdx.x + 1u == gridDim.x ? n_rows : next_row_start(bits, n_rows, (blockIdx.x + 1u) * tile_rows, lane);
         if (lane == 0) { *lo = a; *hi = b; }
     }
 }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_row_starts(const uint32_t *__restrict__
 }
 
 template <int W>
-__global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, const uint32_t *__restrict__ row_starts,
+__global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, const uint32_t *__restrict__ row_starts, uint32_t tile_rows,
                                                            const uint8_t *__restrict__ alive,
                                                            const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
                                                            FragRec *__restrict__ frag, uint32_t split_mask) {
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, cons
     __shared__ uint32_t l_cnt[LF_TILE];        // count; once passed: (local head << 13) | position in the fragment
     __shared__ uint16_t l_heads[LF_TILE];
     __shared__ uint32_t n_heads, t_lo, t_hi;
-    tile_bounds(row_starts, n_rows, &t_lo, &t_hi);
+    tile_bounds(row_starts, n_rows, tile_rows, &t_lo, &t_hi);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t hi = t_hi;
@@ -446,12 +446,12 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
 
 // ol[v]: {fragment head, position in the fragment} -> {chain record (NIL: none), position in the chain}.  Same tiles and
 // chunks as k_local_frag (a fragment never leaves its chunk); nodes that k_orphan_cycles re-homed are fragments of their own.
-__global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t n_rows, const uint32_t *__restrict__ row_starts,
+__global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t n_rows, const uint32_t *__restrict__ row_starts, uint32_t tile_rows,
                                                            uint2 *__restrict__ ol, const FragRec *__restrict__ frag,
                                                            const FinRec *__restrict__ fin) {
     __shared__ uint2 l_chain[LF_TILE];         // per local fragment head: {chain record, nodes of the chain before the fragment}
     __shared__ uint32_t t_lo, t_hi;
-    tile_bounds(row_starts, n_rows, &t_lo, &t_hi);
+    tile_bounds(row_starts, n_rows, tile_rows, &t_lo, &t_hi);
     __syncthreads();
     const uint32_t hi = t_hi;
     for (uint32_t c = t_lo; c < hi; c += LF_TILE / 2u) {

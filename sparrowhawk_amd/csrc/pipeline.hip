@@ -1182,8 +1182,9 @@ public:
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
                            alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
-        const int lf_grid = (int)((n + LF_ROWS - 1) / LF_ROWS);
-        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, alive_.p, winfo.p, ol.p, frag.p, split_mask);
+        const uint32_t tile_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_TILE_ROWS", LF_ROWS), 1), LF_TILE / 2u);
+        const int lf_grid = (int)((n + tile_rows - 1) / tile_rows);
+        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, winfo.p, ol.p, frag.p, split_mask);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1230,7 +1231,7 @@ public:
         hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, d_heads.p, slot_of.p, ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
         hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
-        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, ol.p, frag.p, fin.p);
+        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, ol.p, frag.p, fin.p);
         // rings: their smallest k-mer (these three return at once when there is none)
         hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
         hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);

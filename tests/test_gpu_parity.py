@@ -115,12 +115,17 @@ def test_circular_genome_with_and_without_splitters():
         assert "L\t1\t+\t1\t+\t30M" in out["outgfa"]
 
 
-@pytest.mark.parametrize("k,split_log", [(31, None), (31, "0"), (31, "2"), (31, "9"), (51, None), (51, "12"), (21, "1")])
-def test_many_circular_and_linear_replicons(k, split_log, monkeypatch):
+@pytest.mark.parametrize("k,split_log,tile_rows", [(31, None, None), (31, "0", None), (31, "2", "1"), (31, "9", "50"), (51, None, "7"),
+                                                  (51, "12", "1000"), (21, "1", None), (31, "14", "3"), (41, None, "129")])
+def test_many_circular_and_linear_replicons(k, split_log, tile_rows, monkeypatch):
     """Circular unitigs of every size next to linear ones, all on the device (SPEC S10): cycles with many sampled
-    splitters, with exactly one, with none (the sampling rate is moved around to force each), on both strands."""
+    splitters, with exactly one, with none (the sampling rate is moved around to force each), on both strands; the
+    LDS tiles of the fragment pass cut down to a few rows, so that fragments, rings and orphan rings cross many
+    tile edges (SHK_TILE_ROWS)."""
     if split_log is not None:
         monkeypatch.setenv("SHK_SPLIT_LOG", split_log)
+    if tile_rows is not None:
+        monkeypatch.setenv("SHK_TILE_ROWS", tile_rows)
     rng = np.random.default_rng(1000 + k)
     texts = []
     sizes = [k + 9, 64, 100, 333, 1000, 4000, 20000]
