@@ -244,11 +244,34 @@ static size_t next_record_start(const uint8_t *t, size_t n, size_t from) {
 // handled = false (and nothing counted) when the very first piece is not regular 4-line FASTQ: the caller
 // then runs the host parser over everything.  A later piece that is not regular is parsed on the host from
 // there to the end of its file, with the record numbers and progress of the whole file.
+// one_batch: the text fits one batch.  It is still cut into a few pieces so that piece i+1 travels while piece i is
+// parsed, but the packed pieces are kept and counted together as ONE batch at the end (pass 1 runs over the pieces
+// into the same slices: the partitioning of a single batch, no batch packing, no merge).
 static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1, const uint8_t *t2, size_t l2,
-                                    size_t n1, size_t total, bool &handled) {
+                                    size_t n1, size_t total, bool &handled, bool one_batch = false) {
     handled = false;
     std::string err;
-    const size_t piece_bytes = (size_t)(2 * batch_bases());
+    size_t piece_bytes = (size_t)(2 * batch_bases());
+    if (one_batch) {
+        const char *pv = getenv("SHK_FASTQ_PIECES");
+        const size_t C = (pv && *pv) ? (size_t)std::max<long long>(1, atoll(pv)) : 4;
+        piece_bytes = std::max<size_t>((l1 + (t2 ? l2 : 0)) / C, 1024);
+    }
+    std::vector<GpuPacked> kept;                          // one_batch: the parsed pieces, counted together
+    auto free_kept = [&]() { for (auto &g : kept) gpu_packed_free(g); kept.clear(); };
+    auto count_kept = [&]() -> int {
+        if (kept.empty()) return SHK_OK;
+        std::vector<DevPiece> pcs;
+        for (auto &g : kept) pcs.push_back(DevPiece{g.d_bases, g.d_seg_off, g.n_seg, g.n_bases});
+        std::string e2;
+        const double tc = now_ms();
+        h->batches_started++;
+        const int rc = h->pipe->count_batch_pieces(pcs.data(), pcs.size(), e2);
+        h->pipe->times().add("preprocess_device_total_host_clock", now_ms() - tc);
+        free_kept();
+        if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), e2);
+        return SHK_OK;
+    };
     struct Piece { int file; size_t off, end; bool host_rest; };
     std::vector<Piece> pieces;
     for (int f = 0; f < 2; f++) {
@@ -276,7 +299,7 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
     std::thread &uploader = upl.t;
     int up_rc = 0; std::string up_err;
     auto join_upload = [&]() { if (uploader.joinable()) uploader.join(); };
-    auto drop_all = [&]() { join_upload(); gpu_text_free(cur); gpu_text_free(nxt); };
+    auto drop_all = [&]() { join_upload(); gpu_text_free(cur); gpu_text_free(nxt); free_kept(); };
     // the rest of a file through the host parser (a piece that is not regular 4-line FASTQ, or no boundary found)
     auto host_rest = [&](const Piece &pc) -> int {
         const uint8_t *t = pc.file ? t2 : t1;
@@ -289,6 +312,7 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
         };
         int flush_rc = SHK_OK;
         auto flush = [&](PackedReads &p) -> int { flush_rc = flush_host_batch(h, p); return flush_rc ? -7 : 0; };
+        if (int rck = count_kept()) return rck;           // (one_batch: what the device parsed so far is a batch of its own now)
         if (!counted_any) h->pipe->expect_more_batches();
         int rc2 = pack_fastq(t + pc.off, len - pc.off, h->k, h->min_qual, pr, err, h->progress_every(), prog, 0, batch_bases(), flush, file_reads);
         if (rc2 == -7) return flush_rc;
@@ -322,18 +346,20 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
             });
         }
         GpuPacked gp;
+        const double tp0 = now_ms();
         int rc = gpu_pack_fastq(nullptr, 0, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), gp, err, reads_done, &cur);
+        h->pipe->times().add("fastq_piece_parse_host_clock", now_ms() - tp0);
         if (rc < 0) { gpu_packed_free(gp); drop_all(); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
         if (rc == 1) {
             gpu_packed_free(gp);
-            drop_all(); have_cur = false;
-            if (!counted_any) return SHK_OK;             // handled stays false
+            join_upload(); gpu_text_free(cur); gpu_text_free(nxt); have_cur = false;
+            if (!counted_any) { free_kept(); return SHK_OK; }             // handled stays false
             Piece rest = pc; rest.end = pc.file ? l2 : l1; rest.host_rest = true;
             if (int rc2 = host_rest(rest)) return rc2;
             while (i + 1 < pieces.size() && pieces[i + 1].file == pc.file) i++;      // the rest of this file is done
             continue;
         }
-        if (!counted_any) h->pipe->expect_more_batches();
+        if (!counted_any && !one_batch) h->pipe->expect_more_batches();
         h->pipe->times().add("fastq_h2d_text", gp.h2d_ms);
         h->pipe->times().add("fastq_device_kernels", gp.kernels_ms);
         h->pipe->times().add("fastq_device_pieces_x1", 1.0);
@@ -344,23 +370,30 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
             const uint64_t pct = total ? (100 * (done_before + pc.off + bytes)) / total : 100;
             h->post_mode(("loop:" + std::to_string(every * (gp.first_mark + j + 1)) + ":" + std::to_string(pct)).c_str());
         }
-        const int rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
+        int rc2 = SHK_OK;
         reads_done += gp.n_reads; file_reads += gp.n_reads;
-        gpu_packed_free(gp);
+        if (one_batch) { kept.push_back(gp); gp = GpuPacked(); }       // (counted with the other pieces at the end)
+        else {
+            rc2 = gp.n_seg ? count_one_batch(h, gp.d_bases, gp.d_seg_off, gp.n_seg, gp.n_bases) : SHK_OK;
+            gpu_packed_free(gp);
+        }
         if (rc2) { drop_all(); return rc2; }
         counted_any = true;
         // hand over to the uploaded next piece
+        const double tj0 = now_ms();
         join_upload();
+        h->pipe->times().add("fastq_piece_wait_for_upload_host_clock", now_ms() - tj0);
         gpu_text_free(cur); have_cur = false;
         if (prefetch) {
             if (up_rc) { gpu_text_free(nxt); return fail(h, up_rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, up_err); }
             cur = nxt; nxt = GpuText(); have_cur = true;
         }
     }
-    drop_all();
+    join_upload(); gpu_text_free(cur); gpu_text_free(nxt);
+    h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t0);
+    if (int rck = count_kept()) return rck;
     handled = true;
     h->n_reads = reads_done;
-    h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t0);
     return finish_counting(h);
 }
 
@@ -387,6 +420,20 @@ static int preprocess_impl(shk_handle *h, const uint8_t *fq1, size_t n1, const u
     }
     const size_t text_total = l1 + (fq2 ? l2 : 0);
     const char *force_host = getenv("SHK_HOST_PARSER");
+    // a single-batch text of some size: cut into pieces, piece i+1 uploaded while piece i is parsed (H2D is two thirds
+    // of this entry point), all counted as one batch
+    {
+        const char *mv = getenv("SHK_FASTQ_PIPELINE_MIN");
+        const size_t pipe_min = (mv && *mv) ? (size_t)strtoull(mv, nullptr, 10) : ((size_t)64 << 20);
+        if (!(force_host && *force_host == '1') && text_total / 2 <= batch_bases() && text_total >= pipe_min) {
+            bool handled = false;
+            int rc = preprocess_device_pieces(h, t1, l1, fq2 ? t2 : nullptr, l2, n1, total, handled, true);
+            if (rc || handled) return rc;
+            // (not regular 4-line FASTQ from the first piece on: the host parser below; the single-shot device path
+            // would find the same)
+            force_host = "1";
+        }
+    }
     if (!(force_host && *force_host == '1') && text_total / 2 <= batch_bases()) {
         const double t1c = now_ms();
         GpuPacked gp;

@@ -23,6 +23,9 @@ struct StageTimes {           // milliseconds (HIP events on the pipeline's stre
     void add(const std::string &k, double v) { ms[k] += v; }
 };
 
+// one piece of a batch of packed segments, already in device memory (offsets relative to its own d_bases)
+struct DevPiece { const uint32_t *d_bases, *d_seg_off; uint64_t n_seg, n_bases; };
+
 class IPipeline {
 public:
     virtual ~IPipeline() {}
@@ -32,6 +35,9 @@ public:
     // the same batch with the packed reads still in host memory (h_*): uploaded into d_* piece by piece, overlapped with pass 1
     virtual int count_batch_host(uint32_t *d_bases, uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
                                  uint64_t n_seg, uint64_t n_bases, std::string &err) = 0;
+    // ONE batch that lies in several pieces (a FASTQ text parsed piece by piece while the next piece was uploaded): pass 1
+    // runs over the pieces one after the other into the same slices
+    virtual int count_batch_pieces(const DevPiece *pieces, size_t n_pieces, std::string &err) = 0;
     // more batches will follow the first one (chunked / streamed input of unknown size): partition for the worst case
     virtual void expect_more_batches() = 0;
     // do_bloom (docs/src/assembly.md:18): partitions that go through the k-mer-level repartition pass a Bloom

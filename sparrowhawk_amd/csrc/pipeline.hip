@@ -377,6 +377,34 @@ public:
                          uint64_t n_seg, uint64_t n_bases, std::string &err) override {
         return count_batch_impl(d_bases, d_seg_off, h_bases, h_seg_off, n_seg, n_bases, err);
     }
+    int count_batch_pieces(const DevPiece *pieces, size_t n_pieces, std::string &err) override {
+        std::vector<DevPiece> list;
+        uint64_t n_seg = 0, n_bases = 0;
+        for (size_t i = 0; i < n_pieces; i++)
+            if (pieces[i].n_seg) { list.push_back(pieces[i]); n_seg += pieces[i].n_seg; n_bases += pieces[i].n_bases; }
+        if (list.empty()) return 0;
+        if (list.size() == 1) return count_batch_impl(list[0].d_bases, list[0].d_seg_off, nullptr, nullptr, n_seg, n_bases, err);
+        if (global_mode_) {                                        // (the cross-check path takes batches one by one)
+            for (const DevPiece &pc : list)
+                if (int rc = count_batch_impl(pc.d_bases, pc.d_seg_off, nullptr, nullptr, pc.n_seg, pc.n_bases, err)) return rc;
+            return 0;
+        }
+        piece_list_ = std::move(list);
+        struct Clear { std::vector<DevPiece> &v; ~Clear() { v.clear(); } } clear{piece_list_};
+        return count_batch_impl(piece_list_[0].d_bases, piece_list_[0].d_seg_off, nullptr, nullptr, n_seg, n_bases, err);
+    }
+    // pass 1 over the batch: one launch, or one per piece (count_batch_pieces) appending to the same slices
+    void launch_partition_all(int wblk, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg) {
+        if (piece_list_.empty()) {
+            if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
+            else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
+            return;
+        }
+        for (const DevPiece &pc : piece_list_) {
+            if (wblk == 16) launch_partition<16>(pc.d_bases, pc.d_seg_off, (uint32_t)pc.n_seg);
+            else launch_partition<8>(pc.d_bases, pc.d_seg_off, (uint32_t)pc.n_seg);
+        }
+    }
     int count_batch_impl(const uint32_t *d_bases, const uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
                          uint64_t n_seg, uint64_t n_bases, std::string &err) {
         if (h_bases && (global_mode_ || n_seg == 0)) {            // (nothing to overlap: plain upload first)
@@ -462,8 +490,7 @@ public:
                 cap = (uint64_t)(uint32_t)h[1] + 8;               // (the reads are on the device now: the retry is one launch)
                 continue;
             }
-            if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
-            else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
+            launch_partition_all(wblk, d_bases, d_seg_off, n_seg);
             HIPCHK(hipGetLastError());
             t.mark();
             unsigned long long h[2];
@@ -1298,6 +1325,7 @@ private:
     DevBuf<uint64_t> tkeys_[W]; DevBuf<uint32_t> tcnt_, tstate_; uint64_t tslots_ = 0;
     struct Batch { const uint32_t *bases, *seg_off; uint64_t n_seg; };
     std::vector<Batch> pending_;
+    std::vector<DevPiece> piece_list_;               // count_batch_pieces: the pieces of the batch being partitioned
     uint64_t total_instances_ = 0, n_distinct_ = 0, n_solid_ = 0;
     uint64_t histo_[500] = {0};
     // partitioned counting

@@ -548,6 +548,61 @@ def test_device_parser_takes_large_texts_in_pieces():
     assert e1.states == e2.states and e1.get_assembly() == e2.get_assembly() == ref.get_assembly()
 
 
+def test_single_batch_text_parsed_in_pieces_under_the_upload():
+    """A FASTQ text of one batch (from 64 MB; forced here on a small one) is cut at record boundaries, piece i + 1 is
+    uploaded while piece i is parsed, and the packed pieces are counted together as ONE batch (pass 1 over the
+    pieces into the same slices: no batch packing).  Everything observable equals the host parser's."""
+    g, fq = make_dataset(60000, 30, err=0.01, seed=79)
+    recs = fq.decode().split("\n")
+    for i in range(3, len(recs), 4 * 5):
+        recs[i] = "@" + recs[i][1:]                      # quality lines that start like headers
+    fq = "\n".join(recs).encode()
+    env = {"SHK_FASTQ_PIPELINE_MIN": 1, "SHK_FASTQ_PIECES": 5}
+    ref = product(fq, k=31, min_count=2, min_qual=0, csize=500)          # (the single-shot device path)
+    assert "fastq_device_pieces_x1" not in ref.timings()
+    a = _with_env(env, lambda: product(fq, k=31, min_count=2, min_qual=0, csize=500))
+    ta = a.timings()
+    assert ta.get("fastq_device_pieces_x1", 0) >= 4 and "batch_pack_kernel" not in ta and "batch_merge_kernel" not in ta
+    b = _with_env({**env, "SHK_HOST_PARSER": 1}, lambda: product(fq, k=31, min_count=2, min_qual=0, csize=500))
+    assert a.states == b.states == ref.states
+    assert a.get_assembly() == b.get_assembly() == ref.get_assembly()
+    assert a.get_preprocessing_info() == b.get_preprocessing_info() and a.total_instances == b.total_instances
+    compare_all(a, run_oracle([fq], k=31, min_count=2, min_qual=0))
+    # two files, the second one gzip, the first one without its last newline; two-word keys; one piece per file and more
+    cut = fq.rfind(b"\n@r", 0, len(fq) // 3) + 1
+    f1, f2 = fq[:cut].rstrip(b"\n"), gzip.compress(fq[cut:])
+    for pieces in (2, 7):
+        e = {**env, "SHK_FASTQ_PIECES": pieces}
+        c = _with_env(e, lambda: product(f1, f2, k=51, min_count=1, csize=700))
+        d = _with_env({**e, "SHK_HOST_PARSER": 1}, lambda: product(f1, f2, k=51, min_count=1, csize=700))
+        assert c.timings().get("fastq_device_pieces_x1", 0) >= 2
+        assert c.states == d.states and c.get_assembly() == d.get_assembly()
+    compare_all(c, run_oracle([f1, f2], k=51, min_count=1))
+    # a malformed record deep inside: same message; a blank line in a later piece: the pieces parsed so far are
+    # counted as a batch, the host parser takes the rest of the file, the result does not change
+    lines = fq.split(b"\n")
+    bad = list(lines)
+    bad[4 * 5000 + 2] = b"-"
+    bad = b"\n".join(bad)
+    msgs = []
+    for e in (env, {**env, "SHK_HOST_PARSER": 1}):
+        with pytest.raises(Exception) as ei:
+            _with_env(e, lambda: product(bad, k=31, min_count=2))
+        msgs.append(str(ei.value))
+    assert msgs[0] == msgs[1] and "5000" in msgs[0]
+    gap = list(lines)
+    gap.insert(4 * 9000, b"")
+    gap = b"\n".join(gap)
+    e1 = _with_env(env, lambda: product(gap, k=31, min_count=2, min_qual=0, csize=500))
+    e2 = _with_env({**env, "SHK_HOST_PARSER": 1}, lambda: product(gap, k=31, min_count=2, min_qual=0, csize=500))
+    assert e1.timings().get("fastq_device_pieces_x1", 0) >= 1 and e1.timings().get("fastq_parse_pack_host_clock", 0) == 0
+    assert e1.states == e2.states and e1.get_assembly() == e2.get_assembly() == ref.get_assembly()
+    # irregular from the first record on: the host parser does everything
+    first = b"\n" + fq
+    e3 = _with_env(env, lambda: product(first, k=31, min_count=2, min_qual=0))
+    assert "fastq_device_pieces_x1" not in e3.timings() and e3.get_assembly() == product(fq, k=31, min_count=2, min_qual=0).get_assembly()
+
+
 def test_threaded_output_writer_equals_the_serial_one():
     """Megabyte outputs are written by three threads into one buffer whose section offsets are measured
     first; forced here on a small fragmented assembly (many contigs, links) and compared byte for byte."""

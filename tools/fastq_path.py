@@ -12,13 +12,15 @@ fq = synth.to_fastq_fixed(codes, quals)
 nb = codes.size
 print("FASTQ bytes %.2f GB, bases %.0f M" % (len(fq) / 1e9, nb / 1e6), flush=True)
 del codes, quals
-for name, env, bb in (("device parser", "0", None), ("device, pieces", "0", str(1 << 27)), ("host parser", "1", None)):
+for name, env, bb in (("device, pipelined", "0", None), ("device, single shot", "0", "single"), ("device, batches", "0", str(1 << 27)), ("host parser", "1", None)):
     if os.environ.get("SKIP_HOST") == "1" and env == "1":
         continue
     if os.environ.get("ONLY_DEVICE") == "1" and bb:
         continue
     os.environ["SHK_HOST_PARSER"] = env
-    os.environ.pop("SHK_BATCH_BASES", None)
+    os.environ.pop("SHK_BATCH_BASES", None); os.environ.pop("SHK_FASTQ_PIPELINE_MIN", None)
+    if bb == "single":
+        os.environ["SHK_FASTQ_PIPELINE_MIN"] = str(1 << 60); bb = None   # the whole text uploaded, then parsed
     if bb:
         os.environ["SHK_BATCH_BASES"] = bb               # 256 MB of text per piece
     for it in range(2 if env == "0" else 1):
