@@ -255,7 +255,9 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
     if (one_batch) {
         const char *pv = getenv("SHK_FASTQ_PIECES");
         const size_t C = (pv && *pv) ? (size_t)std::max<long long>(1, atoll(pv)) : 4;
-        piece_bytes = std::max<size_t>((l1 + (t2 ? l2 : 0)) / C, 1024);
+        // the last piece is parsed with nothing left to upload: it is the small one (a tenth of the text)
+        const size_t tot = l1 + (t2 ? l2 : 0);
+        piece_bytes = std::max<size_t>(C >= 3 ? tot / 10 * 9 / (C - 1) : tot / C, 1024);
     }
     std::vector<GpuPacked> kept;                          // one_batch: the parsed pieces, counted together
     auto free_kept = [&]() { for (auto &g : kept) gpu_packed_free(g); kept.clear(); };
