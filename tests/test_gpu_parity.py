@@ -116,12 +116,13 @@ def test_circular_genome_with_and_without_splitters():
 
 
 @pytest.mark.parametrize("k,split_log,tile_rows", [(31, None, None), (31, "0", None), (31, "2", "1"), (31, "9", "50"), (51, None, "7"),
-                                                  (51, "12", "1000"), (21, "1", None), (31, "14", "3"), (41, None, "129")])
+                                                  (51, "12", "1000"), (21, "1", None), (31, "14", "3"), (41, None, "129"), (31, None, "4096"), (51, "3", "4000")])
 def test_many_circular_and_linear_replicons(k, split_log, tile_rows, monkeypatch):
     """Circular unitigs of every size next to linear ones, all on the device (SPEC S10): cycles with many sampled
     splitters, with exactly one, with none (the sampling rate is moved around to force each), on both strands; the
     LDS tiles of the fragment pass cut down to a few rows, so that fragments, rings and orphan rings cross many
-    tile edges (SHK_TILE_ROWS)."""
+    tile edges (SHK_TILE_ROWS); or as large as the LDS arrays, so that a tile whose edge moves on to the next partition
+    start overflows them and is worked off in chunks."""
     if split_log is not None:
         monkeypatch.setenv("SHK_SPLIT_LOG", split_log)
     if tile_rows is not None:
