@@ -609,29 +609,35 @@ __global__ __launch_bounds__(256) void k_ring_rot(Graph<W> g, HeadRec *__restric
     }
 }
 
-// per node: chain record -> output offset (~0 = chain not emitted)
+// per node: chain record -> output offset (~0 = chain not emitted).  One thread takes both orientations of a node:
+// one key load and one 16-byte read of ol for the two; the base an oriented node appends is the last base of its
+// k-mer (orientation 1: the complement of the first), so a reverse complement is only built for the first node of a
+// chain (which spells its whole k-mer).
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
                                               const uint2 *__restrict__ ol,
                                               const EmitRec *__restrict__ head_off,
                                               char *__restrict__ out) {
-    const uint32_t total = g.n * 2;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
-        if (!alive[v >> 1]) continue;
-        const uint2 own = ol[v];                           // {chain record, position in the chain} (k_tile_final)
-        if (own.x == NIL) continue;
-        const EmitRec er = head_off[own.x];
-        const unsigned long long off = er.off;
-        if (off == ~0ull) continue;
-        uint32_t pos = own.y;
-        if (er.rot) pos = pos >= er.rot ? pos - er.rot : pos + er.len - er.rot;    // a circular unitig starts at its smallest k-mer
-        const Kmer<W> x = g.seq(v);
-        char *dst = out + off;
-        const uint32_t ACGT = 0x54474341u;                 // 'A','C','G','T' little-endian
-        dst[g.k - 1 + pos] = (char)((ACGT >> (8 * km_last_base<W>(x))) & 0xFF);
-        if (pos == 0) {
-            for (int i = 0; i + 1 < g.k; i++) {
-                dst[i] = (char)((ACGT >> (8 * km_bits2<W>(x, 2 * (g.k - 1 - i)))) & 0xFF);
+    const uint32_t ACGT = 0x54474341u;                     // 'A','C','G','T' little-endian
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
+        if (!alive[i]) continue;
+        const uint4 o2 = *reinterpret_cast<const uint4 *>(&ol[2u * i]);      // {chain record, position in the chain} x 2 (k_tile_final)
+        if (o2.x == NIL && o2.z == NIL) continue;
+        const Kmer<W> x = g.keys.load(i);
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const uint32_t slot = o ? o2.z : o2.x;
+            if (slot == NIL) continue;
+            const EmitRec er = head_off[slot];
+            if (er.off == ~0ull) continue;
+            uint32_t pos = o ? o2.w : o2.y;
+            if (er.rot) pos = pos >= er.rot ? pos - er.rot : pos + er.len - er.rot;    // a circular unitig starts at its smallest k-mer
+            char *dst = out + er.off;
+            const uint32_t b = o ? 3u - km_bits2<W>(x, 2 * (g.k - 1)) : km_last_base<W>(x);
+            dst[g.k - 1 + pos] = (char)((ACGT >> (8 * b)) & 0xFF);
+            if (pos == 0) {
+                const Kmer<W> y = o ? km_revcomp<W>(x, g.k) : x;
+                for (int j = 0; j + 1 < g.k; j++) dst[j] = (char)((ACGT >> (8 * km_bits2<W>(y, 2 * (g.k - 1 - j)))) & 0xFF);
             }
         }
     }

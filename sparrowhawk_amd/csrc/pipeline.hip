@@ -1296,7 +1296,7 @@ public:
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
             HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * sizeof(EmitRec), hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
-            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, ol.p, d_off.p, d_out.p);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
