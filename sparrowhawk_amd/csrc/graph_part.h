@@ -260,10 +260,11 @@ __global__ __launch_bounds__(256) void k_gp_rows(const uint32_t *__restrict__ gp
             if (valid && p == lp) { my_leader = leader; rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)); gsize = (uint32_t)__popcll(same); }
             todo &= ~same;
         }
+        const uint32_t ro = valid ? roff[p] : 0u;              // (requested together with the reservation, not after it)
         uint32_t base = 0;
         if (valid && lane == my_leader) base = atomicAdd(&cursor[p], gsize);
         base = (uint32_t)__shfl((int)base, my_leader);
-        if (valid) rows[roff[p] + base + rank] = i;
+        if (valid) rows[ro + base + rank] = i;
     }
 }
 
@@ -522,19 +523,24 @@ template <int W>
 __global__ __launch_bounds__(256) void k_tip_candidates(Graph<W> g, const uint8_t *__restrict__ alive,
                                                         uint32_t *__restrict__ cand,
                                                         unsigned int *__restrict__ n_cand) {
+    // one thread per node, both orientations: the alive flag and the adjacency byte are requested together (one memory
+    // round trip per node)
     const int lane = threadIdx.x & 63;
-    const uint32_t total = g.n * 2;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (total + stride - 1) / stride * stride;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
-        bool p = false;
-        if (v < total && alive[v >> 1]) p = (g.indeg(v) == 0) && (g.outdeg(v) == 1);
-        const unsigned long long m = __ballot(p);
-        if (!m) continue;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
-        base = __shfl(base, 0);
-        if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    const uint32_t n_round = (g.n + stride - 1) / stride * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        uint32_t a = 0; bool al = false;
+        if (i < g.n) { a = g.adj[i]; al = alive[i] != 0; }
+#pragma unroll
+        for (uint32_t o = 0; o < 2; o++) {
+            const bool p = al && __popc(outmask_of(a, o ^ 1u)) == 0 && __popc(outmask_of(a, o)) == 1;
+            const unsigned long long m = __ballot(p);
+            if (!m) continue;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
+            base = __shfl(base, 0);
+            if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = 2u * i + o;
+        }
     }
 }
 
@@ -631,18 +637,21 @@ __global__ __launch_bounds__(256) void k_fork_candidates(Graph<W> g, const uint8
                                                          uint32_t *__restrict__ cand,
                                                          unsigned int *__restrict__ n_cand) {
     const int lane = threadIdx.x & 63;
-    const uint32_t total = g.n * 2;
     const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t n_round = (total + stride - 1) / stride * stride;
-    for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < n_round; v += stride) {
-        bool p = false;
-        if (v < total && alive[v >> 1]) p = g.outdeg(v) >= 2;
-        const unsigned long long m = __ballot(p);
-        if (!m) continue;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
-        base = __shfl(base, 0);
-        if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = v;
+    const uint32_t n_round = (g.n + stride - 1) / stride * stride;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
+        uint32_t a = 0; bool al = false;
+        if (i < g.n) { a = g.adj[i]; al = alive[i] != 0; }
+#pragma unroll
+        for (uint32_t o = 0; o < 2; o++) {
+            const bool p = al && __popc(outmask_of(a, o)) >= 2;
+            const unsigned long long m = __ballot(p);
+            if (!m) continue;
+            unsigned int base = 0;
+            if (lane == 0) base = atomicAdd(n_cand, (unsigned int)__popcll(m));
+            base = __shfl(base, 0);
+            if (p) cand[base + __popcll(m & ((1ull << lane) - 1ull))] = 2u * i + o;
+        }
     }
 }
 

@@ -1143,7 +1143,7 @@ public:
         for (int round = 0; round < 32; round++) {
             HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
             if (tips) {
-                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(2ull * n)), B, 0, stream_, g, alive_.p,
+                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
                                    cand.p, (unsigned int *)(ctl_.p + 3));
                 hipLaunchKernelGGL(k_tip_walk<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3),
                                    tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
@@ -1158,7 +1158,7 @@ public:
             }
             if (bubbles) {
                 HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
-                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(2ull * n)), B, 0, stream_, g, alive_.p,
+                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
                                    cand.p, (unsigned int *)(ctl_.p + 3));
                 hipLaunchKernelGGL(k_bubble<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3), mark.p);
                 HIPCHK(hipGetLastError());
