@@ -351,9 +351,28 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         if (!in_lds || KEYS_IN_LDS) gtab[t] = EMPTY64;
     }
     __syncthreads();
-    for (uint32_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
-        const uint32_t i = rows[r];
-        const Kmer<W> key = keys.load(i);
+    // A thread's rows (every 256th of the partition's list) are used twice — inserted here, expanded below.  Up to four
+    // per thread (1024 rows: every partition whose table fits the LDS) stay in registers: their ids and then their keys
+    // are requested in two rounds of independent loads, instead of two dependent loads per row in either phase.
+    constexpr int KEEP = 4;
+    const bool keep = W <= 2 && (r1 - r0) <= (uint32_t)KEEP * 256u;      // (uniform; wider keys: the registers cost more occupancy than the loads)
+    // (four named registers each, chosen by compare-and-select: an indexed array would live in scratch memory)
+    static_assert(KEEP == 4, "kept rows are four named registers");
+    const uint32_t rt = r0 + threadIdx.x;
+    const uint32_t i0 = (keep && rt < r1) ? rows[rt] : NIL, i1 = (keep && rt + 256u < r1) ? rows[rt + 256u] : NIL;
+    const uint32_t i2 = (keep && rt + 512u < r1) ? rows[rt + 512u] : NIL, i3 = (keep && rt + 768u < r1) ? rows[rt + 768u] : NIL;
+    const Kmer<W> k0 = i0 != NIL ? keys.load(i0) : km_zero<W>(), k1 = i1 != NIL ? keys.load(i1) : km_zero<W>();
+    const Kmer<W> k2 = i2 != NIL ? keys.load(i2) : km_zero<W>(), k3 = i3 != NIL ? keys.load(i3) : km_zero<W>();
+    auto kept_i = [=](uint32_t q) { return q == 0 ? i0 : (q == 1 ? i1 : (q == 2 ? i2 : i3)); };
+    auto kept_key = [=](uint32_t q) {
+        Kmer<W> r;
+#pragma unroll
+        for (int w = 0; w < W; w++) r.w[w] = q == 0 ? k0.w[w] : (q == 1 ? k1.w[w] : (q == 2 ? k2.w[w] : k3.w[w]));
+        return r;
+    };
+    for (uint32_t r = r0 + threadIdx.x, q = 0; r < r1; r += blockDim.x, q++) {
+        const uint32_t i = keep ? kept_i(q) : rows[r];
+        const Kmer<W> key = keep ? kept_key(q) : keys.load(i);
         const uint64_t h = gt_hash<W>(key);
         const uint64_t entry = (h & 0xFFFFFFFF00000000ull) | (uint64_t)i;
         uint32_t slot = (uint32_t)h & pmask;
@@ -379,14 +398,14 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
     const int lane = threadIdx.x & 63;
     const uint32_t n_rows = r1 - r0;
     const uint32_t n_round = (n_rows + blockDim.x - 1) / blockDim.x * blockDim.x;
-    for (uint32_t rr_ = threadIdx.x; rr_ < n_round; rr_ += blockDim.x) {
+    for (uint32_t rr_ = threadIdx.x, q = 0; rr_ < n_round; rr_ += blockDim.x, q++) {
         const bool act = rr_ < n_rows;
-        const uint32_t i = act ? rows[r0 + rr_] : 0u;
+        const uint32_t i = act ? (keep ? kept_i(q) : rows[r0 + rr_]) : 0u;
         Kmer<W> x = km_zero<W>(), rx = km_zero<W>();
         MinScan ms{};
         uint32_t out_b = 0, last_b = 0;
         if (act) {
-            x = keys.load(i);
+            x = keep ? kept_key(q) : keys.load(i);
             rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
             if (SHK_DBG(gt.dbg) != 2) ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);      // (2: timing experiment without the scan)
             out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer

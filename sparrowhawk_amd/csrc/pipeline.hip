@@ -1042,10 +1042,14 @@ public:
         for (int j = 0; j < W; j++) tkeys_[j].release();
         tcnt_.release(); tstate_.release(); tslots_ = 0;
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); shard_recv_ = nullptr; batches_.clear();
-        // graph partitions: 256-512 rows each (mini tables of <= 2048 slots fit 16 KB of LDS); the minimiser length is the counting pass's, so rows that
+        // graph partitions: 320-640 rows each on average (mini tables of <= 2048 slots fit 16 KB of LDS); the minimiser length is the counting pass's, so rows that
         // arrive grouped by counting partition are grouped by graph partition too
         gp_ = 64;
-        while (gp_ < 131072u && (uint64_t)gp_ * 512u < n) gp_ <<= 1;
+        // (measured, `profiles/r02_frag/graph_partition_rows.txt`: 610 rows per partition on average beat 305 — fewer workgroups, the
+        // same fixed cost each — while 790 and 980 lose to 400 and 490: partitions above 1024 rows need a table beyond the LDS
+        // one and work in global memory.  The average ends up in (320, 640].)
+        const uint64_t gp_rows_target = env_u64("SHK_GP_ROWS", 640);
+        while (gp_ < 131072u && (uint64_t)gp_ * gp_rows_target < n) gp_ <<= 1;
         gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
