@@ -109,6 +109,11 @@ def main():
                     help="sharded mode: 'lib' = RCCL inside the library (production); 'torch' = the same shk_shard_* "
                          "pieces driven by torch.distributed collectives (rehearsal with --backend gloo --one-gpu)")
     args = ap.parse_args()
+    # Everything that anything prints to stdout from here on (RCCL announces its version there when a communicator is
+    # created) goes to stderr: the contract is ONE JSON line on stdout, written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch                                         # before libshk_hip.so: one HIP runtime
     import torch.distributed as dist
@@ -345,7 +350,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.k <= 63:
             line["cpu_baseline"] = cpu_baseline(args.k, args.min_count, d_bases.cpu().numpy().view("uint32"),
                                                 d_seg.cpu().numpy().view("uint32"), n_bases, res["outfasta"])
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())          # the ONE line on the real stdout
     if sharded and hasattr(comm, "free"):
         comm.free()                                      # the library's RCCL communicator goes before torch's group
     if world > 1:
