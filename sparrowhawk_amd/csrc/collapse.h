@@ -171,11 +171,12 @@ __device__ __forceinline__ void tile_bounds(const uint32_t *__restrict__ bits, u
     }
 }
 __global__ __launch_bounds__(256) void k_row_starts(const uint32_t *__restrict__ gp_of, uint32_t n, uint32_t lowmask,
-                                                    uint32_t *__restrict__ bits) {
+                                                    uint32_t *__restrict__ bits, uint8_t *__restrict__ alive /* := 1 (instead of a fill) */) {
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t n_round = (n + 63u) & ~63u;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         const bool st = i < n && (i == 0u || ((gp_of[i] ^ gp_of[i - 1u]) & lowmask) != 0u);
+        if (i < n) alive[i] = 1;
         const unsigned long long m = __ballot(st);
         if ((threadIdx.x & 63) == 0) { bits[i >> 5] = (uint32_t)m; bits[(i >> 5) + 1u] = (uint32_t)(m >> 32); }
     }

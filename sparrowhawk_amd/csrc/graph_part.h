@@ -541,7 +541,9 @@ struct TipRec { uint32_t start, junction, len, next; unsigned long long sum; };
 template <int W>
 __global__ __launch_bounds__(256) void k_tip_candidates(Graph<W> g, const uint8_t *__restrict__ alive,
                                                         uint32_t *__restrict__ cand,
-                                                        unsigned int *__restrict__ n_cand) {
+                                                        unsigned int *__restrict__ n_cand,
+                                                        uint2 *__restrict__ init_tip_head /* first round: both entries of every node := NIL */,
+                                                        uint8_t *__restrict__ init_mark /* first round: := 0 */) {
     // one thread per node, both orientations: the alive flag and the adjacency byte are requested together (one memory
     // round trip per node)
     const int lane = threadIdx.x & 63;
@@ -549,7 +551,10 @@ __global__ __launch_bounds__(256) void k_tip_candidates(Graph<W> g, const uint8_
     const uint32_t n_round = (g.n + stride - 1) / stride * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         uint32_t a = 0; bool al = false;
-        if (i < g.n) { a = g.adj[i]; al = alive[i] != 0; }
+        if (i < g.n) {
+            a = g.adj[i]; al = alive[i] != 0;
+            if (init_tip_head) { uint2 nil; nil.x = NIL; nil.y = NIL; init_tip_head[i] = nil; init_mark[i] = 0; }   // (instead of two fills)
+        }
 #pragma unroll
         for (uint32_t o = 0; o < 2; o++) {
             const bool p = al && __popc(outmask_of(a, o ^ 1u)) == 0 && __popc(outmask_of(a, o)) == 1;

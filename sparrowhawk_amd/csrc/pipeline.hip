@@ -1067,8 +1067,8 @@ public:
         if (int rc = alive_.alloc(n, err)) return rc;
         if (int rc = row_starts_.alloc(((n + 63) / 64) * 2 + 2, err)) return rc;
         HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));   // (the mini tables are initialised by their builders)
-        HIPCHK(hipMemsetAsync(adj_.p, 0, adj_.n, stream_));
-        HIPCHK(hipMemsetAsync(alive_.p, 1, n ? n : 1, stream_));
+        // (no fills for adj_ and alive_: k_graph_local writes the adjacency byte of every row before k_graph_remote ORs
+        // into it, k_row_starts sets the alive flags)
         HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
         if (n) {
             Graph<W> g = graph_view();
@@ -1079,7 +1079,7 @@ public:
                                ctl_.p + 2);
             // where a group of rows with the same low minimiser-hash bits starts: the tile edges of the collapse (collapse.h)
             hipLaunchKernelGGL(k_row_starts, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, std::min<uint32_t>(gp_, 256u) - 1u,
-                               row_starts_.p);
+                               row_starts_.p, alive_.p);
             HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
@@ -1133,14 +1133,14 @@ public:
         if (int rc = cand.alloc(2ull * n, err)) return rc;
         if (int rc = removed.alloc(n, err)) return rc;
         if (int rc = mark.alloc(n, err)) return rc;
-        HIPCHK(hipMemsetAsync(mark.p, 0, n, stream_));
+        if (!tips) HIPCHK(hipMemsetAsync(mark.p, 0, n, stream_));       // (with tips: k_tip_candidates clears it in the first round)
         if (tips) {
             // every candidate may turn out to be a tip: sized for all oriented nodes, so that no count has to
             // come back to the host inside a round (the counters live in ctl_: 3 candidates, 4 tips, 5/6 removed)
             if (int rc = tip_head.alloc(2ull * n, err)) return rc;
             if (int rc = tiprec.alloc(2ull * n, err)) return rc;
             if (int rc = kill.alloc(2ull * n, err)) return rc;
-            HIPCHK(hipMemsetAsync(tip_head.p, 0xFF, 2ull * n * 4, stream_));
+            // (tip_head := NIL by k_tip_candidates in the first round)
         }
         EvTimer t(stream_);
         const dim3 G(1024), B(256);
@@ -1148,7 +1148,8 @@ public:
             HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
             if (tips) {
                 hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
-                                   cand.p, (unsigned int *)(ctl_.p + 3));
+                                   cand.p, (unsigned int *)(ctl_.p + 3), round == 0 ? (uint2 *)tip_head.p : (uint2 *)nullptr,
+                                   round == 0 ? mark.p : (uint8_t *)nullptr);
                 hipLaunchKernelGGL(k_tip_walk<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3),
                                    tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
                 hipLaunchKernelGGL(k_tip_decide<W>, G, B, 0, stream_, g, tiprec.p, (const unsigned int *)(ctl_.p + 4),
