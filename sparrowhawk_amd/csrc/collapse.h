@@ -57,7 +57,7 @@ template <int W> __device__ __forceinline__ bool node_key_less(const Graph<W> &g
 // handed to the fragment's nodes through LDS, and the kernels behind it (rings, emission) read ol alone.
 // Correct for any row order — a tile that holds no neighbours just makes one-node fragments — fast for the order
 // the counting pass produces.
-struct FragRec { uint32_t next, len, last, pad /* 1: the head of a linear chain */; unsigned long long sum; uint32_t owner, base; };
+struct FragRec { uint32_t next, len, last, chain_head /* 1: the fragment starts a linear chain */; unsigned long long sum; uint32_t owner, base; };
 static_assert(sizeof(FragRec) == 32, "FragRec is one 32-byte record");
 static constexpr int LF_THREADS = 1024, LF_ITEMS = 8;
 static constexpr uint32_t LF_TILE = LF_THREADS * LF_ITEMS;        // 8192 oriented nodes: 64 KB of LDS, two workgroups per CU
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, cons
             const uint32_t v = base + j;
             FragRec f; f.next = winfo[base + cur].x; f.len = pos; f.last = base + cur; f.sum = sum; f.base = 0;
             const bool chain_head = winfo[v ^ 1u].x == NIL;            // no simple predecessor: the first node of a linear chain
-            f.pad = chain_head ? 1u : 0u;
+            f.chain_head = chain_head ? 1u : 0u;
             f.owner = (chain_head || node_sampled(v, split_mask)) ? ol[v].x : NIL;   // a splitter's index (k_succ_split)
             frag[v] = f;
         }
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__
         uint32_t cur = s, len = 0, nxt, last, is_head = 0;
         unsigned long long sum = 0;
         for (;;) {
-            const uint4 a = *reinterpret_cast<const uint4 *>(&frag[cur]);            // next, len, last, pad
+            const uint4 a = *reinterpret_cast<const uint4 *>(&frag[cur]);            // next, len, last, chain_head
             if (cur == s) is_head = a.w;
             const unsigned long long fs = frag[cur].sum;
             if (cur != s) { uint2 ob; ob.x = i; ob.y = len; *reinterpret_cast<uint2 *>(&frag[cur].owner) = ob; }
