@@ -268,6 +268,20 @@ __global__ __launch_bounds__(256) void k_gp_rows(const uint32_t *__restrict__ gp
     }
 }
 
+// rows -> the order of the row lists (rows[r] is the old id of new row r); the lists become the identity
+template <int W>
+__global__ __launch_bounds__(256) void k_regroup_rows(KeyArr<W> keys, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ gp_of,
+                                                      uint32_t *__restrict__ rows, uint32_t n, KeyArr<W> out_keys,
+                                                      uint32_t *__restrict__ out_cnt, uint32_t *__restrict__ out_gp_of) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const uint32_t i = rows[r];
+        out_keys.store(r, keys.load(i));
+        out_cnt[r] = cnt[i];
+        out_gp_of[r] = gp_of[i];
+        rows[r] = r;
+    }
+}
+
 // membership probe in partition p's table
 template <int W>
 __device__ __forceinline__ uint32_t gt_lookup_in(const GraphTable &gt, const KeyArr<W> &keys, const Kmer<W> &q,

@@ -663,6 +663,8 @@ public:
             HIPCHK(stream_wait(stream_));          // one host round trip: counters, histogram and the timer
             ms_out = t.elapsed();
             const uint32_t n_ovf = (uint32_t)h[3];
+            // rows written by the bucket path are ordered by key hash, not grouped by minimiser partition (build_graph regroups)
+            rows_scattered_ = (uint64_t)n_ovf * 4u > n_parts;
             if (n_ovf) {
                 EvTimer t2(stream_);
                 std::vector<OvfRec> ov(n_ovf);
@@ -1077,13 +1079,32 @@ public:
                                gp_of.p, gp_cnt.p);
             hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, gp_roff.p,
                                ctl_.p + 2);
-            // where a group of rows with the same low minimiser-hash bits starts: the tile edges of the collapse (collapse.h)
-            hipLaunchKernelGGL(k_row_starts, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, std::min<uint32_t>(gp_, 256u) - 1u,
-                               row_starts_.p, alive_.p);
             HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
             HIPCHK(hipGetLastError());
+            const uint64_t regroup_env = env_u64("SHK_REGROUP_ROWS", 2);        // 0 never, 1 always, 2 when the rows are scattered
+            if (regroup_env == 1 || (regroup_env == 2 && rows_scattered_)) {
+                // The rows are not grouped by minimiser partition (they came out of the bucket path in key-hash order): move them
+                // into the order of the row lists once.  Every later pass finds a partition's rows side by side again — the key
+                // reads of k_graph_local coalesce, the LDS tiles of the collapse hold neighbours — and the lists become the identity.
+                DevBuf<uint64_t> nk[W]; DevBuf<uint32_t> nc, ngp;
+                for (int j = 0; j < W; j++) if (int rc = nk[j].alloc(n, err)) return rc;
+                if (int rc = nc.alloc(n, err)) return rc;
+                if (int rc = ngp.alloc(n, err)) return rc;
+                KeyArr<W> out_keys; for (int j = 0; j < W; j++) out_keys.w[j] = nk[j].p;
+                hipLaunchKernelGGL(k_regroup_rows<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, scnt_.p, gp_of.p, gp_rows.p, (uint32_t)n,
+                                   out_keys, nc.p, ngp.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(stream_wait(stream_));                          // (the old arrays go back to the pool below)
+                for (int j = 0; j < W; j++) skeys_[j].swap(nk[j]);
+                scnt_.swap(nc); gp_of.swap(ngp);
+                g = graph_view();
+                times_.add("graph_rows_regrouped_x1", 1.0);
+            }
+            // where a group of rows with the same low minimiser-hash bits starts: the tile edges of the collapse (collapse.h)
+            hipLaunchKernelGGL(k_row_starts, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, std::min<uint32_t>(gp_, 256u) - 1u,
+                               row_starts_.p, alive_.p);
             t.stop_later("graph_table_kernel", pending_timers_);
             EvTimer t2(stream_);
             hipLaunchKernelGGL(k_graph_local<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
@@ -1345,6 +1366,7 @@ private:
     const void *shard_recv_ = nullptr;
     DevBuf<uint64_t> ekeys_[W]; DevBuf<uint32_t> ecnt_;
     uint64_t n_emitted_ = 0; uint32_t emit_threshold_ = 0;
+    bool rows_scattered_ = false;                    // most rows came out of the k-mer-level repartition (run_count_partitions)
     // solid set / graph
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
     DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
