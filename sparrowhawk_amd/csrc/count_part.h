@@ -446,6 +446,7 @@ struct CountCtlCore {                                   // what the table, the e
 struct CountCtl : CountCtlCore {                        // + the run table of a partition (k_count_partitions)
     uint32_t pre[257];                                  // exclusive prefix of slice fills (G <= 256)
     unsigned long long roff[256];                       // address/16 of every run's first record (copied once: no dependent global load per fetch)
+    uint32_t next_pi;                                   // the partition after the current one (grabbed from the launch's work counter)
 };
 
 // Table placement hash: add/shift/xor only (Jenkins one-at-a-time finaliser); integer multiplies
@@ -776,6 +777,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     const uint32_t *__restrict__ part_list /* nullable: partitions to process */,
     OvfRec *__restrict__ ovf /* nullable: partitions that do not fit are listed here instead of being split */,
     uint32_t *__restrict__ ovf_n,
+    uint32_t *__restrict__ work_counter /* zero at launch: partitions beyond a workgroup's first one are handed out in order
+                            of demand (partition sizes follow the minimiser distribution: with a fixed share of 16 each the
+                            slowest workgroup decides) */,
     uint32_t probe_blocks, uint32_t defer_after /* != 0: workgroups start in order, so the first ones act as a sample
                             of the partitions (partition = minimiser hash).  ovf_n[1] counts the partitions that were
                             really tried (low 16 bits) and those of them that overflowed (high 16 bits); a workgroup
@@ -807,8 +811,10 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     };
     uint32_t nx_cnt; unsigned long long nx_addr;
     load_runs(blockIdx.x, nx_cnt, nx_addr);
-  for (uint32_t pi = blockIdx.x; pi < n_parts; pi += gridDim.x) {
+  uint32_t pi_next = 0;
+  for (uint32_t pi = blockIdx.x; pi < n_parts; pi = pi_next) {
     const uint32_t p = part_list ? part_list[pi] : pi;
+    if (threadIdx.x == 0) ctl.next_pi = gridDim.x + atomicAdd(work_counter, 1u);     // (read after the two barriers below)
     // exclusive prefix of the run lengths of this partition (S_runs <= 256: threads 0..255, one run each)
     {
         const uint32_t f = nx_cnt;
@@ -837,7 +843,8 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         }
     }
     __syncthreads();
-    load_runs(pi + gridDim.x, nx_cnt, nx_addr);          // the next partition's run table: in flight during this one
+    pi_next = ctl.next_pi;                               // (into a register: thread 0 writes the word again at the top of the next turn)
+    load_runs(pi_next, nx_cnt, nx_addr);                 // the next partition's run table: in flight during this one
    [&]() {                                              // one partition; `return` = done with it
     const uint32_t R = ctl.pre[S_runs];
     // a k-mer count can only reach 2^32 (SPEC S4: saturating) in a partition of >= 2^32 instances = R x (<= 64 per record)

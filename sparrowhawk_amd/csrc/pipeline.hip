@@ -654,7 +654,7 @@ public:
             hipLaunchKernelGGL(k_count_partitions<W>, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
-                               (uint32_t *)(ctl_.p + 3), n_probe / 2, n_probe / 8);
+                               (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_probe / 2, n_probe / 8);
             HIPCHK(hipGetLastError());
             t.mark();
             unsigned long long h[4];
@@ -755,7 +755,7 @@ public:
                     HIPCHK(hipMemcpyAsync(d_list.p, bad.data(), bad.size() * 4, hipMemcpyHostToDevice, stream_));
                     hipLaunchKernelGGL(k_count_partitions<W>, dim3(std::min<uint32_t>((uint32_t)bad.size(), (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, (uint32_t)bad.size(), threshold,
                                        dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
-                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
+                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)d_list.p, (OvfRec *)nullptr, (uint32_t *)nullptr, (uint32_t *)(ctl_.p + 12), 0u, 0u);
                     HIPCHK(hipGetLastError());
                 }
                 ms_out += t2.stop();
