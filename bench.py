@@ -7,8 +7,9 @@ histogram -> filter) -> shk_assemble (graph -> correct -> collapse -> contigs + 
 host) -> shk_get_assembly.  Workload at N=1: BASELINE.json configs[1] — one 5 Mbp isolate,
 100x coverage of 150 bp reads (3 333 334 reads, 500 Mbases), k=31, min_count=5.
 
-Launch: python bench.py --gpus N --steps K --warmup W           (N=1)
-        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1)
+Launch: python bench.py --gpus N --steps K --warmup W           (any N: for N > 1 without a launcher the script
+                                                                 starts its own N ranks as child processes)
+        python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, under a launcher)
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -109,6 +110,22 @@ def main():
                     help="sharded mode: 'lib' = RCCL inside the library (production); 'torch' = the same shk_shard_* "
                          "pieces driven by torch.distributed collectives (rehearsal with --backend gloo --one-gpu)")
     args = ap.parse_args()
+    # ---- N > 1 without a launcher: `python bench.py --gpus N` starts its own N ranks — as FRESH child processes of
+    # torch.distributed.run, before this process has imported torch or touched the GPU (a process that has initialised
+    # the GPU must never exec or be replaced) — hands their stdout through (rank 0's ONE JSON line) and exits with
+    # their code.  Under a launcher (WORLD_SIZE set by torch.distributed.run) this is skipped.
+    if args.gpus > 1 and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes (see the task's environment notes)
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     # Everything that anything prints to stdout from here on (RCCL announces its version there when a communicator is
     # created) goes to stderr: the contract is ONE JSON line on stdout, written to the saved descriptor at the end.
     sys.stdout.flush()

@@ -781,6 +781,27 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     std::string err;
     auto cfail = [&](int rc) { return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); };
     const double t0 = now_ms();
+    // A failure on ONE rank (device memory, a slice that overflows, a partition beyond 2^32 records: all depend on that
+    // rank's share of the reads) must not leave the others blocked in the next collective: every local step's result
+    // travels with the next small collective — as an extra element of one that exists anyway, or as a one-word
+    // all-reduce in front of the two big exchanges — and all ranks leave together.  A collective that fails itself
+    // marks the communicator broken (shk_comm_free then aborts it: peers fail fast).
+    auto peer_failed = [&](const char *stage) {
+        return fail(h, SHK_E_DEVICE, std::string("shard_preprocess: another rank failed during ") + stage + " (this rank's state is intact up to there; free the handle)");
+    };
+    // SHK_FAULT_INJECT=<step> (pass1 | pack | count | rows | alloc) makes that local step of THIS process fail: the tests
+    // set it on one rank to see every rank leave with an error instead of hanging.  It never changes a result.
+    const char *inject = getenv("SHK_FAULT_INJECT");
+    auto injected = [&](const char *step) -> int {
+        return (inject && !strcmp(inject, step)) ? fail(h, SHK_E_INTERNAL, std::string("injected fault (SHK_FAULT_INJECT=") + step + ")") : SHK_OK;
+    };
+    auto agree = [&](int local_rc, const char *stage) -> int {
+        uint64_t f = local_rc ? 1u : 0u;
+        std::string e2;
+        if (int rc = comm_allreduce_host_u64(c, &f, 1, st, e2)) { if (local_rc) return local_rc; err = e2; return cfail(rc); }
+        if (local_rc) return local_rc;
+        return f ? peer_failed(stage) : SHK_OK;
+    };
     // ---- the partition count must be the same everywhere: from the global instance count
     if (n_partitions == 0) {
         uint64_t inst = n_bases > n_seg * (uint64_t)(h->k - 1) ? n_bases - n_seg * (uint64_t)(h->k - 1) : 0;
@@ -790,25 +811,39 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     if (n_partitions < world) return fail(h, SHK_E_PARAM, "shard_preprocess: fewer partitions than ranks");
     const uint32_t P = n_partitions;
     // ---- pass 1 on this rank's reads
-    std::vector<uint64_t> part(P, 0);
-    if (int rc = shard_partition_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads, P, part.data())) return rc;
+    std::vector<uint64_t> part((size_t)P + 1, 0);          // [P] = this rank failed
+    int rc_p1 = shard_partition_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads, P, part.data());
+    if (!rc_p1) rc_p1 = injected("pass1");
+    part[P] = rc_p1 ? 1u : 0u;
     // ---- the size exchange: every rank learns what every rank holds per partition
-    std::vector<uint64_t> all((size_t)world * P);
-    if (int rc = comm_allgather_host_u64(c, part.data(), P, all.data(), st, err)) return cfail(rc);
+    std::vector<uint64_t> all_raw((size_t)world * (P + 1)), all((size_t)world * P);
+    if (int rc = comm_allgather_host_u64(c, part.data(), (size_t)P + 1, all_raw.data(), st, err)) { if (rc_p1) return rc_p1; return cfail(rc); }
+    if (rc_p1) return rc_p1;
+    for (uint32_t r = 0; r < world; r++) {
+        if (all_raw[(size_t)r * (P + 1) + P]) return peer_failed("pass 1");
+        memcpy(&all[(size_t)r * P], &all_raw[(size_t)r * (P + 1)], (size_t)P * 8);
+    }
     ExchangePlan plan;
-    if (int rc = plan_exchange(all.data(), world, P, rank, plan, err)) return cfail(rc);
     const uint64_t rec_bytes = (uint64_t)h->pipe->rec_words() * 8u;
     uint64_t n_send = 0, n_recv = 0;
-    for (uint32_t r = 0; r < world; r++) { n_send += plan.send_counts[r]; n_recv += plan.recv_counts[r]; }
     // ---- pack (destination-major) and exchange
     struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, gk[4], gc;
     // (declared after the blocks, so it runs before they go back to the pool: on every way out — errors included —
     // the stream is drained first; the pool has no stream-ordering bookkeeping)
     struct DrainOnExit { void *st; ~DrainOnExit() { std::string e; (void)device_stream_sync(st, e); } } drain{st};
-    send.bytes = (size_t)(n_send * rec_bytes + 64); send.p = device_pool_alloc(send.bytes);
-    recv.bytes = (size_t)(n_recv * rec_bytes + 64); recv.p = device_pool_alloc(recv.bytes);
-    if (!send.p || !recv.p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
-    if (int rc = shard_pack_impl(h, send.p, plan.base.data(), P)) return rc;
+    {
+        int rc_pack = SHK_OK;
+        if (int rc = plan_exchange(all.data(), world, P, rank, plan, err)) rc_pack = cfail(rc);
+        if (!rc_pack) {
+            for (uint32_t r = 0; r < world; r++) { n_send += plan.send_counts[r]; n_recv += plan.recv_counts[r]; }
+            send.bytes = (size_t)(n_send * rec_bytes + 64); send.p = device_pool_alloc(send.bytes);
+            recv.bytes = (size_t)(n_recv * rec_bytes + 64); recv.p = device_pool_alloc(recv.bytes);
+            if (!send.p || !recv.p) rc_pack = fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
+        }
+        if (!rc_pack) rc_pack = shard_pack_impl(h, send.p, plan.base.data(), P);
+        if (!rc_pack) rc_pack = injected("pack");
+        if (int rc = agree(rc_pack, "the packing of the records")) return rc;
+    }
     {
         std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
         uint64_t a = 0, b = 0;
@@ -818,35 +853,52 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         }
         const double tx = now_ms();
         if (int rc = comm_alltoallv(c, send.p, so.data(), sb.data(), recv.p, ro.data(), rb.data(), st, err)) return cfail(rc);
-        if (int rc = device_stream_sync(st, err)) return cfail(rc);
+        if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
         h->pipe->times().add("shard_exchange_host_clock", now_ms() - tx);
         h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * rec_bytes) / 1e6);
     }
     device_pool_release(send.p, send.bytes); send.p = nullptr;
-    // ---- pass 2 over the owned partitions, then the global histogram
-    uint64_t red[SHK_HISTO_BINS + 1] = {0};
-    if (int rc = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
-                                  &red[SHK_HISTO_BINS])) return rc;
-    if (int rc = comm_allreduce_host_u64(c, red, SHK_HISTO_BINS + 1, st, err)) return cfail(rc);
+    // ---- pass 2 over the owned partitions, then the global histogram ([501] = ranks that failed)
+    uint64_t red[SHK_HISTO_BINS + 2] = {0};
+    int rc_cnt = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
+                                  &red[SHK_HISTO_BINS]);
+    if (!rc_cnt) rc_cnt = injected("count");
+    if (rc_cnt) memset(red, 0, sizeof red);
+    red[SHK_HISTO_BINS + 1] = rc_cnt ? 1u : 0u;
+    if (int rc = comm_allreduce_host_u64(c, red, SHK_HISTO_BINS + 2, st, err)) { if (rc_cnt) return rc_cnt; return cfail(rc); }
+    if (rc_cnt) return rc_cnt;
+    if (red[SHK_HISTO_BINS + 1]) return peer_failed("pass 2");
     // ---- fit / filter (identical on every rank), local solid rows
     const void *keys[4] = {nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
     uint64_t n_local = 0; uint32_t used = 0;
-    if (int rc = shard_rows_impl(h, red, keys, &cnt, &n_local, &used)) return rc;
+    int rc_rows = shard_rows_impl(h, red, keys, &cnt, &n_local, &used);
+    if (!rc_rows) rc_rows = injected("rows");
     // ---- all-gather of the solid rows
-    std::vector<uint64_t> counts(world);
-    if (int rc = comm_allgather_host_u64(c, &n_local, 1, counts.data(), st, err)) return cfail(rc);
+    std::vector<uint64_t> counts2((size_t)world * 2), counts(world);
+    const uint64_t mine2[2] = {rc_rows ? 0u : n_local, rc_rows ? 1u : 0u};
+    if (int rc = comm_allgather_host_u64(c, mine2, 2, counts2.data(), st, err)) { if (rc_rows) return rc_rows; return cfail(rc); }
+    if (rc_rows) return rc_rows;
+    for (uint32_t r = 0; r < world; r++) { if (counts2[2 * r + 1]) return peer_failed("the filter"); counts[r] = counts2[2 * r]; }
     uint64_t n_total = 0;
     std::vector<uint64_t> off8(world), len8(world), off4(world), len4(world);
     for (uint32_t r = 0; r < world; r++) { off8[r] = n_total * 8; len8[r] = counts[r] * 8; off4[r] = n_total * 4; len4[r] = counts[r] * 4; n_total += counts[r]; }
-    for (uint32_t j = 0; j < W; j++) {
-        gk[j].bytes = (size_t)(n_total * 8 + 64); gk[j].p = device_pool_alloc(gk[j].bytes);
-        if (!gk[j].p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
-        if (int rc = comm_allgatherv(c, keys[j], gk[j].p, off8.data(), len8.data(), st, err)) return cfail(rc);
+    {
+        int rc_alloc = SHK_OK;
+        for (uint32_t j = 0; j < W && !rc_alloc; j++) {
+            gk[j].bytes = (size_t)(n_total * 8 + 64); gk[j].p = device_pool_alloc(gk[j].bytes);
+            if (!gk[j].p) rc_alloc = fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
+        }
+        if (!rc_alloc) {
+            gc.bytes = (size_t)(n_total * 4 + 64); gc.p = device_pool_alloc(gc.bytes);
+            if (!gc.p) rc_alloc = fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
+        }
+        if (!rc_alloc) rc_alloc = injected("alloc");
+        if (int rc = agree(rc_alloc, "the allocation of the solid set")) return rc;
     }
-    gc.bytes = (size_t)(n_total * 4 + 64); gc.p = device_pool_alloc(gc.bytes);
-    if (!gc.p) return fail(h, SHK_E_OOM, "shard_preprocess: device memory for the solid set");
+    for (uint32_t j = 0; j < W; j++)
+        if (int rc = comm_allgatherv(c, keys[j], gk[j].p, off8.data(), len8.data(), st, err)) return cfail(rc);
     if (int rc = comm_allgatherv(c, cnt, gc.p, off4.data(), len4.data(), st, err)) return cfail(rc);
-    if (int rc = device_stream_sync(st, err)) return cfail(rc);
+    if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
     const void *kp[4] = {gk[0].p, gk[1].p, gk[2].p, gk[3].p};
     if (int rc = shard_set_solid_impl(h, kp, gc.p, n_total, red[SHK_HISTO_BINS])) return rc;
     h->pipe->times().add("shard_preprocess_host_clock", now_ms() - t0);

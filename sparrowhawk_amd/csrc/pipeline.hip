@@ -462,6 +462,9 @@ public:
                 const uint64_t n_words = (n_bases + 15) / 16 + 1;
                 std::vector<hipEvent_t> evs((size_t)C, nullptr);
                 struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto e : v) if (e) (void)hipEventDestroy(e); } } evg{evs};
+                // on every way out, errors included, the copy stream is idle: the caller's host buffers and the device
+                // blocks (which go back to a pool without stream-ordering bookkeeping) are no longer read or written
+                struct CopyDrain { hipStream_t s; ~CopyDrain() { (void)hipStreamSynchronize(s); } } copy_drain{copy_stream_};
                 for (uint64_t c = 0; c < C; c++) {
                     const uint64_t s0 = n_seg * c / C, s1 = n_seg * (c + 1) / C;
                     const uint64_t w0 = h_seg_off[s0] >> 4, w1 = std::min<uint64_t>(n_words, (((uint64_t)h_seg_off[s1] + 15) >> 4) + 1);
@@ -669,9 +672,17 @@ public:
                 EvTimer t2(stream_);
                 std::vector<OvfRec> ov(n_ovf);
                 HIPCHK(hipMemcpy(ov.data(), d_ovf.p, (size_t)n_ovf * sizeof(OvfRec), hipMemcpyDeviceToHost));
-                std::vector<OvfItem> items(n_ovf);
+                std::vector<OvfItem> items;
+                items.reserve(n_ovf);
+                std::vector<uint32_t> bad;
                 uint32_t n_untried = 0;
                 for (uint32_t i = 0; i < n_ovf; i++) {
+                    // A partition of >= 2^32 instances may hold a k-mer whose count saturates (SPEC S4).  The bucket path
+                    // counts without the saturating add and keeps 32-bit bucket cursors: such a giant is re-run by residue
+                    // classes in k_count_partitions instead, whose inserts saturate (R >= 2^26 there).
+                    if (ov[i].instances >= 0xFFFFFFF0ull) { bad.push_back(ov[i].p); continue; }
+                    items.emplace_back();
+                    OvfItem &item = items.back();
                     // buckets sized by INSTANCES (1.1 table sizes each, any F): the distinct/instance estimate of the
                     // aborted round is biased high (repeats show up late), and a bucket that turns out to hold
                     // too many distinct k-mers only costs itself a second pass over its own k-mer list
@@ -683,12 +694,11 @@ public:
                     // (Bloom mode: at least one sighting per distinct k-mer never reaches the buckets — error-rich
                     // partitions are mostly singletons — so the regions start at the instance count, not 1.5 x it)
                     const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", bloom ? 100 : 150) / (100ull * F) + 256;   // 50 % slack
-                    items[i].p = ov[i].p; items[i].F = F; items[i].cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
-                    items[i].pad = 0; items[i].base = 0;
+                    item.p = ov[i].p; item.F = F; item.cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
+                    item.pad = 0; item.base = 0;
                 }
                 // scatter + count; an item whose bucket region overflows (a Poisson tail of heavy k-mers in one
                 // bucket) is scattered again with twice the room, at most three times, then re-run by residue classes
-                std::vector<uint32_t> bad;
                 size_t n_good_total = 0;
                 const int max_passes = (int)env_u64("SHK_OVF_MAX_PASSES", 4);
                 for (int pass = 0; pass < max_passes && !items.empty(); pass++) {

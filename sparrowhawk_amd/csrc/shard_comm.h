@@ -23,6 +23,10 @@ void comm_destroy(ShardComm *c);
 int comm_rank(const ShardComm *c);
 int comm_world(const ShardComm *c);
 int comm_device(const ShardComm *c);
+// a rank that cannot go on (a collective failed locally): comm_destroy will abort the communicator (ncclCommAbort)
+// instead of destroying it, so peers blocked in a collective fail fast
+void comm_mark_broken(ShardComm *c);
+std::string comm_async_error(ShardComm *c);           // ncclCommGetAsyncError as text; "" when there is none
 
 // All operate on device memory and are enqueued on `stream` (a hipStream_t); none of them waits for the stream.
 // sum of n uint64 over the ranks, in place

@@ -24,6 +24,8 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                       // optional (a stand-in library may lack it)
+    ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t *) = nullptr;   // optional
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -46,12 +48,18 @@ Rccl &rccl() {
         const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         void *h = nullptr;
         const char *over = getenv("SHK_RCCL_LIBRARY");
+        // (dlerror() hands its message out once and clears it: one call per failure)
         if (over && *over) {
             h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
-            if (!h) { r.why = std::string("SHK_RCCL_LIBRARY: ") + (dlerror() ? dlerror() : "cannot be loaded"); return; }
+            if (!h) { const char *e = dlerror(); r.why = std::string("SHK_RCCL_LIBRARY: ") + (e ? e : "cannot be loaded"); return; }
         }
-        for (const char *n : names) { if (h) break; h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); }
-        if (!h) { r.why = std::string("librccl.so.1 not found: ") + (dlerror() ? dlerror() : ""); return; }
+        std::string last;
+        for (const char *n : names) {
+            if (h) break;
+            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (!h) { const char *e = dlerror(); last = e ? e : "cannot be loaded"; }
+        }
+        if (!h) { r.why = "librccl.so.1 not found: " + last; return; }
         auto sym = [&](const char *n) -> void * { void *p = dlsym(h, n); if (!p && r.why.empty()) r.why = std::string("librccl lacks ") + n; return p; };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
@@ -65,6 +73,8 @@ Rccl &rccl() {
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
         r.ok = r.why.empty();
+        r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
+        r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
     });
     return r;
 }
@@ -74,19 +84,27 @@ Rccl &rccl() {
 struct ShardComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
+    // staging of the small host-side collectives, allocated with the communicator: a rank that runs out of device
+    // memory later can still take part in them (the error agreement of shk_shard_preprocess rides on them)
+    void *stage = nullptr; size_t stage_bytes = 0;
+    bool broken = false;                   // a collective failed: the communicator is aborted, not destroyed
 };
 
+// (a failed collective leaves the communicator in an undefined state: it is marked and later aborted, so that
+// peers blocked in the same collective fail fast instead of waiting for this rank for ever)
 #define RCCLCHK(call)                                                                         \
     do {                                                                                      \
         const ncclResult_t _r = (call);                                                       \
         if (_r != ncclSuccess) {                                                              \
             err = std::string(#call) + ": " + (R.GetErrorString ? R.GetErrorString(_r) : "?"); \
+            if (c) c->broken = true;                                                          \
             return -5;                                                                        \
         }                                                                                     \
     } while (0)
 
 int comm_unique_id(uint8_t id[SHARD_UNIQUE_ID_BYTES], std::string &err) {
     Rccl &R = rccl();
+    ShardComm *c = nullptr;
     if (!R.ok) { err = R.why; return -5; }
     ncclUniqueId u;
     RCCLCHK(R.GetUniqueId(&u));
@@ -109,14 +127,36 @@ ShardComm *comm_create(const uint8_t id[SHARD_UNIQUE_ID_BYTES], int rank, int wo
         err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "?");
         delete c; return nullptr;
     }
+    // room for the largest small collective: world x (PART_MAX_P + 2) counts, plus this rank's contribution
+    c->stage_bytes = ((size_t)world + 1) * (16384 + 8) * 8;
+    if (hipMalloc(&c->stage, c->stage_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        err = "out of device memory (communicator staging)";
+        (void)R.CommDestroy(c->comm); delete c; return nullptr;
+    }
     return c;
 }
 
 void comm_destroy(ShardComm *c) {
     if (!c) return;
     Rccl &R = rccl();
-    if (c->comm && R.ok) (void)R.CommDestroy(c->comm);
+    if (c->comm && R.ok) {
+        if (c->broken && R.CommAbort) (void)R.CommAbort(c->comm);
+        else (void)R.CommDestroy(c->comm);
+    }
+    if (c->stage) (void)hipFree(c->stage);
     delete c;
+}
+void comm_mark_broken(ShardComm *c) { if (c) c->broken = true; }
+// an error RCCL found asynchronously (a peer that died, a link that failed): "" when there is none or the
+// library cannot tell
+std::string comm_async_error(ShardComm *c) {
+    Rccl &R = rccl();
+    if (!c || !R.ok || !R.CommGetAsyncError) return "";
+    ncclResult_t ar = ncclSuccess;
+    if (R.CommGetAsyncError(c->comm, &ar) != ncclSuccess || ar == ncclSuccess || ar == ncclInProgress) return "";
+    c->broken = true;
+    return std::string("RCCL asynchronous error: ") + (R.GetErrorString ? R.GetErrorString(ar) : "?");
 }
 int comm_rank(const ShardComm *c) { return c ? c->rank : 0; }
 int comm_world(const ShardComm *c) { return c ? c->world : 1; }
@@ -176,34 +216,40 @@ int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64
 namespace {
 struct PoolBlock {
     void *p = nullptr; size_t bytes = 0;
-    explicit PoolBlock(size_t b) : bytes(b ? b : 8) { p = device_pool_alloc(bytes); }
+    explicit PoolBlock(size_t b, bool unused = false) : bytes(b ? b : 8) { if (!unused) p = device_pool_alloc(bytes); }
     ~PoolBlock() { if (p) device_pool_release(p, bytes); }
 };
 }  // namespace
 
 int comm_allreduce_host_u64(ShardComm *c, uint64_t *host_inout, size_t n, void *stream, std::string &err) {
     if (!n) return 0;
-    PoolBlock b(n * 8);
-    if (!b.p) { err = "device allocation failed (all-reduce staging)"; return -4; }
+    if (!c) { err = "comm: not initialised"; return -1; }
+    PoolBlock b(n * 8 <= c->stage_bytes ? 0 : n * 8, n * 8 <= c->stage_bytes);
+    void *buf = n * 8 <= c->stage_bytes ? c->stage : b.p;
+    if (!buf) { err = "device allocation failed (all-reduce staging)"; return -4; }
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemcpyAsync(b.p, host_inout, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
-    if (int rc = comm_allreduce_u64(c, b.p, n, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
-    if (hipMemcpyAsync(host_inout, b.p, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        err = std::string("all-reduce: ") + hipGetErrorString(hipGetLastError()); return -5;
+    if (hipMemcpyAsync(buf, host_inout, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
+    if (int rc = comm_allreduce_u64(c, buf, n, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
+    if (hipMemcpyAsync(host_inout, buf, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        err = std::string("all-reduce: ") + hipGetErrorString(hipGetLastError()); c->broken = true; return -5;
     }
     return 0;
 }
 
 int comm_allgather_host_u64(ShardComm *c, const uint64_t *host_in, size_t n, uint64_t *host_out, void *stream, std::string &err) {
     if (!n) return 0;
+    if (!c) { err = "comm: not initialised"; return -1; }
     const size_t world = (size_t)comm_world(c);
-    PoolBlock in(n * 8), out(n * 8 * world);
-    if (!in.p || !out.p) { err = "device allocation failed (all-gather staging)"; return -4; }
+    const bool fits = n * 8 * (world + 1) <= c->stage_bytes;
+    PoolBlock blk(fits ? 0 : n * 8 * (world + 1), fits);
+    char *base = fits ? (char *)c->stage : (char *)blk.p;
+    if (!base) { err = "device allocation failed (all-gather staging)"; return -4; }
+    void *in = base, *out = base + n * 8;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemcpyAsync(in.p, host_in, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
-    if (int rc = comm_allgather(c, in.p, out.p, n * 8, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
-    if (hipMemcpyAsync(host_out, out.p, n * 8 * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        err = std::string("all-gather: ") + hipGetErrorString(hipGetLastError()); return -5;
+    if (hipMemcpyAsync(in, host_in, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
+    if (int rc = comm_allgather(c, in, out, n * 8, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
+    if (hipMemcpyAsync(host_out, out, n * 8 * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+        err = std::string("all-gather: ") + hipGetErrorString(hipGetLastError()); c->broken = true; return -5;
     }
     return 0;
 }

@@ -139,17 +139,26 @@ class LibComm:
         self._L = _lib.load()
         self._c = None
         ident = (C.c_uint8 * 128)()
+        status, why = 0, ""
         if rank == 0:
             if self._L.shk_comm_unique_id(ident) != 0:
-                raise ShkError(-5, self._L.shk_comm_error().decode())
+                status, why = 1, self._L.shk_comm_error().decode()
         if world > 1:
+            # Every rank takes part in the broadcast whatever happened on rank 0: the id travels with a status byte
+            # (129 bytes), and a failure is raised on EVERY rank after it — the callers' next collective
+            # ("did all communicators come up?") then still matches across ranks.
             import torch
             import torch.distributed as dist
-            t = torch.tensor(list(bytes(ident)), dtype=torch.uint8)
+            t = torch.tensor(list(bytes(ident)) + [status], dtype=torch.uint8)
             if dist.get_backend(group) == "nccl":
                 t = t.cuda()
             dist.broadcast(t, src=0, group=group)
-            ident = (C.c_uint8 * 128)(*t.cpu().tolist())
+            got = t.cpu().tolist()
+            ident = (C.c_uint8 * 128)(*got[:128])
+            if got[128] and rank != 0:
+                status, why = 1, "rank 0 could not create the RCCL unique id"
+        if status:
+            raise ShkError(-5, why)
         self._c = self._L.shk_comm_init(ident, int(rank), int(world))
         if not self._c:
             raise ShkError(-5, self._L.shk_comm_error().decode())

@@ -110,8 +110,21 @@ def main():
         d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
         torch.cuda.synchronize()
         h = AssemblyHelper.new(k, True, cfg["min_count"], cfg["min_qual"], 0, False, cfg["do_fit"], False, False)
-        sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm,
-                                n_partitions=cfg.get("P") or 0)
+        inj = cfg.get("inject")                        # {"rank": r, "step": s}: that rank's local step fails (SHK_FAULT_INJECT)
+        if inj and inj["rank"] == rank:
+            os.environ["SHK_FAULT_INJECT"] = inj["step"]
+        try:
+            sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm,
+                                    n_partitions=cfg.get("P") or 0)
+        except ShkError as e:
+            # every rank must get here together (the error agreement inside shk_shard_preprocess): none may hang
+            with open(f"{out_path}.{rank}", "w") as f:
+                json.dump({"error": str(e), "code": e.code}, f)
+            h.free()
+            comm.free()
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         h.assemble()
         res = {"pre": h.get_preprocessing_info(), "asm": h.get_assembly(), "states": h.states,
                "total_instances": h.total_instances, "timings": h.timings()}

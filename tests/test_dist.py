@@ -258,3 +258,55 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
         assert r["pre"] == o.preprocessing_json() and r["asm"] == o.assembly_json()
         assert r["total_instances"] == o.total_instances
         assert r["timings"]["shard_exchange_sent_MB"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,step,bad_rank", [(2, "pass1", 1), (3, "pack", 2), (2, "count", 0), (3, "rows", 1), (2, "alloc", 1)])
+def test_a_failure_on_one_rank_ends_the_collective_call_on_every_rank(world, step, bad_rank):
+    """A local failure on ONE rank of shk_shard_preprocess (device memory, a slice or partition that overflows: all
+    depend on that rank's share of the reads) must not leave the other ranks blocked in the next collective: the
+    failure travels with the next small collective and every rank returns an error.  SHK_FAULT_INJECT makes the
+    named local step fail on one process; the launch would time out if a rank hung."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset
+    g, fq = make_dataset(30000, 30, err=0.01, seed=77)
+    os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fqp = os.path.join(d, "reads.fq")
+            open(fqp, "wb").write(fq)
+            cfgp = os.path.join(d, "cfg.json")
+            json.dump({"fastq": fqp, "k": 31, "min_count": 3, "min_qual": 20, "do_fit": False, "P": 64,
+                       "inject": {"rank": bad_rank, "step": step}}, open(cfgp, "w"))
+            out = os.path.join(d, "res")
+            launch(world, ["rccl", out, cfgp], 29780 + world, timeout=180)
+            res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    finally:
+        os.environ.pop("SHK_RCCL_LIBRARY", None)
+    for r, x in enumerate(res):
+        assert "error" in x, (r, x)
+        if r == bad_rank:
+            assert "injected fault" in x["error"]
+        else:
+            assert "another rank failed" in x["error"]
+
+
+def test_a_missing_rccl_library_is_an_error_not_a_crash():
+    """ADVICE r2: dlerror() clears its message when read — reading it twice handed std::string a null pointer and the
+    process died instead of returning SHK_E_DEVICE.  Runs in a child (the library resolves RCCL once per process)."""
+    code = r'''
+import os, sys
+sys.path.insert(0, os.environ["SHK_ROOT"])
+import ctypes as C
+from sparrowhawk_amd import _lib
+L = _lib.load()
+ident = (C.c_uint8 * 128)()
+rc = L.shk_comm_unique_id(ident)
+msg = L.shk_comm_error().decode()
+assert rc != 0 and "SHK_RCCL_LIBRARY" in msg and "nonexistent" in msg, (rc, msg)
+assert not L.shk_comm_init(ident, 0, 1)
+print("OK", msg)
+'''
+    env = dict(os.environ, SHK_ROOT=ROOT, SHK_RCCL_LIBRARY="/nonexistent/librccl.so.1")
+    pr = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
+    assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]

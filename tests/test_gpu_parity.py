@@ -629,16 +629,20 @@ def test_long_reads_are_split_into_overlapping_segments():
         assert h.total_instances == 2 * (len(seq) - k + 1)
 
 
-def test_counts_saturate_at_u32_max():
+@pytest.mark.parametrize("P,genome", [(64, 3000), (1, 20000)])
+def test_counts_saturate_at_u32_max(P, genome):
     """SPEC S4: counts are u32 and saturate at 0xFFFFFFFF.  Forced through the shard layer's run tables: the
     same packed records are listed 256 times as the runs of their partition (weights via repeated records),
-    so a poly-A 31-mer seen 2^24 + a bit times counts past 2^32, while every other count is 256 x the oracle's."""
+    so a poly-A 31-mer seen 2^24 + a bit times counts past 2^32, while every other count is 256 x the oracle's.
+    P = 1, 20 000 distinct k-mers: the one partition does not fit the LDS table AND holds >= 2^32 instances — it
+    must not go through the k-mer-level repartition (no saturating add, 32-bit bucket cursors) but through the
+    residue-class re-runs, which saturate."""
     import ctypes as C
     import torch
     from sparrowhawk_amd import pack_fastq
     k, reps = 31, 256
     n_polya = (1 << 24) // 120 + 50                       # 120 windows per 150-base read: just past 2^24 instances
-    g, fq_small = make_dataset(3000, 20, seed=91)
+    g, fq_small = make_dataset(genome, 20, seed=91)
     polya = b"".join(b"@a%d\n%s\n+\n%s\n" % (i, b"A" * 150, b"I" * 150) for i in range(n_polya))
     fq = fq_small + polya
     o = run_oracle([fq], k=k, min_count=0, min_qual=0)
@@ -650,7 +654,6 @@ def test_counts_saturate_at_u32_max():
     torch.cuda.synchronize()
     h = AssemblyHelper.new(k, True, 0, 0, 0, False, False, False, False)
     L = h._L
-    P = 64
     part = np.zeros(P, dtype=np.uint64)
     h._check(L.shk_shard_partition(h._h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, P, part.ctypes.data))
     rec_bytes = L.shk_shard_record_bytes(h._h)
@@ -664,6 +667,8 @@ def test_counts_saturate_at_u32_max():
     inst = C.c_uint64(0)
     h._check(L.shk_shard_count(h._h, send.data_ptr(), run_off.ctypes.data, run_cnt.ctypes.data, P, reps, histo.ctypes.data, C.byref(inst)))
     assert inst.value == reps * o.total_instances
+    if P == 1:
+        assert h.timings().get("count_residue_rerun_x1", 0) == 1 and h.timings().get("count_repartitioned_x1", 0) == 0
     keys = (C.c_void_p * 1)()
     cnt = C.c_void_p()
     n_rows, used = C.c_uint64(0), C.c_uint32(0)
