@@ -198,3 +198,102 @@ def test_output_formats():
     j = json.loads(o.assembly_json())
     assert list(j.keys()) == ["outfasta", "ncontigs", "outdot", "outgfa", "outgfav2"]
     assert j["outfasta"] == o.fasta() and j["ncontigs"] == 4
+
+
+# ---- the graph stages (SPEC S8-S11) against a brute-force Python graph written from the SPEC alone -------------
+def _random_graph_case(rng, case):
+    """<= 3 kbp of sequence built to exercise the correction and collapse rules: substitution errors (tips at read
+    ends, bubbles inside), exact and inverted repeats (forks, hairpins), circular plasmids (rings), low coverage
+    (dead ends, gaps).  Returns (fastq bytes, k, min_count, flags)."""
+    k = int(rng.choice([15, 17, 21, 25, 31, 33, 41]))
+    L = int(rng.integers(300, 3001 if case % 8 == 0 else 1501))
+    g = "".join(rng.choice(list("ACGT"), L))
+    style = case % 6
+    if style in (1, 4):                                   # a direct repeat longer than k
+        r = int(rng.integers(k + 1, 4 * k)); a = int(rng.integers(0, L - r)); b = int(rng.integers(0, L - r))
+        g = g[:b] + g[a:a + r] + g[b + r:]
+    if style in (2, 4):                                   # an inverted repeat (hairpin stem)
+        r = int(rng.integers(k + 1, 3 * k)); a = int(rng.integers(0, L - r)); b = int(rng.integers(0, L - r))
+        g = g[:b] + revcomp(g[a:a + r]) + g[b + r:]
+    replicons = [(g, False)]
+    if style in (3, 4, 5):                                # plasmids: rings, some shorter than a read
+        for _ in range(int(rng.integers(1, 4))):
+            pl = int(rng.integers(k + 2, 400))
+            replicons.append(("".join(rng.choice(list("ACGT"), pl)), True))
+    if style == 5:                                        # a tandem repeat: a ring glued into the chromosome
+        u = "".join(rng.choice(list("ACGT"), int(rng.integers(k + 1, 3 * k))))
+        p = int(rng.integers(0, L)); replicons[0] = (g[:p] + u * int(rng.integers(2, 5)) + g[p:], False)
+    cov = float(rng.choice([6, 10, 16, 30]))
+    err = float(rng.choice([0.0, 0.003, 0.01, 0.03]))
+    rl = int(rng.choice([60, 100, 150]))
+    recs = []
+    for seq, circ in replicons:
+        n = max(2, int(len(seq) * cov / rl))
+        for i in range(n):
+            if circ:
+                s0 = int(rng.integers(0, len(seq)))
+                ext = seq * (rl // len(seq) + 2)
+                rd = ext[s0:s0 + rl]
+            else:
+                ll = min(rl, len(seq))
+                s0 = int(rng.integers(0, len(seq) - ll + 1))
+                rd = seq[s0:s0 + ll]
+            rd = list(rd)
+            for j in range(len(rd)):
+                if rng.random() < err:
+                    rd[j] = "ACGT"[("ACGT".index(rd[j]) + int(rng.integers(1, 4))) % 4]
+            rd = "".join(rd)
+            if rng.random() < 0.5:
+                rd = revcomp(rd)
+            recs.append(f"@r{len(recs)}\n{rd}\n+\n{'I' * len(rd)}\n")
+    min_count = int(rng.choice([0, 1, 1, 2, 3]))
+    flags = dict(no_bubble_collapse=bool(case % 7 == 3), no_dead_end_removal=bool(case % 11 == 5))
+    return "".join(recs).encode(), k, min_count, flags
+
+
+def _int_to_kmer(v, k):
+    return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_graph_stages_against_a_brute_force_python_graph(block):
+    """VERDICT r2 'weak' 2: S8-S10 of the oracle were pinned only by hand cases and by cpu_mt.cpp (same author, same
+    SPEC).  tests/pygraph.py is a third restatement that shares nothing with them — strings for k-mers, explicit
+    oriented nodes, the rules of S9/S10 spelled literally.  320 random inputs (40 per block) with errors, repeats,
+    hairpins, plasmids and tandem rings: initial adjacency bytes, the node set after correction, the ordered contig
+    list with its count sums, the FASTA and the GFA1 (links included) must be identical."""
+    from pygraph import PyGraph
+    rng = np.random.default_rng(7000 + block)
+    stats = dict(tips=0, bubbles=0, rings=0, contigs=0, links=0)
+    for case in range(block * 40, block * 40 + 40):
+        fq, k, min_count, flags = _random_graph_case(rng, case)
+        W = (2 * k + 63) // 64
+        counts = {}                                       # (every base is ACGT at quality 'I': S2 masks nothing)
+        for rd, _q in parse_fastq(fq):
+            for i in range(len(rd) - k + 1):
+                s = rd[i:i + k]
+                r = revcomp(s)
+                x = s if s < r else r
+                counts[x] = counts.get(x, 0) + 1
+        pg = PyGraph(counts, k, min_count)
+        o = run_oracle([fq], k=k, min_count=min_count, min_qual=0, **flags)
+        keys, cnt = o.solid()
+        ok = [_int_to_kmer(sum(int(keys[i, j]) << (64 * j) for j in range(W)), k) for i in range(len(cnt))]
+        assert ok == sorted(pg.alive), f"case {case}: solid sets differ"
+        assert [int(c) for c in cnt] == [pg.count[x] for x in ok]
+        assert o.adjacency().tolist() == [pg.adjacency_byte(x) for x in ok], f"case {case}: initial adjacency differs"
+        pg.correct(tips=not flags["no_dead_end_removal"], bubbles=not flags["no_bubble_collapse"])
+        o.assemble()
+        assert [bool(a) for a in o.alive()] == [x in pg.alive for x in ok], f"case {case}: node set after correction differs"
+        assert o.adjacency().tolist() == [pg.adjacency_byte(x) if x in pg.alive else a for x, a in zip(ok, o.adjacency().tolist())], \
+            f"case {case}: adjacency after correction differs"
+        contigs, fasta, gfa = pg.assembly()
+        assert o.contigs() == [s for s, _ in contigs], f"case {case}: contigs differ"
+        assert [int(x) for x in o.contig_kc()] == [kc for _, kc in contigs]
+        assert o.fasta() == fasta and o.gfa1() == gfa, f"case {case}: FASTA / GFA1 differ"
+        assert (o.tips_removed, o.bubbles_removed) == (pg.tips_removed, pg.bubbles_removed), f"case {case}: removal counts differ"
+        stats["tips"] += pg.tips_removed; stats["bubbles"] += pg.bubbles_removed
+        stats["rings"] += pg.n_rings
+        stats["contigs"] += len(contigs); stats["links"] += gfa.count("\nL\t")
+    # the campaign really exercises every rule
+    assert stats["tips"] > 0 and stats["bubbles"] > 0 and stats["rings"] > 0 and stats["links"] > 0, stats
