@@ -181,6 +181,7 @@ def _mt():
             "cpumt_hardware_threads": (C.c_uint, []), "cpumt_new": (vp, [u32, u32]), "cpumt_free": (None, [vp]),
             "cpumt_threads": (u32, [vp]), "cpumt_count": (None, [vp, vp, vp, u64, u32]),
             "cpumt_total_instances": (u64, [vp]), "cpumt_histo": (None, [vp, vp]), "cpumt_filter": (C.c_int, [vp, u32]),
+            "cpumt_count_times": (None, [vp, vp, vp]), "cpumt_set_threads": (None, [vp, u32]),
             "cpumt_n_solid": (u64, [vp]), "cpumt_get_solid": (None, [vp, vp, vp]),
             "cpumt_assemble": (None, [vp, C.c_int, C.c_int]), "cpumt_n_contigs": (u64, [vp]), "cpumt_fasta": (cp, [vp]),
         }.items():
@@ -222,6 +223,16 @@ class CpuMt:
 
     @property
     def total_instances(self): return self.L.cpumt_total_instances(self.h)
+
+    def set_threads(self, threads):
+        self.L.cpumt_set_threads(self.h, threads)
+        self.threads = self.L.cpumt_threads(self.h)
+
+    def count_times(self):
+        """seconds of the last count(): (scatter into partitions, per-partition tables)"""
+        a, b = C.c_double(0), C.c_double(0)
+        self.L.cpumt_count_times(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     def histo(self):
         h = np.zeros(500, dtype=np.uint64)

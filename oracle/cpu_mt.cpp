@@ -16,9 +16,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <functional>
 #include <mutex>
 #include <string>
@@ -74,101 +76,146 @@ template <typename K> struct Asm {
     K canonical(K f, int *o) const { const K r = revcomp(f); if (r < f) { *o = 1; return r; } *o = 0; return f; }
 
     // ---------------------------------------------------------------- count
+    // Two-pass radix scatter into ONE arena (round 2 kept threads x 512 growing std::vectors: 256 threads fighting the
+    // allocator, 67 M k-mers/s).  Pass A: every thread walks its static share of the segments and counts its k-mers per
+    // partition (partition = top bits of the key hash).  Prefix sums give every (partition, thread) its exact range of
+    // the arena.  Pass B: the same walk again, k-mers written through small per-partition write-combining buffers (one
+    // cache line each) to their final place.  Then every partition — contiguous in the arena — is counted by one thread
+    // in an open-addressing table that fits its cache.
+    template <typename F> void run_threads(unsigned T, F &&fn) {
+        std::vector<std::thread> ts;
+        for (unsigned t = 1; t < T; t++) ts.emplace_back([&fn, t] { fn(t); });
+        fn(0u);
+        for (auto &t : ts) t.join();
+    }
+    template <typename F> void walk_segments(const uint32_t *bases, const uint32_t *seg_off, size_t s0, size_t s1, F &&emit) const {
+        const int sh = 2 * (k - 1);
+        for (size_t s = s0; s < s1; s++) {
+            const uint64_t lo = seg_off[s], hi = seg_off[s + 1];
+            if (hi - lo < (uint64_t)k) continue;
+            K f = 0, r = 0;
+            uint64_t i = lo;
+            uint32_t word = bases[i >> 4] >> (2 * (i & 15));
+            for (; i < hi; i++) {
+                if ((i & 15) == 0) word = bases[i >> 4];
+                const uint32_t c = word & 3u; word >>= 2;
+                f = ((f << 2) | (K)c) & mask;
+                r = (r >> 2) | ((K)(3u - c) << sh);
+                if (i - lo + 1 >= (uint64_t)k) emit(f < r ? f : r);
+            }
+        }
+    }
+    double t_scatter = 0, t_tables = 0;                          // seconds, of the last count()
+    // The arena is kept between calls (a service counts sample after sample) and asked to be backed by huge pages:
+    // 3.2 GB of first-touch 4 KB page faults from 256 threads serialise in the kernel (the scatter did not scale
+    // beyond 32 threads with a fresh malloc per call).
+    void *arena_mem = nullptr; size_t arena_bytes = 0;
+    K *get_arena(size_t n) {
+        const size_t want = ((n + 1) * sizeof(K) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+        if (want > arena_bytes) {
+            if (arena_mem) free(arena_mem);
+            arena_mem = aligned_alloc((size_t)2 << 20, want);
+            arena_bytes = arena_mem ? want : 0;
+            if (arena_mem) {
+                (void)madvise(arena_mem, want, MADV_HUGEPAGE);
+                // first touch in parallel, one huge page at a time
+                const size_t pages = want >> 21;
+                std::atomic<size_t> next{0};
+                run_threads(std::min<unsigned>(threads, 64u), [&](unsigned) {
+                    for (;;) { const size_t i = next.fetch_add(1); if (i >= pages) break; memset((char *)arena_mem + (i << 21), 0, (size_t)1 << 21); }
+                });
+            }
+        }
+        return (K *)arena_mem;
+    }
+    ~Asm() { if (arena_mem) free(arena_mem); }
     void count(const uint32_t *bases, const uint32_t *seg_off, uint64_t n_seg, uint32_t emit_threshold) {
         emit_thr = emit_threshold;
-        constexpr unsigned PB = 9, P = 1u << PB;
-        std::vector<std::vector<std::vector<K>>> buf(threads, std::vector<std::vector<K>>(P));
-        std::atomic<unsigned> tid{0};
-        std::atomic<uint64_t> inst{0};
-        auto base_at = [&](uint64_t i) -> uint32_t { return (bases[i >> 4] >> (2 * (i & 15))) & 3u; };
+        const auto c0 = std::chrono::steady_clock::now();
+        constexpr unsigned PB = 12, P = 1u << PB;                // 4096 partitions: ~100 k instances each at 400 M
+        const unsigned T = threads;
+        std::vector<uint64_t> cnt_tp((size_t)T * P, 0);         // [thread][partition]
+        auto share = [&](unsigned t, size_t &s0, size_t &s1) { s0 = (size_t)(n_seg * t / T); s1 = (size_t)(n_seg * (t + 1) / T); };
+        run_threads(T, [&](unsigned t) {
+            size_t s0, s1; share(t, s0, s1);
+            uint64_t *mine = &cnt_tp[(size_t)t * P];
+            walk_segments(bases, seg_off, s0, s1, [&](K x) { mine[KeyOps<K>::hash(x) >> (64 - PB)]++; });
+        });
+        // arena layout: partition-major, inside a partition thread-major
+        std::vector<uint64_t> pbase(P + 1, 0);
         {
-            std::atomic<size_t> next{0};
-            auto body = [&] {
-                const unsigned me = tid.fetch_add(1);
-                auto &mine = buf[me];
-                uint64_t local = 0;
-                const int sh = 2 * (k - 1);
-                for (;;) {
-                    const size_t a = next.fetch_add(4096);
-                    if (a >= n_seg) break;
-                    const size_t b = std::min<size_t>(n_seg, a + 4096);
-                    for (size_t s = a; s < b; s++) {
-                        const uint64_t lo = seg_off[s], hi = seg_off[s + 1];
-                        if (hi - lo < (uint64_t)k) continue;
-                        K f = 0, r = 0;
-                        for (uint64_t i = lo; i < hi; i++) {
-                            const uint32_t c = base_at(i);
-                            f = ((f << 2) | (K)c) & mask;
-                            r = (r >> 2) | ((K)(3u - c) << sh);
-                            if (i - lo + 1 >= (uint64_t)k) {
-                                const K x = f < r ? f : r;
-                                mine[KeyOps<K>::hash(x) >> (64 - PB)].push_back(x);
-                                local++;
-                            }
-                        }
-                    }
-                }
-                inst += local;
-            };
-            std::vector<std::thread> ts;
-            for (unsigned t = 1; t < threads; t++) ts.emplace_back(body);
-            body();
-            for (auto &t : ts) t.join();
+            uint64_t at = 0;
+            for (unsigned p = 0; p < P; p++) {
+                pbase[p] = at;
+                for (unsigned t = 0; t < T; t++) { const uint64_t c = cnt_tp[(size_t)t * P + p]; cnt_tp[(size_t)t * P + p] = at; at += c; }
+            }
+            pbase[P] = at;
+            total_instances = at;
         }
-        total_instances = inst;
+        K *arena = get_arena((size_t)total_instances);
+        run_threads(T, [&](unsigned t) {
+            size_t s0, s1; share(t, s0, s1);
+            uint64_t *cur = &cnt_tp[(size_t)t * P];
+            constexpr unsigned WC = 64 / sizeof(K);              // one cache line per partition
+            std::vector<K> wc((size_t)P * WC);
+            std::vector<uint8_t> fill(P, 0);
+            walk_segments(bases, seg_off, s0, s1, [&](K x) {
+                const unsigned p = (unsigned)(KeyOps<K>::hash(x) >> (64 - PB));
+                K *w = &wc[(size_t)p * WC];
+                w[fill[p]++] = x;
+                if (fill[p] == WC) { memcpy(arena + cur[p], w, sizeof(K) * WC); cur[p] += WC; fill[p] = 0; }
+            });
+            for (unsigned p = 0; p < P; p++) if (fill[p]) { memcpy(arena + cur[p], &wc[(size_t)p * WC], sizeof(K) * fill[p]); cur[p] += fill[p]; }
+        });
+        const auto c1 = std::chrono::steady_clock::now();
         // every partition counted by one thread
         std::vector<std::vector<K>> pk(P); std::vector<std::vector<uint32_t>> pc(P);
-        std::vector<std::vector<uint64_t>> ph(threads, std::vector<uint64_t>(500, 0));
-        std::atomic<unsigned> tid2{0};
+        std::vector<std::vector<uint64_t>> ph(T, std::vector<uint64_t>(500, 0));
         {
             std::atomic<unsigned> next{0};
-            auto body = [&] {
-                const unsigned me = tid2.fetch_add(1);
-                std::vector<K> tk; std::vector<uint32_t> tc;
+            run_threads(T, [&](unsigned me) {
+                std::vector<K> tk, nk; std::vector<uint32_t> tc, nc;
+                auto insert = [&](std::vector<K> &kk, std::vector<uint32_t> &cc, size_t cp, K x, uint32_t w) -> bool {
+                    size_t i = (size_t)((KeyOps<K>::hash(x) * 0x9E3779B97F4A7C15ull) >> 20) & (cp - 1);
+                    for (;;) {
+                        if (cc[i] == 0) { kk[i] = x; cc[i] = w; return true; }
+                        if (kk[i] == x) { const uint64_t v = (uint64_t)cc[i] + w; cc[i] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; return false; }
+                        i = (i + 1) & (cp - 1);
+                    }
+                };
                 for (;;) {
                     const unsigned p = next.fetch_add(1);
                     if (p >= P) break;
-                    size_t n = 0;
-                    for (unsigned t = 0; t < threads; t++) n += buf[t][p].size();
+                    const uint64_t n = pbase[p + 1] - pbase[p];
                     if (!n) continue;
-                    size_t cap = 1024; while (cap < n / 8) cap <<= 1;        // grows when it fills up (error-rich reads)
+                    size_t cap = 1024; while (cap < n / 16) cap <<= 1;       // grows when it fills up (error-rich reads)
                     tk.assign(cap, 0); tc.assign(cap, 0);
                     size_t used = 0;
-                    auto insert = [&](std::vector<K> &kk, std::vector<uint32_t> &cc, size_t cp, K x, uint32_t w) -> bool {
-                        size_t i = (KeyOps<K>::hash(x) * 0x9E3779B97F4A7C15ull >> 20) & (cp - 1);
-                        for (;;) {
-                            if (cc[i] == 0) { kk[i] = x; cc[i] = w; return true; }
-                            if (kk[i] == x) { const uint64_t v = (uint64_t)cc[i] + w; cc[i] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; return false; }
-                            i = (i + 1) & (cp - 1);
-                        }
-                    };
-                    for (unsigned t = 0; t < threads; t++) {
-                        for (const K x : buf[t][p]) {
-                            if (insert(tk, tc, cap, x, 1)) {
-                                if (++used * 10 > cap * 6) {                 // rehash at 60 %
-                                    std::vector<K> nk(cap * 4, 0); std::vector<uint32_t> nc(cap * 4, 0);
-                                    for (size_t i = 0; i < cap; i++) if (tc[i]) insert(nk, nc, cap * 4, tk[i], tc[i]);
-                                    tk.swap(nk); tc.swap(nc); cap *= 4;
-                                }
+                    const K *src = arena + pbase[p];
+                    for (uint64_t j = 0; j < n; j++) {
+                        if (insert(tk, tc, cap, src[j], 1)) {
+                            if (++used * 10 > cap * 6) {                     // rehash at 60 %
+                                nk.assign(cap * 4, 0); nc.assign(cap * 4, 0);
+                                for (size_t i = 0; i < cap; i++) if (tc[i]) insert(nk, nc, cap * 4, tk[i], tc[i]);
+                                tk.swap(nk); tc.swap(nc); cap *= 4;
                             }
                         }
-                        std::vector<K>().swap(buf[t][p]);
                     }
                     for (size_t i = 0; i < cap; i++) if (tc[i]) {
                         ph[me][tc[i] >= 500 ? 499 : tc[i] - 1]++;
                         if (tc[i] > emit_thr) { pk[p].push_back(tk[i]); pc[p].push_back(tc[i]); }
                     }
                 }
-            };
-            std::vector<std::thread> ts;
-            for (unsigned t = 1; t < threads; t++) ts.emplace_back(body);
-            body();
-            for (auto &t : ts) t.join();
+            });
         }
-        for (unsigned t = 0; t < threads; t++) for (int b = 0; b < 500; b++) histo[b] += ph[t][b];
+        for (int b = 0; b < 500; b++) histo[b] = 0;
+        for (unsigned t = 0; t < T; t++) for (int b = 0; b < 500; b++) histo[b] += ph[t][b];
         size_t tot = 0; for (unsigned p = 0; p < P; p++) tot += pk[p].size();
         rkeys.clear(); rcnt.clear(); rkeys.reserve(tot); rcnt.reserve(tot);
         for (unsigned p = 0; p < P; p++) { rkeys.insert(rkeys.end(), pk[p].begin(), pk[p].end()); rcnt.insert(rcnt.end(), pc[p].begin(), pc[p].end()); }
+        const auto c2 = std::chrono::steady_clock::now();
+        t_scatter = std::chrono::duration<double>(c1 - c0).count();
+        t_tables = std::chrono::duration<double>(c2 - c1).count();
     }
 
     // ---------------------------------------------------------------- filter + index
@@ -180,18 +227,34 @@ template <typename K> struct Asm {
         // rows in key order: node ids (and with them every tie-break below) do not depend on the thread count
         std::vector<uint32_t> ord(keys.size());
         for (size_t i = 0; i < ord.size(); i++) ord[i] = (uint32_t)i;
-        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+        {
+            // parallel merge sort: chunks sorted by the threads, then merged pairwise
+            auto less = [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; };
+            unsigned C = 1; while (C * 2 <= threads && C < 64 && ord.size() / (C * 2) >= 65536) C *= 2;
+            std::vector<size_t> edge(C + 1);
+            for (unsigned c = 0; c <= C; c++) edge[c] = ord.size() * c / C;
+            run_threads(C, [&](unsigned c) { std::sort(ord.begin() + edge[c], ord.begin() + edge[c + 1], less); });
+            for (unsigned w = 1; w < C; w *= 2)
+                run_threads(C / (2 * w), [&](unsigned j) {
+                    std::inplace_merge(ord.begin() + edge[2 * w * j], ord.begin() + edge[2 * w * j + w], ord.begin() + edge[2 * w * j + 2 * w], less);
+                });
+        }
         std::vector<K> k2(keys.size()); std::vector<uint32_t> c2(keys.size());
         for (size_t i = 0; i < ord.size(); i++) { k2[i] = keys[ord[i]]; c2[i] = cnt[ord[i]]; }
         keys.swap(k2); cnt.swap(c2);
         const size_t n = keys.size();
         size_t cap = 16; while (cap < 2 * n + 2) cap <<= 1;
         index.assign(cap, 0); imask = cap - 1;
-        for (size_t i = 0; i < n; i++) {                      // (serial: 5 M inserts, a fraction of a second)
-            size_t s = KeyOps<K>::hash(keys[i]) & imask;
-            while (index[s]) s = (s + 1) & imask;
-            index[s] = (uint32_t)i + 1;
-        }
+        parallel_for(threads, n, 1 << 16, [&](size_t a, size_t b) {      // claim the first empty slot (keys are distinct)
+            for (size_t i = a; i < b; i++) {
+                size_t s = KeyOps<K>::hash(keys[i]) & imask;
+                for (;;) {
+                    uint32_t expect = 0;
+                    if (__atomic_compare_exchange_n(&index[s], &expect, (uint32_t)i + 1, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) break;
+                    s = (s + 1) & imask;
+                }
+            }
+        });
         return 0;
     }
     int64_t find(K x) const {
@@ -383,11 +446,14 @@ template <typename K> struct Asm {
     }
     std::string spell(const std::vector<onode> &path) const {
         static const char B[4] = {'A', 'C', 'G', 'T'};
-        std::string s;
-        s.reserve(path.size() + k);
+        std::string s(path.size() + k - 1, 'A');
         const K x = seq(path[0]);
-        for (int i = 0; i < k; i++) s.push_back(B[(uint32_t)(x >> (2 * (k - 1 - i))) & 3u]);
-        for (size_t i = 1; i < path.size(); i++) s.push_back(B[(uint32_t)seq(path[i]) & 3u]);
+        for (int i = 0; i < k; i++) s[i] = B[(uint32_t)(x >> (2 * (k - 1 - i))) & 3u];
+        // the last base of an oriented node: of its k-mer, or the complement of the k-mer's first base
+        auto last_base = [&](onode v) -> uint32_t { const K y = keys[v >> 1]; return (v & 1) ? 3u - (uint32_t)(y >> (2 * (k - 1))) : (uint32_t)y & 3u; };
+        auto fill = [&](size_t a, size_t b) { for (size_t i = std::max<size_t>(a, 1); i < b; i++) s[k - 1 + i] = B[last_base(path[i]) & 3u]; };
+        if (path.size() >= ((size_t)1 << 20)) parallel_for(threads, path.size(), 1 << 16, fill);   // (a chromosome: all threads)
+        else fill(0, path.size());
         return s;
     }
     static std::string rc_str(const std::string &s) {
@@ -481,6 +547,17 @@ void cpumt_count(void *p, const uint32_t *bases, const uint32_t *seg_off, uint64
     Ctx *c = (Ctx *)p; DISPATCH(c, count(bases, seg_off, n_seg, emit_threshold));
 }
 uint64_t cpumt_total_instances(void *p) { Ctx *c = (Ctx *)p; return DISPATCH(c, total_instances); }
+// seconds the last cpumt_count spent scattering k-mers into partitions / counting the partitions
+void cpumt_count_times(void *p, double *scatter_s, double *tables_s) {
+    Ctx *c = (Ctx *)p;
+    *scatter_s = DISPATCH(c, t_scatter); *tables_s = DISPATCH(c, t_tables);
+}
+// a new thread count for the next call (bench.py times the count at several)
+void cpumt_set_threads(void *p, uint32_t threads) {
+    Ctx *c = (Ctx *)p;
+    c->threads = threads ? threads : cpumt_hardware_threads();
+    if (c->a64) c->a64->threads = c->threads; else c->a128->threads = c->threads;
+}
 void cpumt_histo(void *p, uint64_t *out500) { Ctx *c = (Ctx *)p; memcpy(out500, c->a64 ? c->a64->histo : c->a128->histo, 500 * 8); }
 int cpumt_filter(void *p, uint32_t threshold) { Ctx *c = (Ctx *)p; return DISPATCH(c, filter(threshold)); }
 uint64_t cpumt_n_solid(void *p) { Ctx *c = (Ctx *)p; return DISPATCH(c, keys.size()); }
