@@ -192,6 +192,15 @@ int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0
  * bounds, kc[n] their k-mer count sums.  Returns a malloc'd NUL-terminated JSON (shk_host_free) or NULL. */
 char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k);
 void shk_host_free(void *p);
+/* SPEC S9 (tips, bubbles) and S10 (chains of simple links, the circular cut) on UNITIG records instead of k-mers — what the
+ * sharded assembly runs on every rank's host once the k-mer-level contraction is done on the GPUs (csrc/unitig_graph.h:
+ * one record per strand of a unitig; first / last: [n_recs][W] words of its first / last k-mer as spelled; min_*: the
+ * smallest oriented node of a record and its position, read for the records of rings only).  Exposed for the CPU tests.
+ * Returns a malloc'd text (shk_host_free): "removed <tip nodes> <bubble nodes>", then one line per contig
+ * "<ring> <rot> <nodes> <kc> : <record> <record> ...", or NULL on inconsistent input. */
+char *shk_host_unitig_assemble(uint32_t k, uint64_t n_recs, const uint64_t *first, const uint64_t *last, const uint64_t *len,
+                               const uint64_t *kc, const uint8_t *circ, const uint64_t *min_key, const uint8_t *min_o,
+                               const uint64_t *min_pos, int tips, int bubbles);
 
 /* Device buffers of freed handles are cached process-wide for the next handle (a handle lives
  * for one preprocess+assemble); this returns the cache to the driver.  SHK_NO_POOL=1 disables it. */

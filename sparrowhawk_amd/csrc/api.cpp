@@ -17,6 +17,7 @@
 #include "outputs.h"
 #include "pipeline.h"
 #include "shard_comm.h"
+#include "unitig_graph.h"
 
 namespace shk {
 bool spectrum_fit(const uint64_t *histo500, uint32_t *out);
@@ -1027,5 +1028,38 @@ char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const ui
     } catch (...) { return nullptr; }
 }
 void shk_host_free(void *p) { free(p); }
+char *shk_host_unitig_assemble(uint32_t k, uint64_t n_recs, const uint64_t *first, const uint64_t *last, const uint64_t *len,
+                               const uint64_t *kc, const uint8_t *circ, const uint64_t *min_key, const uint8_t *min_o,
+                               const uint64_t *min_pos, int tips, int bubbles) {
+    try {
+        if ((k & 1u) == 0 || k < SHK_K_MIN || k > SHK_K_MAX || (n_recs && (!first || !last || !len || !kc || !circ))) return nullptr;
+        const uint32_t W = (2 * k + 63) / 64;
+        std::vector<UnitigRec> recs((size_t)n_recs);
+        for (uint64_t r = 0; r < n_recs; r++) {
+            for (uint32_t j = 0; j < W; j++) { recs[r].first[j] = first[r * W + j]; recs[r].last[j] = last[r * W + j]; }
+            recs[r].len = len[r]; recs[r].kc = kc[r]; recs[r].circ = circ[r];
+        }
+        UnitigGraphResult res; std::string err;
+        auto fail_text = [](const std::string &e) -> char * { const std::string t = "error: " + e; char *o = (char *)malloc(t.size() + 1); if (o) memcpy(o, t.c_str(), t.size() + 1); return o; };
+        if (unitig_assemble((int)k, recs, tips != 0, bubbles != 0, res, err)) return fail_text(err);
+        std::vector<UnitigMinKey> mk((size_t)n_recs);
+        for (uint32_t r : res.need_min) {
+            if (!min_key || !min_o || !min_pos) return nullptr;
+            for (uint32_t j = 0; j < W; j++) mk[r].key[j] = min_key[(uint64_t)r * W + j];
+            mk[r].o = min_o[r]; mk[r].pos = min_pos[r]; mk[r].valid = true;
+        }
+        if (unitig_resolve_rings((int)k, recs, mk, res, err)) return fail_text(err);
+        std::string text = "removed " + std::to_string(res.tips_removed) + " " + std::to_string(res.bubbles_removed) + "\n";
+        for (const UnitigContig &c : res.contigs) {
+            text += std::to_string(c.ring ? 1 : 0) + " " + std::to_string(c.rot) + " " + std::to_string(c.len_nodes) + " " + std::to_string(c.kc) + " :";
+            for (uint32_t r : c.recs) text += " " + std::to_string(r);
+            text += "\n";
+        }
+        char *out = (char *)malloc(text.size() + 1);
+        if (!out) return nullptr;
+        memcpy(out, text.c_str(), text.size() + 1);
+        return out;
+    } catch (...) { return nullptr; }
+}
 
 }  // extern "C"

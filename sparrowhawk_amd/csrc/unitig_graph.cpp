@@ -1,0 +1,334 @@
+// unitig_graph.cpp — SPEC S9 / S10 on unitig records (see unitig_graph.h for why that is exact).
+#include "unitig_graph.h"
+
+#include <algorithm>
+#include <map>
+#include <unordered_map>
+
+#include "kmer.h"
+
+namespace shk {
+namespace {
+
+template <int W> struct UG {
+    const int k;
+    const std::vector<UnitigRec> &R;
+    const uint32_t n;
+    std::vector<Kmer<W>> F, T;                   // first / last k-mer of every record, as spelled
+    std::vector<uint32_t> mirror;
+    std::vector<uint8_t> alive;
+    struct PE { Kmer<W> p; uint32_t r; };
+    std::vector<PE> by_prefix;                   // linear records by the first k-1 bases of their first k-mer
+    uint64_t T_LEN;                              // T_TIP = T_BUB = 2k nodes
+
+    UG(int k_, const std::vector<UnitigRec> &recs) : k(k_), R(recs), n((uint32_t)recs.size()), T_LEN(2ull * (uint64_t)k_) {}
+
+    static Kmer<W> load(const uint64_t *w) { Kmer<W> x; for (int i = 0; i < W; i++) x.w[i] = w[i]; return x; }
+    Kmer<W> prefix(const Kmer<W> &x) const {      // the first k-1 bases as a 2(k-1)-bit integer
+        Kmer<W> r;
+        for (int i = 0; i < W; i++) r.w[i] = (x.w[i] >> 2) | (i + 1 < W ? x.w[i + 1] << 62 : 0ull);
+        return r;
+    }
+    Kmer<W> suffix(const Kmer<W> &x) const {      // the last k-1 bases
+        Kmer<W> r = x;
+        const int bits = 2 * (k - 1);
+        for (int i = 0; i < W; i++) {
+            const int lo = 64 * i;
+            if (bits <= lo) r.w[i] = 0;
+            else if (bits < lo + 64) r.w[i] &= (1ull << (bits - lo)) - 1ull;
+        }
+        return r;
+    }
+    Kmer<W> canon(const Kmer<W> &x, int &o) const { return km_canonical<W>(x, k, o); }
+
+    int init(std::string &err) {
+        F.resize(n); T.resize(n); mirror.assign(n, UG_NIL); alive.assign(n, 1);
+        for (uint32_t r = 0; r < n; r++) { F[r] = load(R[r].first); T[r] = load(R[r].last); }
+        std::vector<PE> by_first;
+        for (uint32_t r = 0; r < n; r++) if (!R[r].circ) { by_first.push_back(PE{F[r], r}); by_prefix.push_back(PE{prefix(F[r]), r}); }
+        auto less = [](const PE &a, const PE &b) { return km_less<W>(a.p, b.p) || (km_eq<W>(a.p, b.p) && a.r < b.r); };
+        std::sort(by_first.begin(), by_first.end(), less);
+        std::sort(by_prefix.begin(), by_prefix.end(), less);
+        for (size_t i = 1; i < by_first.size(); i++)
+            if (km_eq<W>(by_first[i].p, by_first[i - 1].p)) { err = "unitig graph: two chains start at the same oriented node"; return -1; }
+        for (uint32_t r = 0; r < n; r++) {
+            if (R[r].circ) continue;
+            const Kmer<W> want = km_revcomp<W>(T[r], k);
+            auto it = std::lower_bound(by_first.begin(), by_first.end(), PE{want, 0}, less);
+            if (it == by_first.end() || !km_eq<W>(it->p, want)) { err = "unitig graph: a chain without its mirror strand"; return -1; }
+            mirror[r] = it->r;
+        }
+        for (uint32_t r = 0; r < n; r++)
+            if (!R[r].circ && mirror[mirror[r]] != r) { err = "unitig graph: mirror strands do not pair up"; return -1; }
+        return 0;
+    }
+
+    // out-neighbours of r's last node: the alive records whose first k-mer overlaps its last k-mer by k-1
+    int outs(uint32_t r, uint32_t (&o)[4]) const {
+        if (R[r].circ) return 0;
+        const Kmer<W> s = suffix(T[r]);
+        auto it = std::lower_bound(by_prefix.begin(), by_prefix.end(), PE{s, 0}, [](const PE &a, const PE &b) {
+            return km_less<W>(a.p, b.p) || (km_eq<W>(a.p, b.p) && a.r < b.r); });
+        int c = 0;
+        for (; it != by_prefix.end() && km_eq<W>(it->p, s); ++it) if (alive[it->r] && c < 4) o[c++] = it->r;
+        return c;
+    }
+    int outdeg(uint32_t r) const { uint32_t o[4]; return outs(r, o); }
+    // in-neighbours of r's first node (as records that END there): the mirrors of the out-neighbours of r's mirror
+    int ins(uint32_t r, uint32_t (&o)[4]) const {
+        if (R[r].circ) return 0;
+        const int c = outs(mirror[r], o);
+        for (int i = 0; i < c; i++) o[i] = mirror[o[i]];
+        return c;
+    }
+    int indeg(uint32_t r) const { uint32_t o[4]; return ins(r, o); }
+
+    void kill(const std::vector<uint32_t> &doomed, uint64_t &nodes) {
+        for (uint32_t r : doomed) {
+            if (!alive[r]) continue;
+            alive[r] = 0; alive[mirror[r]] = 0;
+            nodes += R[r].len;
+        }
+    }
+
+    uint64_t tip_round() {
+        struct Tip { uint64_t len, sum; std::vector<uint32_t> path; };
+        std::map<uint32_t, std::vector<Tip>> attached;               // junction record (its first node) -> tips
+        for (uint32_t v = 0; v < n; v++) {
+            if (!alive[v] || R[v].circ || indeg(v) != 0) continue;
+            Tip t; t.path.push_back(v); t.len = R[v].len; t.sum = R[v].kc;
+            if (t.len > T_LEN) continue;                             // |P| > T inside the first chain: not a tip
+            uint32_t cur = v;
+            for (;;) {
+                uint32_t o[4];
+                if (outs(cur, o) != 1) break;                        // not a tip
+                const uint32_t nx = o[0];
+                if (indeg(nx) >= 2) { attached[nx].push_back(std::move(t)); break; }
+                t.path.push_back(nx); t.len += R[nx].len; t.sum += R[nx].kc; cur = nx;
+                if (t.len > T_LEN) break;                            // not a tip
+            }
+        }
+        std::vector<uint32_t> doomed;
+        for (auto &kv : attached) {
+            std::vector<Tip> &tips = kv.second;
+            const size_t d = (size_t)indeg(kv.first), t = tips.size();
+            size_t best = 0;
+            if (t == d) {
+                for (size_t q = 1; q < t; q++) {                      // max of (|P|, sum of counts, smaller first canonical k-mer)
+                    const Tip &A = tips[q], &B = tips[best];
+                    bool better;
+                    if (A.len != B.len) better = A.len > B.len;
+                    else if (A.sum != B.sum) better = A.sum > B.sum;
+                    else { int oa, ob; better = km_less<W>(canon(F[A.path[0]], oa), canon(F[B.path[0]], ob)); }
+                    if (better) best = q;
+                }
+            }
+            for (size_t q = 0; q < t; q++) {
+                if (t == d && q == best) continue;
+                for (uint32_t r : tips[q].path) doomed.push_back(r);
+            }
+        }
+        uint64_t nodes = 0;
+        kill(doomed, nodes);
+        return nodes;
+    }
+
+    uint64_t bubble_round() {
+        std::vector<uint32_t> doomed;
+        for (uint32_t S = 0; S < n; S++) {
+            if (!alive[S] || R[S].circ) continue;
+            uint32_t ob[4];
+            const int no = outs(S, ob);
+            if (no < 2) continue;
+            struct Branch { std::vector<uint32_t> path; uint64_t len = 0, sum = 0; uint32_t end = UG_NIL; bool ok = false; };
+            Branch br[4];
+            for (int b = 0; b < no; b++) {
+                Branch &B = br[b];
+                const uint32_t bn = ob[b];
+                if (indeg(bn) != 1) continue;
+                B.path.push_back(bn); B.len = R[bn].len; B.sum = R[bn].kc;
+                if (B.len > T_LEN) continue;                         // too long inside the first chain
+                uint32_t cur = bn;
+                for (;;) {
+                    uint32_t o[4];
+                    if (outs(cur, o) != 1) break;                    // dead end or fork
+                    const uint32_t nx = o[0];
+                    if (indeg(nx) >= 2) { B.end = nx; B.ok = true; break; }
+                    B.path.push_back(nx); B.len += R[nx].len; B.sum += R[nx].kc; cur = nx;
+                    if (B.len > T_LEN) break;                        // too long
+                }
+            }
+            for (int a = 0; a < no; a++) {
+                if (!br[a].ok) continue;
+                const uint32_t E = br[a].end;
+                {   // evaluated only from the side with key(S) <= key(rc(E)): S = last node of record S, E = first node of record E
+                    int os, oe;
+                    const Kmer<W> ks = canon(T[S], os), ke = canon(F[E], oe);
+                    const int oe_m = 1 - oe;                         // rc(E): the same k-mer, the other orientation
+                    bool le;
+                    if (km_less<W>(ks, ke)) le = true; else if (km_less<W>(ke, ks)) le = false; else le = os <= oe_m;
+                    if (!le) continue;
+                }
+                int grp = 0; bool best = true;
+                for (int b = 0; b < no; b++) {
+                    if (!br[b].ok || br[b].end != E) continue;
+                    grp++;
+                    if (b == a) continue;
+                    // is b better than a?  exact means by cross-multiplication (node counts <= 2k: no overflow in 128 bits, nor in 64 in practice)
+                    const unsigned __int128 l = (unsigned __int128)br[b].sum * br[a].len, r = (unsigned __int128)br[a].sum * br[b].len;
+                    bool better;
+                    if (l != r) better = l > r;
+                    else if (br[b].len != br[a].len) better = br[b].len < br[a].len;
+                    else { int o1, o2; better = km_less<W>(canon(F[br[b].path[0]], o1), canon(F[br[a].path[0]], o2)); }
+                    if (better) best = false;
+                }
+                if (grp >= 2 && !best) for (uint32_t r : br[a].path) doomed.push_back(r);
+            }
+        }
+        uint64_t nodes = 0;
+        kill(doomed, nodes);
+        return nodes;
+    }
+
+    // S10 on what is left: r -> s is simple iff it is r's only out-edge, s's only in-edge and s's first node is neither
+    // r's last node nor its reverse complement
+    uint32_t simple_succ(uint32_t r) const {
+        uint32_t o[4];
+        if (outs(r, o) != 1) return UG_NIL;
+        const uint32_t s = o[0];
+        if (indeg(s) != 1) return UG_NIL;
+        if (km_eq<W>(F[s], T[r]) || km_eq<W>(F[s], km_revcomp<W>(T[r], k))) return UG_NIL;
+        return s;
+    }
+
+    void chains(UnitigGraphResult &out) {
+        std::vector<uint32_t> succ(n, UG_NIL), pred(n, UG_NIL);
+        for (uint32_t r = 0; r < n; r++) if (alive[r] && !R[r].circ) { succ[r] = simple_succ(r); }
+        for (uint32_t r = 0; r < n; r++) if (succ[r] != UG_NIL) pred[succ[r]] = r;
+        std::vector<uint8_t> seen(n, 0);
+        auto finish = [&](UnitigContig &c) {
+            for (uint32_t r : c.recs) { c.len_nodes += R[r].len; c.kc += R[r].kc; }
+            out.contigs.push_back(std::move(c));
+        };
+        for (uint32_t r = 0; r < n; r++) {                           // linear: from every record without a simple predecessor
+            if (!alive[r] || R[r].circ || pred[r] != UG_NIL || seen[r]) continue;
+            UnitigContig c;
+            for (uint32_t cur = r; cur != UG_NIL; cur = succ[cur]) { c.recs.push_back(cur); seen[cur] = 1; }
+            // the mirror strand is a chain of its own: the one whose first record has the smaller id speaks for both
+            const uint32_t mirror_first = mirror[c.recs.back()];
+            for (uint32_t x : c.recs) seen[mirror[x]] = 1;
+            (void)mirror_first;
+            finish(c);
+        }
+        for (uint32_t r = 0; r < n; r++) {                           // what is left closes on itself: a ring made of several records
+            if (!alive[r] || R[r].circ || seen[r]) continue;
+            UnitigContig c; c.ring = true;
+            for (uint32_t cur = r;;) { c.recs.push_back(cur); seen[cur] = 1; cur = succ[cur]; if (cur == r || cur == UG_NIL) break; }
+            for (uint32_t x : c.recs) { seen[mirror[x]] = 1; out.need_min.push_back(x); out.need_min.push_back(mirror[x]); }
+            finish(c);
+        }
+        for (uint32_t r = 0; r < n; r++) {                           // rings from the start: each strand a record of its own
+            if (!alive[r] || !R[r].circ) continue;
+            UnitigContig c; c.ring = true; c.recs.push_back(r);
+            out.need_min.push_back(r);
+            finish(c);
+        }
+    }
+};
+
+template <int W> int assemble_t(int k, const std::vector<UnitigRec> &recs, bool tips, bool bubbles, UnitigGraphResult &out, std::string &err) {
+    UG<W> g(k, recs);
+    if (int rc = g.init(err)) return rc;
+    out = UnitigGraphResult();
+    if (tips || bubbles) {
+        for (int round = 0; round < 32; round++) {                   // MAX_ROUNDS (S9)
+            const uint64_t a = tips ? g.tip_round() : 0, b = bubbles ? g.bubble_round() : 0;
+            out.tips_removed += a; out.bubbles_removed += b; out.rounds++;
+            if (a + b == 0) break;
+        }
+    }
+    g.chains(out);
+    out.mirror = g.mirror;
+    return 0;
+}
+
+template <int W> int resolve_t(int k, const std::vector<UnitigRec> &recs, const std::vector<UnitigMinKey> &mk, UnitigGraphResult &out, std::string &err) {
+    auto key_less = [&](const UnitigMinKey &a, const UnitigMinKey &b) {   // (x, o) lexicographic
+        for (int i = W - 1; i >= 0; i--) if (a.key[i] != b.key[i]) return a.key[i] < b.key[i];
+        return a.o < b.o;
+    };
+    auto key_same_kmer = [&](const UnitigMinKey &a, const UnitigMinKey &b) {
+        for (int i = 0; i < W; i++) if (a.key[i] != b.key[i]) return false;
+        return true;
+    };
+    std::vector<UnitigContig> kept;
+    std::vector<UnitigContig> all;                                  // (the partner search below looks at all of them: work on a copy)
+    all.swap(out.contigs);
+    // rings that were rings from the start come as one contig per strand: the strand that holds its smallest k-mer in
+    // orientation 0 is the one SPEC S10 spells; its partner (same k-mer, orientation 1) goes
+    for (const UnitigContig &c0 : all) {
+        UnitigContig c = c0;
+        if (!c.ring) { kept.push_back(std::move(c)); continue; }
+        for (uint32_t r : c.recs) if (r >= mk.size() || !mk[r].valid) { err = "unitig graph: a ring without its smallest k-mer"; return -1; }
+        if (c.recs.size() == 1 && recs[c.recs[0]].circ) {
+            const UnitigMinKey &m = mk[c.recs[0]];
+            if (m.o != 0) {
+                // the mirror strand; dropped if the other strand exists (it always does when this record was ranked from a
+                // sampled node; a ring without one is reported on the strand of its smallest k-mer alone)
+                bool partner = false;
+                for (const UnitigContig &d : all)
+                    if (&d != &c0 && d.ring && d.recs.size() == 1 && recs[d.recs[0]].circ && mk[d.recs[0]].valid &&
+                        key_same_kmer(mk[d.recs[0]], m) && mk[d.recs[0]].o == 0) { partner = true; break; }
+                if (partner) continue;
+                err = "unitig graph: a ring known on its mirror strand only"; return -1;
+            }
+            c.rot = m.pos;
+            kept.push_back(std::move(c));
+            continue;
+        }
+        // a ring of several records: this strand, or the mirror records in reverse order
+        UnitigMinKey best; bool best_here = true; uint64_t best_off = 0;
+        uint64_t off = 0;
+        for (uint32_t r : c.recs) {
+            if (!best.valid || key_less(mk[r], best)) { best = mk[r]; best_here = true; best_off = off + mk[r].pos; }
+            off += recs[r].len;
+        }
+        std::vector<uint32_t> mrecs;
+        for (size_t i = c.recs.size(); i-- > 0;) mrecs.push_back(out.mirror[c.recs[i]]);
+        off = 0;
+        for (uint32_t r : mrecs) {
+            if (r >= mk.size() || !mk[r].valid) { err = "unitig graph: a ring without its smallest k-mer"; return -1; }
+            if (key_less(mk[r], best)) { best = mk[r]; best_here = false; best_off = off + mk[r].pos; }
+            off += recs[r].len;
+        }
+        if (!best_here) c.recs = mrecs;
+        c.rot = best_off;
+        kept.push_back(std::move(c));
+    }
+    out.contigs.swap(kept);
+    (void)k;
+    return 0;
+}
+
+}  // namespace
+
+int unitig_assemble(int k, const std::vector<UnitigRec> &recs, bool tips, bool bubbles, UnitigGraphResult &out, std::string &err) {
+    switch ((2 * k + 63) / 64) {
+        case 1: return assemble_t<1>(k, recs, tips, bubbles, out, err);
+        case 2: return assemble_t<2>(k, recs, tips, bubbles, out, err);
+        case 3: return assemble_t<3>(k, recs, tips, bubbles, out, err);
+        case 4: return assemble_t<4>(k, recs, tips, bubbles, out, err);
+    }
+    err = "k too large"; return -1;
+}
+int unitig_resolve_rings(int k, const std::vector<UnitigRec> &recs, const std::vector<UnitigMinKey> &min_of, UnitigGraphResult &out, std::string &err) {
+    switch ((2 * k + 63) / 64) {
+        case 1: return resolve_t<1>(k, recs, min_of, out, err);
+        case 2: return resolve_t<2>(k, recs, min_of, out, err);
+        case 3: return resolve_t<3>(k, recs, min_of, out, err);
+        case 4: return resolve_t<4>(k, recs, min_of, out, err);
+    }
+    err = "k too large"; return -1;
+}
+
+}  // namespace shk
