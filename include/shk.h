@@ -133,8 +133,14 @@ int shk_shard_set_solid(shk_handle *h, const void *const *d_keys /* [W] */, cons
  *   pass 1 -> all-gather of the per-partition record counts (the size exchange) -> pack -> ONE pairwise
  *   exchange of the records (grouped ncclSend/ncclRecv) -> pass 2 over the owned partitions -> all-reduce
  *   of histogram + instance count (501 x u64) -> fit / filter -> all-gather of the solid rows -> install,
- * leaving every rank's handle "preprocessed" with the identical global solid set; shk_assemble() follows as
- * usual.  A Rust host binds these five functions and never writes a collective itself. */
+ * leaving every rank's handle "preprocessed".  By default the GRAPH STAYS SHARDED: every rank keeps the solid k-mers of
+ * its own partitions, and shk_assemble() on these handles is COLLECTIVE over the same communicator (call it on every
+ * rank; keep the communicator until it has returned): adjacency with one pairwise exchange of neighbour queries and one
+ * of answers, non-branching paths contracted per rank and stitched across ranks, tips / bubbles on the graph of unitigs,
+ * every rank writing the bases of its own k-mers into the contigs (csrc/shard_graph.h).  Every rank ends with the same
+ * get_assembly() text; the stage-inspection getters then describe the rank's own rows.  With SHK_SHARD_GRAPH=0 in the
+ * environment the solid set is gathered instead (all-gather of the solid rows) and shk_assemble() runs locally, on the
+ * whole graph, on every rank.  A Rust host binds these five functions and never writes a collective itself. */
 #define SHK_UNIQUE_ID_BYTES 128
 typedef struct shk_comm shk_comm;
 int shk_comm_unique_id(uint8_t id[SHK_UNIQUE_ID_BYTES]);

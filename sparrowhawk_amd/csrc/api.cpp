@@ -53,6 +53,7 @@ struct shk_handle {
     PackedReads stream_reads;          // shk_push_reads accumulator
     uint64_t n_reads = 0;
     uint64_t batches_started = 0;      // batches handed to the pipeline (a failure after the first one poisons the handle)
+    ShardComm *shard_comm = nullptr;   // sharded assembly: the communicator shk_shard_preprocess ran on (shk_assemble is collective over it)
     AssemblyText text;
 
     const char *mode() const { return do_bloom ? "bloom" : (chunk_size > 0 ? "chunked" : "bulk"); }
@@ -673,6 +674,27 @@ static int assemble_impl(shk_handle *h) {
     std::string err;
     const double t0 = now_ms();
     h->post("assembly:start");
+    if (h->pipe->sharded_graph()) {
+        // the graph is spread over the ranks of the communicator shk_shard_preprocess ran on: collective (csrc/shard_graph.h).
+        // The three phases run interleaved across ranks; the states are posted in the reference's order.
+        if (!h->shard_comm) return fail(h, SHK_E_STATE, "assemble: the communicator of the sharded preprocess is gone");
+        h->post("assembly:create_graph");
+        std::vector<RawContig> contigs;
+        if (h->pipe->n_solid_global() >= (1u << 20)) writer_prewarm(3000);
+        int rc = h->pipe->shard_assemble(h->shard_comm, !h->no_deadend, !h->no_bubble, contigs, err);
+        if (rc) { if (rc == -5) comm_mark_broken(h->shard_comm); return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err); }
+        h->post("assembly:correct_graph");
+        h->post("assembly:collapse_graph");
+        h->pipe->times().add("assemble_device_total_host_clock", now_ms() - t0);
+        h->post("assembly:saving");
+        const double t1 = now_ms();
+        build_assembly_text(contigs, h->k, h->text);
+        h->asm_json.swap(h->text.json);
+        h->pipe->times().add("outputs_host_clock", now_ms() - t1);
+        h->st = St::Assembled;
+        h->post("assembly:end");
+        return SHK_OK;
+    }
     h->post("assembly:create_graph");
     int rc = h->pipe->build_graph(err);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
@@ -790,7 +812,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     auto peer_failed = [&](const char *stage) {
         return fail(h, SHK_E_DEVICE, std::string("shard_preprocess: another rank failed during ") + stage + " (this rank's state is intact up to there; free the handle)");
     };
-    // SHK_FAULT_INJECT=<step> (pass1 | pack | count | rows | alloc) makes that local step of THIS process fail: the tests
+    // SHK_FAULT_INJECT=<step> (pass1 | pack | count | rows | keep | alloc) makes that local step of THIS process fail: the tests
     // set it on one rank to see every rank leave with an error instead of hanging.  It never changes a result.
     const char *inject = getenv("SHK_FAULT_INJECT");
     auto injected = [&](const char *step) -> int {
@@ -880,6 +902,25 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     if (int rc = comm_allgather_host_u64(c, mine2, 2, counts2.data(), st, err)) { if (rc_rows) return rc_rows; return cfail(rc); }
     if (rc_rows) return rc_rows;
     for (uint32_t r = 0; r < world; r++) { if (counts2[2 * r + 1]) return peer_failed("the filter"); counts[r] = counts2[2 * r]; }
+    // ---- the graph stays sharded (default): every rank keeps its own rows and shk_assemble() runs collectively over this
+    // communicator (csrc/shard_graph.h).  SHK_SHARD_GRAPH=0: round 2's path — gather the solid set, assemble on every rank.
+    {
+        const char *sg = getenv("SHK_SHARD_GRAPH");
+        if (!(sg && *sg == '0')) {
+            int rc_keep = SHK_OK;
+            { std::string e2; const int r2 = h->pipe->shard_keep_local(world, rank, P, counts.data(), red, red[SHK_HISTO_BINS], e2);
+              if (r2) rc_keep = fail(h, r2 == -1 ? SHK_E_PARAM : SHK_E_DEVICE, e2); }
+            if (!rc_keep) rc_keep = injected("keep");
+            if (int rc = agree(rc_keep, "the hand-over to the sharded assembly")) return rc;
+            h->shard_comm = c;
+            h->post("preprocess:saving");
+            h->pre_json = preprocessing_json(h->pipe->n_solid_global(), h->histo, h->used_min_count);
+            h->st = St::Preprocessed;
+            h->post("preprocess:end");
+            h->pipe->times().add("shard_preprocess_host_clock", now_ms() - t0);
+            return SHK_OK;
+        }
+    }
     uint64_t n_total = 0;
     std::vector<uint64_t> off8(world), len8(world), off4(world), len4(world);
     for (uint32_t r = 0; r < world; r++) { off8[r] = n_total * 8; len8[r] = counts[r] * 8; off4[r] = n_total * 4; len4[r] = counts[r] * 4; n_total += counts[r]; }

@@ -105,7 +105,9 @@ __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *_
             if (al && __popc(om) == 1) {
                 c = cv;
                 const uint32_t u = nbv < NB_MULTI ? nbv : g.follow(v, (uint32_t)__ffs((int)om) - 1u);   // (several at build time: look the survivor up)
-                if (u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
+                // (sharded assembly: a neighbour on another rank ends the LOCAL chain here; the link is stitched across ranks later)
+                const bool xr = g.xref && (u & g.xref) && u < NB_MULTI;
+                if (!xr && u != NIL && g.indeg(u) == 1 && u != v && u != (v ^ 1u)) s = u;
             } else if (al) c = cv;
             uint2 w; w.x = s; w.y = c; winfo[v] = w;
         }

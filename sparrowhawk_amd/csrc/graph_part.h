@@ -428,11 +428,13 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         uint32_t a = 0, n_out = 0, n_in = 0, u_out = NIL, u_in = NIL;
 #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
-            bool remote = false; uint32_t p = 0;
+            bool remote = false; uint32_t p = 0, xowner = 0; bool cross = false;
             if (act) {
-                p = (j < 4 ? min(ms.min_wo_first, nt32_next_hash_lut(ms.last, out_b, j, lut))
-                           : min(ms.min_wo_last, nt32_prev_hash_lut(ms.first, j - 4u, last_b, lut))) & gt.gp_mask;
-                remote = p != P || !in_lds;
+                const uint32_t hmin = j < 4 ? min(ms.min_wo_first, nt32_next_hash_lut(ms.last, out_b, j, lut))
+                                            : min(ms.min_wo_last, nt32_prev_hash_lut(ms.first, j - 4u, last_b, lut));
+                p = hmin & gt.gp_mask;
+                if (gt.world > 1) { xowner = gt.owner_of(hmin); cross = xowner != gt.rank; }     // (sharded assembly: the candidate lives on another rank)
+                remote = cross || p != P || !in_lds;
                 if (SHK_DBG(gt.dbg) == 3) remote = false;                       // timing experiment: scan + candidates only
                 if (SHK_DBG(gt.dbg) == 4 && remote) { remote = false; }         // timing experiment: no remote queue
                 else if (!remote && SHK_DBG(gt.dbg) != 3) {
@@ -463,7 +465,8 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
                 if (lane == 0) base = atomicAdd(&q_fill, (uint32_t)__popcll(m));
                 base = (uint32_t)__shfl((int)base, 0);
                 if (remote) myq[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] =
-                    (unsigned long long)i | ((unsigned long long)j << 32) | ((unsigned long long)p << 35);
+                    (unsigned long long)i | ((unsigned long long)j << 32) | ((unsigned long long)p << 35) |
+                    (cross ? (1ull << 63) | ((unsigned long long)xowner << 52) : 0ull);
             }
         }
         if (act) {
@@ -490,7 +493,8 @@ __global__ __launch_bounds__(256) void k_graph_remote(KeyArr<W> keys, int k, Gra
     const uint32_t nq = qcnt[P];
     for (uint32_t t = threadIdx.x; t < nq; t += blockDim.x) {
         const unsigned long long q = myq[t];
-        const uint32_t i = (uint32_t)q, j = (uint32_t)(q >> 32) & 7u, p = (uint32_t)(q >> 35);
+        if (q >> 63) continue;                                  // a cross-rank query: answered by its owner (shard_graph.h)
+        const uint32_t i = (uint32_t)q, j = (uint32_t)(q >> 32) & 7u, p = (uint32_t)(q >> 35) & 0x1FFFFu;
         const Kmer<W> x = keys.load(i);
         const Kmer<W> rx = km_revcomp<W>(x, k);
         bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
@@ -522,6 +526,7 @@ template <int W> struct Graph {
     const uint32_t *nb;                        // unique out-neighbour at build time (NIL: none or several)
     int k;
     uint32_t n;
+    uint32_t xref = 0;                         // sharded assembly: 0x80000000 — an nb[] entry with this bit (and < NB_MULTI) names a node of another rank
     __device__ __forceinline__ uint32_t outmask(uint32_t v) const { return outmask_of(adj[v >> 1], v & 1); }
     __device__ __forceinline__ uint32_t outdeg(uint32_t v) const { return __popc(outmask(v)); }
     __device__ __forceinline__ uint32_t indeg(uint32_t v) const { return __popc(outmask(v ^ 1)); }

@@ -8,6 +8,8 @@
 
 namespace shk {
 
+struct ShardComm;             // shard_comm.h
+
 struct RawContig {            // one unitig as spelled by the device, arbitrary strand
     // The sequence either lives in the pipeline's pinned download buffer (ext: valid until the next
     // collapse() or the pipeline's destruction — a 5 Mbp contig is not copied again) or in `own`.
@@ -70,6 +72,15 @@ public:
     virtual int shard_rows(uint32_t threshold, const void **keys_soa, const void **cnt, uint64_t *n, std::string &err) = 0;
     virtual int shard_set_solid(const void *const *keys_soa, const void *cnt, uint64_t n, const uint64_t histo[500],
                                 uint64_t total_instances, std::string &err) = 0;
+    // sharded ASSEMBLY (shard_graph.h): instead of shard_set_solid — which installs the gathered solid set on every rank —
+    // the rank keeps the rows of its own counting partitions (after shard_rows) and assembles with the graph spread over
+    // the ranks.  rows_per_rank: [world] solid rows of every rank; n_count_partitions: the P of the counting pass (partition
+    // p belongs to rank p % world).  shard_assemble is collective over `comm`.
+    virtual int shard_keep_local(uint32_t world, uint32_t rank, uint32_t n_count_partitions, const uint64_t *rows_per_rank,
+                                 const uint64_t histo[500], uint64_t total_instances, std::string &err) = 0;
+    virtual bool sharded_graph() const = 0;
+    virtual uint64_t n_solid_global() const = 0;
+    virtual int shard_assemble(ShardComm *comm, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) = 0;
     virtual StageTimes &times() = 0;
     virtual void *stream() = 0;
     virtual int device() const = 0;                  // the HIP device this pipeline's stream and buffers live on

@@ -26,6 +26,8 @@
 
 #include "kmer.h"
 #include "pipeline.h"
+#include "shard_comm.h"
+#include "unitig_graph.h"
 
 namespace shk {
 
@@ -79,6 +81,14 @@ struct GraphTable {                            // entry = fingerprint<<32 | node
     uint32_t gp_mask;                          // GP - 1
     int gm;                                    // minimiser length of the graph partition function
     uint32_t dbg;                              // timing experiments only (SHK_DEBUG_G)
+    // sharded assembly (one process per GPU): a k-mer lives on rank ((minimiser hash & cp_mask) % world) — the owner of
+    // its counting partition.  world == 1: everything is local.  world_inv = ceil(2^32 / world) (exact quotients below 2^16)
+    uint32_t cp_mask = 0, world = 1, rank = 0, world_inv = 0;
+    __device__ __forceinline__ uint32_t owner_of(uint32_t minhash) const {
+        const uint32_t x = minhash & cp_mask;                  // < 16384
+        const uint32_t q = __umulhi(x, world_inv);
+        return x - q * world;
+    }
 };
 
 }  // namespace shk
@@ -88,6 +98,7 @@ namespace shk {
 #include "count_global.h"
 #include "graph_part.h"
 #include "collapse.h"
+#include "shard_graph.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -1045,6 +1056,11 @@ public:
         g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
         g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
         g.n = (uint32_t)n_solid_;
+        if (sh_active_) {                                   // sharded assembly: which rank owns a neighbour candidate
+            g.gt.cp_mask = sh_P_ - 1u; g.gt.world = sh_world_; g.gt.rank = sh_rank_;
+            g.gt.world_inv = (uint32_t)((0x100000000ull + sh_world_ - 1u) / sh_world_);
+            g.xref = XREF;
+        }
         return g;
     }
 
@@ -1061,7 +1077,9 @@ public:
         // same fixed cost each — while 790 and 980 lose to 400 and 490: partitions above 1024 rows need a table beyond the LDS
         // one and work in global memory.  The average ends up in (320, 640].)
         const uint64_t gp_rows_target = env_u64("SHK_GP_ROWS", 640);
-        while (gp_ < 131072u && (uint64_t)gp_ * gp_rows_target < n) gp_ <<= 1;
+        // (sharded assembly: every rank must cut the k-mer space into the same graph partitions — from the global node count)
+        const uint64_t n_for_gp = sh_active_ ? n_solid_global_ : n;
+        while (gp_ < 131072u && (uint64_t)gp_ * gp_rows_target < n_for_gp) gp_ <<= 1;
         gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
@@ -1123,6 +1141,23 @@ public:
                                gp_cnt.p, adj_.p, nb_.p);
             HIPCHK(hipGetLastError());
             t2.stop_later("adjacency_kernel", pending_timers_);
+            if (sh_active_ && sh_world_ > 1) {
+                // the candidates that live on other ranks: staged compactly before `queries` goes (shard_cross_adjacency)
+                HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+                hipLaunchKernelGGL(k_xq_total, dim3(gp_), dim3(256), 0, stream_, gp_roff.p, queries.p, gp_cnt.p, (unsigned int *)(ctl_.p + 13));
+                unsigned int n_x = 0;
+                if (int rc = read_ctl(n_x, 13, err)) return rc;
+                xq_n_ = n_x;
+                if (int rc = xq_dest_.alloc(n_x, err)) return rc;
+                if (int rc = xq_pay_.alloc((size_t)n_x * (W + 1), err)) return rc;
+                if (int rc = xq_meta_.alloc(n_x, err)) return rc;
+                if (n_x) {
+                    HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+                    hipLaunchKernelGGL(k_xq_stage<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, gp_roff.p, queries.p, gp_cnt.p,
+                                       (unsigned int *)(ctl_.p + 13), n_x, xq_dest_.p, xq_pay_.p, xq_meta_.p);
+                    HIPCHK(hipGetLastError());
+                }
+            }
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
             unsigned long long h[3];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -1225,29 +1260,36 @@ public:
     // ---- collapse ----------------------------------------------------------------------------
     // Counters in ctl_: 5 = splitters (k_succ_split, then appended to by k_orphan_cycles), 6 = chains reported
     // (k_rank_tails), 7 = splitters that sit on a circular unitig (statistic), 8 = flags of k_orphan_cycles.
-    int collapse(std::vector<RawContig> &out, std::string &err) override {
-        out.clear();
-        if (!graph_ready_) { err = "graph not built"; return -2; }
-        const uint32_t n = (uint32_t)n_solid_;
-        if (n == 0) return 0;
-        const uint32_t total = 2 * n;
-        Graph<W> g = graph_view();
-        DevBuf<uint32_t> spl;
+    struct ChainState {                // the ranking of the chains of simple links: per node (chain record, position), per chain a HeadRec
+        DevBuf<uint32_t> spl, slot_of;
         DevBuf<uint2> winfo, ol;
         DevBuf<SegRec> segs;
-        DevBuf<FragRec> frag;                                            // indexed by node id, written at fragment heads only
-        if (int rc = winfo.alloc(total, err)) return rc;
-        if (int rc = frag.alloc(total, err)) return rc;
-        if (int rc = spl.alloc(total, err)) return rc;
-        if (int rc = ol.alloc(total, err)) return rc;
+        DevBuf<FragRec> frag;          // indexed by node id, written at fragment heads only
+        DevBuf<RankRec> Ra, Rb;
+        DevBuf<FinRec> fin;
+        DevBuf<HeadRec> d_heads;
+        DevBuf<RingMin> ringmin;
+        std::vector<HeadRec> heads;
+        uint32_t seg_cap = 0;
+    };
+    // rings: also find the smallest k-mer of every circular chain and the strand / rotation it is spelled with (single GPU);
+    // the sharded assembly settles rings across ranks itself (shard_graph.h)
+    int rank_chains(ChainState &cs, bool rings, std::string &err) {
+        const uint32_t n = (uint32_t)n_solid_;
+        const uint32_t total = 2 * n;
+        Graph<W> g = graph_view();
+        if (int rc = cs.winfo.alloc(total, err)) return rc;
+        if (int rc = cs.frag.alloc(total, err)) return rc;
+        if (int rc = cs.spl.alloc(total, err)) return rc;
+        if (int rc = cs.ol.alloc(total, err)) return rc;
         HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 .. 8 as above, 9 = alive oriented nodes, 10 = nodes walked
         const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
         EvTimer t1(stream_);
         hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
-                           alive_.p, winfo.p, spl.p, ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
+                           alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
         const uint32_t tile_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_TILE_ROWS", LF_ROWS), 1), LF_TILE / 2u);
         const int lf_grid = (int)((n + tile_rows - 1) / tile_rows);
-        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, winfo.p, ol.p, frag.p, split_mask);
+        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask);
         HIPCHK(hipGetLastError());
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
@@ -1255,67 +1297,83 @@ public:
         times_.add("collapse_n_splitters_x1e-3", n_spl * 1e-3);
         // circular unitigs without a sampled node add one splitter each (k_orphan_cycles): room for them
         const uint32_t seg_cap = n_spl + total / 8u + 1024u;
-        if (int rc = segs.alloc(seg_cap, err)) return rc;
+        cs.seg_cap = seg_cap;
+        if (int rc = cs.segs.alloc(seg_cap, err)) return rc;
         const unsigned int *d_nspl = (const unsigned int *)(ctl_.p + 5);
         {
             EvTimer t2(stream_);
             if (n_spl) {
                 hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_,
-                                   spl.p, n_spl, frag.p, segs.p, split_mask, ctl_.p + 10);
+                                   cs.spl.p, n_spl, cs.frag.p, cs.segs.p, split_mask, ctl_.p + 10);
             }
-            hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, winfo.p, ol.p,
-                               frag.p, spl.p, segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
+            hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, cs.winfo.p, cs.ol.p,
+                               cs.frag.p, cs.spl.p, cs.segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
             HIPCHK(hipGetLastError());
             t2.stop_later("collapse_walk", pending_timers_);
         }
         // ---- rank the splitter list on the device: prefix sums by pointer jumping, rings in the same pass (collapse.h)
-        DevBuf<RankRec> Ra, Rb; DevBuf<uint32_t> slot_of; DevBuf<FinRec> fin; DevBuf<EmitRec> d_off; DevBuf<HeadRec> d_heads;
-        DevBuf<RingMin> ringmin; DevBuf<char> d_out;
-        if (int rc = Ra.alloc(seg_cap, err)) return rc;
-        if (int rc = Rb.alloc(seg_cap, err)) return rc;
-        if (int rc = slot_of.alloc(seg_cap, err)) return rc;
-        if (int rc = fin.alloc(seg_cap, err)) return rc;
-        if (int rc = d_heads.alloc(seg_cap, err)) return rc;
-        if (int rc = ringmin.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.Ra.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.Rb.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.slot_of.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.fin.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.d_heads.alloc(seg_cap, err)) return rc;
+        if (int rc = cs.ringmin.alloc(seg_cap, err)) return rc;
         // (the list may have grown by the orphan cycles; grids cover the n_spl the host knows plus a margin, the
         // kernels loop to the device-side count)
         const int gr = grid_for((uint64_t)n_spl + 65536u);
         // (a chain has at most n_spl splitters: the ones k_orphan_cycles appends are chains of their own)
         int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl + 1u) { reach *= RANK_HOPS; rounds++; } }
         EvTimer tr(stream_);
-        HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
-        hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ra.p);
-        RankRec *Ri = Ra.p, *Ro = Rb.p;
+        HIPCHK(hipMemsetAsync(cs.slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
+        hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, cs.Ra.p);
+        RankRec *Ri = cs.Ra.p, *Ro = cs.Rb.p;
         for (int r = 0; r < rounds; r++) {
             hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, d_nspl, Ri, Ro);
             std::swap(Ri, Ro);
         }
         const unsigned int *d_ncyc = (const unsigned int *)(ctl_.p + 7);
-        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, segs.p, d_nspl, Ri, d_heads.p, slot_of.p, ringmin.p,
+        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, cs.segs.p, d_nspl, Ri, cs.d_heads.p, cs.slot_of.p, cs.ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
-        hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, segs.p, d_nspl, Ri, slot_of.p, fin.p);
-        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, ol.p, frag.p, fin.p);
-        // rings: their smallest k-mer (these three return at once when there is none)
-        hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
-        hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, ol.p, ringmin.p, d_ncyc);
-        hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, d_heads.p, (const unsigned int *)(ctl_.p + 6), ringmin.p,
-                           winfo.p, ol.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
+        hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, Ri, cs.slot_of.p, cs.fin.p);
+        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, cs.ol.p, cs.frag.p, cs.fin.p);
+        if (rings) {
+            // rings: their smallest k-mer (these three return at once when there is none)
+            hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
+            hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
+            hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), cs.ringmin.p,
+                               cs.winfo.p, cs.ol.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
+        }
         HIPCHK(hipGetLastError());
         unsigned long long hc[4];
         // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
         // round trip just for them is 30-40 us of idle GPU)
         constexpr unsigned int HEADS_SPEC = 512;
-        std::vector<HeadRec> heads(HEADS_SPEC);
+        std::vector<HeadRec> &heads = cs.heads;
+        heads.assign(HEADS_SPEC, HeadRec());
         HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipMemcpyAsync(heads.data(), d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(heads.data(), cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
         HIPCHK(stream_wait(stream_));
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
         times_.add("collapse_rank_device", tr.stop());
         heads.resize(n_heads);
-        if (n_heads > HEADS_SPEC)
-            HIPCHK(hipMemcpy(heads.data() + HEADS_SPEC, d_heads.p + HEADS_SPEC, (size_t)(n_heads - HEADS_SPEC) * sizeof(HeadRec), hipMemcpyDeviceToHost));
+        // (sharded assembly: the chain records stay on the device — one per ~10 nodes; only their number is needed here)
+        if (rings && n_heads > HEADS_SPEC)
+            HIPCHK(hipMemcpy(heads.data() + HEADS_SPEC, cs.d_heads.p + HEADS_SPEC, (size_t)(n_heads - HEADS_SPEC) * sizeof(HeadRec), hipMemcpyDeviceToHost));
+        return 0;
+    }
+
+    int collapse(std::vector<RawContig> &out, std::string &err) override {
+        out.clear();
+        if (!graph_ready_) { err = "graph not built"; return -2; }
+        const uint32_t n = (uint32_t)n_solid_;
+        if (n == 0) return 0;
+        Graph<W> g = graph_view();
+        ChainState cs;
+        if (int rc = rank_chains(cs, true, err)) return rc;
+        std::vector<HeadRec> &heads = cs.heads;
+        DevBuf<EmitRec> d_off; DevBuf<char> d_out;
         // each unitig exists on both strands: keep the canonical one (decided on the device)
         std::vector<EmitRec> head_off(heads.size());
         std::vector<uint32_t> emitted;
@@ -1332,7 +1390,7 @@ public:
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
             HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * sizeof(EmitRec), hipMemcpyHostToDevice, stream_));
             EvTimer t3(stream_);
-            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, ol.p, d_off.p, d_out.p);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
@@ -1348,6 +1406,384 @@ public:
         }
         return 0;
     }
+
+    // ---- sharded assembly (shard_graph.h) ---------------------------------------------------------------------
+    int shard_keep_local(uint32_t world, uint32_t rank, uint32_t n_count_partitions, const uint64_t *rows_per_rank,
+                         const uint64_t histo[500], uint64_t total_instances, std::string &err) override {
+        if (world < 1 || world > ROUTE_MAX_WORLD || rank >= world || n_count_partitions < 1 || (n_count_partitions & (n_count_partitions - 1))) {
+            err = "shard_keep_local: bad world / rank / partition count"; return -1;
+        }
+        if (rows_per_rank[rank] != n_solid_) { err = "shard_keep_local: this rank's row count disagrees with the filter"; return -1; }
+        if (n_solid_ >= (1ull << 30)) { err = "sharded assembly: more than 2^30 solid k-mers on one rank"; return -1; }
+        sh_world_ = world; sh_rank_ = rank; sh_P_ = n_count_partitions;
+        sh_gbase_.assign(world + 1, 0);
+        for (uint32_t r = 0; r < world; r++) sh_gbase_[r + 1] = sh_gbase_[r] + rows_per_rank[r];
+        n_solid_global_ = sh_gbase_[world];
+        total_instances_ = total_instances; n_distinct_ = 0;
+        for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
+        sh_active_ = true; graph_ready_ = false;
+        return 0;
+    }
+    bool sharded_graph() const override { return sh_active_; }
+    uint64_t n_solid_global() const override { return sh_active_ ? n_solid_global_ : n_solid_; }
+
+    // n_items staged records (dest[i] = rank, or NIL: no record; PW words each) -> one pairwise exchange.  r.recv holds
+    // what the other ranks sent here (source-major), r.sidx[i] the index item i got in r.send (the order answers come back in)
+    struct Routed {
+        DevBuf<uint64_t> send, recv; DevBuf<uint32_t> sidx;
+        std::vector<uint64_t> send_cnt, recv_cnt; uint64_t n_send = 0, n_recv = 0;
+    };
+    template <int PW>
+    int route_exchange(ShardComm *c, const uint32_t *dest, const uint64_t *pay, uint32_t n_items, Routed &r, std::string &err) {
+        const uint32_t world = sh_world_;
+        DevBuf<uint32_t> d_cnt; DevBuf<unsigned long long> d_cur;
+        if (int rc = d_cnt.alloc(ROUTE_MAX_WORLD, err)) return rc;
+        if (int rc = d_cur.alloc(ROUTE_MAX_WORLD, err)) return rc;
+        std::vector<uint32_t> h_cnt(ROUTE_MAX_WORLD, 0);
+        if (n_items) {
+            HIPCHK(hipMemsetAsync(d_cnt.p, 0, ROUTE_MAX_WORLD * 4, stream_));
+            hipLaunchKernelGGL(k_route_count, dim3(grid_for(n_items)), dim3(256), 0, stream_, dest, n_items, d_cnt.p);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt.p, ROUTE_MAX_WORLD * 4, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(stream_wait(stream_));
+        }
+        r.send_cnt.assign(world, 0); r.recv_cnt.assign(world, 0); r.n_send = 0; r.n_recv = 0;
+        std::vector<unsigned long long> cur(ROUTE_MAX_WORLD, 0);
+        for (uint32_t d = 0; d < world; d++) { r.send_cnt[d] = h_cnt[d]; cur[d] = r.n_send; r.n_send += h_cnt[d]; }
+        // the size exchange: every rank's row of counts
+        std::vector<uint64_t> all((size_t)world * world);
+        if (int rc = comm_allgather_host_u64(c, r.send_cnt.data(), world, all.data(), stream_, err)) return rc;
+        for (uint32_t s = 0; s < world; s++) { r.recv_cnt[s] = all[(size_t)s * world + sh_rank_]; r.n_recv += r.recv_cnt[s]; }
+        if (int rc = r.send.alloc(r.n_send * PW + 1, err)) return rc;
+        if (int rc = r.recv.alloc(r.n_recv * PW + 1, err)) return rc;
+        if (int rc = r.sidx.alloc(n_items, err)) return rc;
+        if (n_items) {
+            HIPCHK(hipMemcpyAsync(d_cur.p, cur.data(), ROUTE_MAX_WORLD * 8, hipMemcpyHostToDevice, stream_));
+            hipLaunchKernelGGL((k_route_pack<PW>), dim3((n_items + ROUTE_CH - 1) / ROUTE_CH), dim3(256), 0, stream_, dest, pay, n_items,
+                               d_cur.p, r.send.p, r.sidx.p);
+            HIPCHK(hipGetLastError());
+        }
+        std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
+        uint64_t a = 0, b = 0;
+        for (uint32_t q = 0; q < world; q++) { so[q] = a; sb[q] = r.send_cnt[q] * PW * 8; a += sb[q]; ro[q] = b; rb[q] = r.recv_cnt[q] * PW * 8; b += rb[q]; }
+        if (int rc = comm_alltoallv(c, r.send.p, so.data(), sb.data(), r.recv.p, ro.data(), rb.data(), stream_, err)) return rc;
+        HIPCHK(stream_wait(stream_));                      // (d_cur / cur go out of scope; the caller reads r.recv next)
+        times_.add("shard_graph_exchanged_MB", (double)(r.n_send * PW * 8) / 1e6);
+        return 0;
+    }
+    // the answers to what was received (one u64 per received record, in r.recv's order) travel back: back[i] = answer to r.send[i]
+    int reply_exchange(ShardComm *c, const Routed &r, const unsigned long long *ans, DevBuf<unsigned long long> &back, std::string &err) {
+        const uint32_t world = sh_world_;
+        if (int rc = back.alloc(r.n_send + 1, err)) return rc;
+        std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
+        uint64_t a = 0, b = 0;
+        for (uint32_t q = 0; q < world; q++) { so[q] = a; sb[q] = r.recv_cnt[q] * 8; a += sb[q]; ro[q] = b; rb[q] = r.send_cnt[q] * 8; b += rb[q]; }
+        if (int rc = comm_alltoallv(c, ans, so.data(), sb.data(), back.p, ro.data(), rb.data(), stream_, err)) return rc;
+        HIPCHK(stream_wait(stream_));
+        return 0;
+    }
+
+    int shard_assemble(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) override {
+        out.clear();
+        if (!sh_active_) { err = "shard_assemble: the handle was not preprocessed by the sharded path"; return -2; }
+        const uint32_t world = sh_world_, rank = sh_rank_;
+        const uint32_t n = (uint32_t)n_solid_;
+        const unsigned long long gbase = sh_gbase_[rank];
+        // every local step's result travels with the next collective: all ranks leave together (as in shk_shard_preprocess)
+        auto agree = [&](int local_rc, const char *stage) -> int {
+            uint64_t f = local_rc ? 1u : 0u;
+            std::string e2;
+            if (int rc = comm_allreduce_host_u64(c, &f, 1, stream_, e2)) { if (local_rc) return local_rc; err = e2; return rc; }
+            if (local_rc) return local_rc;
+            if (f) { err = std::string("sharded assembly: another rank failed during ") + stage; return -5; }
+            return 0;
+        };
+        const double t_all0 = now_ms_();
+        // ---- 1. adjacency: local tables, local candidates, then the candidates of other ranks
+        xq_n_ = 0;
+        EvTimer tg(stream_);
+        int rc_local = build_graph(err);
+        if (int rc = agree(rc_local, "the local graph build")) return rc;
+        Graph<W> g = graph_view();
+        DevBuf<unsigned long long> xnb;                  // per cross query: the neighbour's oriented global id (~0: not a solid k-mer)
+        Routed rq;
+        DevBuf<uint32_t> xq_sidx_keep;
+        if (world > 1) {
+            if (int rc = route_exchange<W + 1>(c, xq_dest_.p, xq_pay_.p, xq_n_, rq, err)) return rc;
+            DevBuf<unsigned long long> ans, back;
+            if (int rc = ans.alloc(rq.n_recv + 1, err)) return rc;
+            if (rq.n_recv) {
+                hipLaunchKernelGGL(k_xq_answer<W>, dim3(grid_for(rq.n_recv)), dim3(256), 0, stream_, g.keys, g.gt, rq.recv.p, rq.n_recv, gbase, ans.p);
+                HIPCHK(hipGetLastError());
+            }
+            if (int rc = reply_exchange(c, rq, ans.p, back, err)) return rc;
+            if (int rc = xnb.alloc(xq_n_ + 1, err)) return rc;
+            if (xq_n_) {
+                hipLaunchKernelGGL(k_xq_apply, dim3(grid_for(xq_n_)), dim3(256), 0, stream_, xq_meta_.p, rq.sidx.p, back.p, xq_n_, adj_.p, nb_.p, xnb.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));    // (stage inspection: the complete initial adjacency)
+            }
+            HIPCHK(stream_wait(stream_));                // (ans / back go out of scope)
+            rq.send.release(); rq.recv.release();
+            xq_pay_.release(); xq_dest_.release();
+        } else if (int rc = xnb.alloc(1, err)) return rc;
+        times_.add("shard_graph_adjacency_total", tg.stop());
+        times_.add("shard_graph_cross_queries_x1e-3", xq_n_ * 1e-3);
+        // ---- 2. half links: which links across ranks are simple
+        EvTimer th(stream_);
+        DevBuf<uint32_t> xpred;                          // per local oriented node: record of hl.recv that names its simple predecessor on another rank
+        if (int rc = xpred.alloc(2ull * n + 2, err)) return rc;
+        HIPCHK(hipMemsetAsync(xpred.p, 0xFF, (2ull * n + 2) * 4, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+        Routed hl;
+        if (world > 1) {
+            DevBuf<uint32_t> hdest; DevBuf<uint64_t> hpay;
+            if (int rc = hdest.alloc(2ull * n + 1, err)) return rc;
+            if (int rc = hpay.alloc(4ull * n + 2, err)) return rc;
+            if (n) {
+                hipLaunchKernelGGL(k_hl_stage, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, adj_.p, nb_.p, n, xnb.p, xq_meta_.p, gbase, hdest.p, hpay.p);
+                HIPCHK(hipGetLastError());
+            }
+            if (int rc = route_exchange<2>(c, hdest.p, hpay.p, 2u * n, hl, err)) return rc;
+            if (hl.n_recv) {
+                hipLaunchKernelGGL(k_hl_apply, dim3(grid_for(hl.n_recv)), dim3(256), 0, stream_, hl.recv.p, hl.n_recv, gbase, n, adj_.p, xpred.p, (uint32_t *)(ctl_.p + 13));
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(stream_wait(stream_));
+            hl.send.release();
+        } else if (int rc = hl.recv.alloc(2, err)) return rc;
+        times_.add("shard_graph_half_links", th.stop());
+        // ---- 3. the chains of simple links that stay on this rank (the single-GPU contraction)
+        ChainState cs;
+        int rc_chain = 0;
+        if (n) rc_chain = rank_chains(cs, false, err);
+        const uint32_t n_lch = n ? (uint32_t)cs.heads.size() : 0u;
+        // ---- 4. stitching: the local chains of all ranks, ranked by every rank
+        EvTimer ts(stream_);
+        std::vector<uint64_t> lcnt(world, 0), lbase(world + 1, 0);
+        {
+            uint64_t mine[2] = {rc_chain ? 0u : n_lch, rc_chain ? 1u : 0u};
+            std::vector<uint64_t> all2((size_t)world * 2);
+            if (int rc = comm_allgather_host_u64(c, mine, 2, all2.data(), stream_, err)) { if (rc_chain) return rc_chain; return rc; }
+            if (rc_chain) return rc_chain;
+            for (uint32_t r = 0; r < world; r++) { if (all2[2 * r + 1]) { err = "sharded assembly: another rank failed during the local contraction"; return -5; } lcnt[r] = all2[2 * r]; }
+            for (uint32_t r = 0; r < world; r++) lbase[r + 1] = lbase[r] + lcnt[r];
+        }
+        const uint64_t M = lbase[world];
+        if (M >= 0xFFFFFFF0ull) { err = "sharded assembly: more than 2^32 local chains"; return -1; }
+        DevBuf<SegRec> lsegs, gsegs;
+        DevBuf<unsigned long long> d_gbases;
+        if (int rc = lsegs.alloc(n_lch + 1, err)) return rc;
+        if (int rc = gsegs.alloc(M + 1, err)) return rc;
+        if (int rc = d_gbases.alloc(world + 1, err)) return rc;
+        HIPCHK(hipMemcpyAsync(d_gbases.p, sh_gbase_.data(), (size_t)(world + 1) * 8, hipMemcpyHostToDevice, stream_));
+        {
+            DevBuf<uint32_t> ldest; DevBuf<uint64_t> lpay; DevBuf<unsigned long long> lans, lback;
+            Routed ls;
+            if (int rc = ldest.alloc(n_lch + 1, err)) return rc;
+            if (int rc = lpay.alloc(n_lch + 1, err)) return rc;
+            if (n_lch) {
+                hipLaunchKernelGGL(k_lchain_stage, dim3(grid_for(n_lch)), dim3(256), 0, stream_, cs.d_heads.p, n_lch, xpred.p, hl.recv.p,
+                                   d_gbases.p, world, lsegs.p, ldest.p, lpay.p);
+                HIPCHK(hipGetLastError());
+            }
+            if (world > 1) {
+                if (int rc = route_exchange<1>(c, ldest.p, lpay.p, n_lch, ls, err)) return rc;
+                if (int rc = lans.alloc(ls.n_recv + 1, err)) return rc;
+                if (ls.n_recv) {
+                    hipLaunchKernelGGL(k_ls_answer, dim3(grid_for(ls.n_recv)), dim3(256), 0, stream_, ls.recv.p, ls.n_recv, gbase, n, cs.ol.p,
+                                       (uint32_t)lbase[rank], lans.p, (uint32_t *)(ctl_.p + 13));
+                    HIPCHK(hipGetLastError());
+                }
+                if (int rc = reply_exchange(c, ls, lans.p, lback, err)) return rc;
+            } else { if (int rc = lback.alloc(1, err)) return rc; if (int rc = ls.sidx.alloc(n_lch + 1, err)) return rc; }
+            if (n_lch) {
+                hipLaunchKernelGGL(k_ls_apply, dim3(grid_for(n_lch)), dim3(256), 0, stream_, ldest.p, ls.sidx.p, lback.p, n_lch, (uint32_t)lbase[rank], lsegs.p);
+                HIPCHK(hipGetLastError());
+            }
+            // gather the chain records of all ranks (32 bytes each)
+            std::vector<uint64_t> off(world), len(world);
+            for (uint32_t r = 0; r < world; r++) { off[r] = lbase[r] * sizeof(SegRec); len[r] = lcnt[r] * sizeof(SegRec); }
+            if (int rc = comm_allgatherv(c, lsegs.p, gsegs.p, off.data(), len.data(), stream_, err)) return rc;
+            unsigned int fl = 0;
+            if (int rc = read_ctl(fl, 13, err)) return rc;         // (also: the staging buffers above are idle when they go)
+            if (fl) { err = fl == 1 ? "sharded assembly: a record reached a rank that does not own its k-mer (ownership rules disagree)" : "sharded assembly: the two sides of a link across ranks disagree"; return -6; }
+        }
+        // rank the gathered list: unitigs (rings across ranks in the same pass: collapse.h)
+        DevBuf<RankRec> Ra, Rb; DevBuf<uint32_t> slot_of, uid_of_slot; DevBuf<FinRec> fin; DevBuf<UHead> d_uheads; DevBuf<unsigned int> d_M;
+        const uint32_t Mu = (uint32_t)M;
+        if (int rc = Ra.alloc(M + 1, err)) return rc;
+        if (int rc = Rb.alloc(M + 1, err)) return rc;
+        if (int rc = slot_of.alloc(M + 1, err)) return rc;
+        if (int rc = fin.alloc(M + 1, err)) return rc;
+        if (int rc = d_uheads.alloc(M + 1, err)) return rc;
+        if (int rc = d_M.alloc(2, err)) return rc;
+        unsigned int n_u = 0;
+        std::vector<UHead> uheads;
+        if (Mu) {
+            const unsigned int hM[2] = {Mu, 0u};
+            HIPCHK(hipMemcpyAsync(d_M.p, hM, 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemsetAsync(slot_of.p, 0xFF, (size_t)M * 4, stream_));
+            const int gr = grid_for(M);
+            int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < M + 1u) { reach *= RANK_HOPS; rounds++; } }
+            hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, gsegs.p, (const unsigned int *)d_M.p, Ra.p);
+            RankRec *Ri = Ra.p, *Ro = Rb.p;
+            for (int r = 0; r < rounds; r++) { hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, (const unsigned int *)d_M.p, Ri, Ro); std::swap(Ri, Ro); }
+            hipLaunchKernelGGL(k_stitch_tails, dim3(gr), dim3(256), 0, stream_, gsegs.p, (const unsigned int *)d_M.p, Ri, d_uheads.p, slot_of.p, d_M.p + 1);
+            hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, gsegs.p, (const unsigned int *)d_M.p, Ri, slot_of.p, fin.p);
+            HIPCHK(hipGetLastError());
+            unsigned int hM2[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(hM2, d_M.p, 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(stream_wait(stream_));
+            n_u = hM2[1];
+            uheads.resize(n_u);
+            if (n_u) HIPCHK(hipMemcpy(uheads.data(), d_uheads.p, (size_t)n_u * sizeof(UHead), hipMemcpyDeviceToHost));
+        }
+        times_.add("shard_graph_stitch", ts.stop());
+        times_.add("shard_graph_local_chains_x1e-3", n_lch * 1e-3);
+        times_.add("shard_graph_unitigs_x1", (double)n_u);
+        // ---- 5. the unitig graph on the host (identical on every rank: the records are put in the order of their first chain)
+        const double t_host0 = now_ms_();
+        std::vector<uint32_t> order(n_u);
+        for (uint32_t i = 0; i < n_u; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return uheads[a].root < uheads[b].root; });
+        std::vector<uint32_t> h_uid_of_slot(n_u);
+        for (uint32_t u = 0; u < n_u; u++) h_uid_of_slot[order[u]] = u;
+        // first / last k-mer of every unitig: asked of the rank that holds that chain
+        std::vector<EndReq> reqs;
+        for (uint32_t u = 0; u < n_u; u++) {
+            const UHead &h = uheads[order[u]];
+            if (h.root >= lbase[rank] && h.root < lbase[rank + 1]) reqs.push_back(EndReq{u, 0u, (uint32_t)(h.root - lbase[rank]), 0u});
+            if (h.tail >= lbase[rank] && h.tail < lbase[rank + 1]) reqs.push_back(EndReq{u, 1u, (uint32_t)(h.tail - lbase[rank]), 0u});
+        }
+        DevBuf<EndReq> d_req; DevBuf<uint64_t> d_ends;
+        const size_t ends_words = (size_t)n_u * 2 * W;
+        if (int rc = d_req.alloc(reqs.size() + 1, err)) return rc;
+        if (int rc = d_ends.alloc(ends_words + 1, err)) return rc;
+        if (int rc = uid_of_slot.alloc(n_u + 1, err)) return rc;
+        std::vector<uint64_t> h_ends(ends_words + 1, 0);
+        if (n_u) {
+            HIPCHK(hipMemsetAsync(d_ends.p, 0, ends_words * 8, stream_));
+            HIPCHK(hipMemcpyAsync(uid_of_slot.p, h_uid_of_slot.data(), (size_t)n_u * 4, hipMemcpyHostToDevice, stream_));
+            if (!reqs.empty()) {
+                HIPCHK(hipMemcpyAsync(d_req.p, reqs.data(), reqs.size() * sizeof(EndReq), hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL(k_fill_ends<W>, dim3(grid_for(reqs.size())), dim3(256), 0, stream_, g, cs.d_heads.p, d_req.p, (uint32_t)reqs.size(), d_ends.p);
+                HIPCHK(hipGetLastError());
+            }
+            if (int rc = comm_allreduce_u64(c, d_ends.p, ends_words, stream_, err)) return rc;     // (every word is written by exactly one rank)
+            HIPCHK(hipMemcpyAsync(h_ends.data(), d_ends.p, ends_words * 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(stream_wait(stream_));
+        }
+        std::vector<UnitigRec> recs(n_u);
+        for (uint32_t u = 0; u < n_u; u++) {
+            const UHead &h = uheads[order[u]];
+            for (int w = 0; w < W; w++) { recs[u].first[w] = h_ends[((size_t)u * 2 + 0) * W + w]; recs[u].last[w] = h_ends[((size_t)u * 2 + 1) * W + w]; }
+            recs[u].len = h.len; recs[u].kc = h.kc; recs[u].circ = h.circ;
+        }
+        UnitigGraphResult res;
+        int rc_ug = unitig_assemble(k_, recs, tips, bubbles, res, err);
+        if (int rc = agree(rc_ug ? -6 : 0, "the unitig graph")) return rc;
+        tips_removed_ = res.tips_removed; bubbles_removed_ = res.bubbles_removed; rounds_ = res.rounds;
+        // rings: the smallest k-mer of their records — a pass over the nodes of the rings, on every rank, merged on the host
+        if (!res.need_min.empty()) {
+            const uint32_t n_rings = (uint32_t)res.need_min.size();
+            std::vector<uint32_t> ring_of_uid(n_u, NIL);
+            for (uint32_t i = 0; i < n_rings; i++) ring_of_uid[res.need_min[i]] = i;
+            DevBuf<uint32_t> d_ring_of_uid, ring_of, vmin; DevBuf<unsigned long long> pmin; DevBuf<uint64_t> rep;
+            if (int rc = d_ring_of_uid.alloc(n_u + 1, err)) return rc;
+            if (int rc = ring_of.alloc(n_lch + 1, err)) return rc;
+            if (int rc = vmin.alloc(n_rings + 1, err)) return rc;
+            if (int rc = pmin.alloc(n_rings + 1, err)) return rc;
+            if (int rc = rep.alloc((size_t)n_rings * (W + 2) + 1, err)) return rc;
+            HIPCHK(hipMemcpyAsync(d_ring_of_uid.p, ring_of_uid.data(), (size_t)n_u * 4, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemsetAsync(pmin.p, 0xFF, (size_t)n_rings * 8, stream_));
+            HIPCHK(hipMemsetAsync(vmin.p, 0xFF, (size_t)n_rings * 4, stream_));
+            std::vector<uint64_t> h_pmin(n_rings, ~0ull), all_pmin((size_t)world * n_rings);
+            if (n_lch) {
+                hipLaunchKernelGGL(k_ring_of, dim3(grid_for(n_lch)), dim3(256), 0, stream_, fin.p, (uint32_t)lbase[rank], n_lch, uid_of_slot.p, d_ring_of_uid.p, ring_of.p);
+                hipLaunchKernelGGL(k_sring_min1<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, cs.ol.p, ring_of.p, pmin.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h_pmin.data(), pmin.p, (size_t)n_rings * 8, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(stream_wait(stream_));
+            }
+            if (int rc = comm_allgather_host_u64(c, h_pmin.data(), n_rings, all_pmin.data(), stream_, err)) return rc;
+            for (uint32_t i = 0; i < n_rings; i++) for (uint32_t r = 0; r < world; r++) h_pmin[i] = std::min(h_pmin[i], all_pmin[(size_t)r * n_rings + i]);
+            std::vector<uint64_t> h_rep((size_t)n_rings * (W + 2), ~0ull), all_rep((size_t)world * n_rings * (W + 2));
+            if (n_lch) {
+                HIPCHK(hipMemcpyAsync(pmin.p, h_pmin.data(), (size_t)n_rings * 8, hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL(k_sring_min2<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, cs.ol.p, ring_of.p, pmin.p, vmin.p);
+                hipLaunchKernelGGL(k_sring_report<W>, dim3(grid_for(n_rings)), dim3(256), 0, stream_, g, cs.ol.p, fin.p, (uint32_t)lbase[rank], vmin.p, n_rings, rep.p);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h_rep.data(), rep.p, h_rep.size() * 8, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(stream_wait(stream_));
+            }
+            if (int rc = comm_allgather_host_u64(c, h_rep.data(), h_rep.size(), all_rep.data(), stream_, err)) return rc;
+            std::vector<UnitigMinKey> mk(n_u);
+            for (uint32_t i = 0; i < n_rings; i++) {
+                UnitigMinKey best;
+                for (uint32_t r = 0; r < world; r++) {
+                    const uint64_t *o = &all_rep[((size_t)r * n_rings + i) * (W + 2)];
+                    if (o[W] == ~0ull) continue;
+                    UnitigMinKey cand; cand.valid = true; cand.o = (uint32_t)o[W]; cand.pos = o[W + 1];
+                    for (int w = 0; w < W; w++) cand.key[w] = o[w];
+                    bool less = !best.valid;
+                    if (!less) {
+                        bool decided = false;
+                        for (int w = W - 1; w >= 0 && !decided; w--) if (cand.key[w] != best.key[w]) { less = cand.key[w] < best.key[w]; decided = true; }
+                        if (!decided) less = cand.o < best.o;
+                    }
+                    if (less) best = cand;
+                }
+                mk[res.need_min[i]] = best;
+            }
+            int rc_rr = unitig_resolve_rings(k_, recs, mk, res, err);
+            if (int rc = agree(rc_rr ? -6 : 0, "the rings of the unitig graph")) return rc;
+        }
+        // layout: contig text offsets, and for every unitig record where its nodes go
+        std::vector<ULayout> lay(n_u + 1);
+        for (auto &L : lay) { L.off = ~0ull; L.node_off = 0; L.ring_len = 0; L.rot = 0; }
+        uint64_t text_bytes = 0;
+        std::vector<uint64_t> c_off(res.contigs.size());
+        for (size_t i = 0; i < res.contigs.size(); i++) {
+            const UnitigContig &ct = res.contigs[i];
+            c_off[i] = text_bytes;
+            uint64_t node_off = 0;
+            for (uint32_t r : ct.recs) {
+                lay[r].off = text_bytes; lay[r].node_off = node_off; lay[r].ring_len = ct.ring ? ct.len_nodes : 0; lay[r].rot = ct.ring ? ct.rot : 0;
+                node_off += recs[r].len;
+            }
+            text_bytes += ct.len_nodes + (uint64_t)(k_ - 1);
+        }
+        times_.add("shard_graph_unitig_host_clock", now_ms_() - t_host0);
+        // ---- 6. emission
+        EvTimer te(stream_);
+        const uint64_t text_words = (text_bytes + 7) / 8;
+        DevBuf<ULayout> d_lay; DevBuf<char> d_text;
+        if (int rc = d_lay.alloc(n_u + 1, err)) return rc;
+        if (int rc = d_text.alloc(text_words * 8 + 8, err)) return rc;
+        if (int rc = hout_.alloc(text_words * 8 + 8, err)) return rc;
+        if (text_bytes) {
+            HIPCHK(hipMemsetAsync(d_text.p, 0, text_words * 8, stream_));
+            HIPCHK(hipMemcpyAsync(d_lay.p, lay.data(), (size_t)(n_u + 1) * sizeof(ULayout), hipMemcpyHostToDevice, stream_));
+            if (n) {
+                hipLaunchKernelGGL(k_shard_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, cs.ol.p, fin.p, (uint32_t)lbase[rank], uid_of_slot.p, d_lay.p, d_text.p);
+                HIPCHK(hipGetLastError());
+            }
+            if (int rc = comm_allreduce_u64(c, d_text.p, text_words, stream_, err)) return rc;      // (the ranks' bytes are disjoint: sum = merge)
+            HIPCHK(hipMemcpyAsync(hout_.p, d_text.p, text_words * 8, hipMemcpyDeviceToHost, stream_));
+        }
+        HIPCHK(stream_wait(stream_));
+        times_.add("shard_graph_emit", te.stop());
+        out.reserve(res.contigs.size());
+        for (size_t i = 0; i < res.contigs.size(); i++) {
+            RawContig rcg; rcg.kc = res.contigs[i].kc;
+            rcg.ext = hout_.p + c_off[i]; rcg.ext_n = res.contigs[i].len_nodes + (uint64_t)(k_ - 1);
+            out.push_back(std::move(rcg));
+        }
+        times_.add("shard_assemble_host_clock", now_ms_() - t_all0);
+        return 0;
+    }
+    static double now_ms_() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 private:
     int k_;
@@ -1387,6 +1823,13 @@ private:
     DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;
     uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;
+    // sharded assembly (shard_graph.h)
+    bool sh_active_ = false;
+    uint32_t sh_world_ = 1, sh_rank_ = 0, sh_P_ = 1;
+    std::vector<uint64_t> sh_gbase_;                 // [world + 1] first global node id of every rank
+    uint64_t n_solid_global_ = 0;
+    uint32_t xq_n_ = 0;                              // cross-rank neighbour queries of this rank (build_graph)
+    DevBuf<uint32_t> xq_dest_; DevBuf<uint64_t> xq_pay_; DevBuf<unsigned long long> xq_meta_;
 };
 
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }

@@ -87,6 +87,41 @@ def main():
                 res[str(i)]["asm"] = asm
         with open(f"{out_path}.{rank}", "w") as f:
             json.dump(res, f)
+    elif mode == "rccl_many":
+        # several inputs through shk_shard_preprocess + the collective shk_assemble in ONE launch (process start-up is
+        # most of a small case's time): cfg["cases"] = [{fastq, k, min_count, min_qual, do_fit, no_bubble_collapse,
+        # no_dead_end_removal, P}]; every rank writes the list of its results
+        from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
+        from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+        dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
+        torch.cuda.set_device(dev)
+        cfg = json.load(open(sys.argv[3]))
+        comm = LibComm(rank, world)
+        results = []
+        for cs in cfg["cases"]:
+            fq = open(cs["fastq"], "rb").read()
+            k = cs["k"]
+            recs = fq.decode().split("@r")[1:]
+            mine = ("@r" + "@r".join(recs[rank::world])).encode() if recs[rank::world] else b""
+            bases, seg, nb, nr = pack_fastq(mine, k, cs["min_qual"])
+            d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+            d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+            torch.cuda.synchronize()
+            h = AssemblyHelper.new(k, bool(cs.get("verbose", False)), cs["min_count"], cs["min_qual"], 0, False, bool(cs.get("do_fit", False)),
+                                   bool(cs.get("no_bubble_collapse", False)), bool(cs.get("no_dead_end_removal", False)))
+            try:
+                sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm, n_partitions=cs.get("P") or 0)
+                h.assemble()
+                res = {"pre": h.get_preprocessing_info(), "asm": h.get_assembly(), "n_solid_local": h.n_solid}
+                if cs.get("timings"):
+                    res["timings"] = h.timings()
+            except ShkError as e:
+                res = {"error": str(e)}
+            results.append(res)
+            h.free()
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(results, f)
+        comm.free()
     elif mode == "rccl":
         from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
         from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
@@ -110,6 +145,8 @@ def main():
         d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
         torch.cuda.synchronize()
         h = AssemblyHelper.new(k, True, cfg["min_count"], cfg["min_qual"], 0, False, cfg["do_fit"], False, False)
+        if cfg.get("replicated"):                      # round 2's path: gather the solid set, every rank assembles the whole graph
+            os.environ["SHK_SHARD_GRAPH"] = "0"
         inj = cfg.get("inject")                        # {"rank": r, "step": s}: that rank's local step fails (SHK_FAULT_INJECT)
         if inj and inj["rank"] == rank:
             os.environ["SHK_FAULT_INJECT"] = inj["step"]

@@ -230,8 +230,9 @@ def mock_rccl_library():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,k,do_fit,P", [(2, 31, False, 0), (3, 51, True, 64), (4, 31, False, 128)])
-def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P):
+@pytest.mark.parametrize("world,k,do_fit,P,replicated", [(2, 31, False, 0, False), (3, 51, True, 64, False), (4, 31, False, 128, False),
+                                                         (3, 31, True, 0, True)])
+def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P, replicated):
     """shk_shard_preprocess with 2, 3 and 4 ranks on the one GPU: the library's own multi-rank code (size exchange,
     plan, pack, the pairwise exchange with its offsets, histogram all-reduce, gather of the solid rows) runs exactly
     as on a node, only the bytes travel through tests/mock_rccl instead of RCCL (which refuses two ranks on one
@@ -245,9 +246,9 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
             fqp = os.path.join(d, "reads.fq")
             open(fqp, "wb").write(fq)
             cfgp = os.path.join(d, "cfg.json")
-            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P}, open(cfgp, "w"))
+            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P, "replicated": replicated}, open(cfgp, "w"))
             out = os.path.join(d, "res")
-            launch(world, ["rccl", out, cfgp], 29760 + world, timeout=300)
+            launch(world, ["rccl", out, cfgp], 29760 + world + (10 if replicated else 0), timeout=300)
             res = [json.load(open(f"{out}.{r}")) for r in range(world)]
     finally:
         os.environ.pop("SHK_RCCL_LIBRARY", None)
@@ -261,7 +262,7 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,step,bad_rank", [(2, "pass1", 1), (3, "pack", 2), (2, "count", 0), (3, "rows", 1), (2, "alloc", 1)])
+@pytest.mark.parametrize("world,step,bad_rank", [(2, "pass1", 1), (3, "pack", 2), (2, "count", 0), (3, "rows", 1), (2, "keep", 1), (2, "alloc", 1)])
 def test_a_failure_on_one_rank_ends_the_collective_call_on_every_rank(world, step, bad_rank):
     """A local failure on ONE rank of shk_shard_preprocess (device memory, a slice or partition that overflows: all
     depend on that rank's share of the reads) must not leave the other ranks blocked in the next collective: the
@@ -277,6 +278,7 @@ def test_a_failure_on_one_rank_ends_the_collective_call_on_every_rank(world, ste
             open(fqp, "wb").write(fq)
             cfgp = os.path.join(d, "cfg.json")
             json.dump({"fastq": fqp, "k": 31, "min_count": 3, "min_qual": 20, "do_fit": False, "P": 64,
+                       "replicated": step == "alloc",        # (that step exists only where the solid set is gathered)
                        "inject": {"rank": bad_rank, "step": step}}, open(cfgp, "w"))
             out = os.path.join(d, "res")
             launch(world, ["rccl", out, cfgp], 29780 + world, timeout=180)
@@ -310,3 +312,147 @@ print("OK", msg)
     env = dict(os.environ, SHK_ROOT=ROOT, SHK_RCCL_LIBRARY="/nonexistent/librccl.so.1")
     pr = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=120)
     assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-1500:]
+
+
+# ---- the graph phases sharded over the ranks (csrc/shard_graph.h) -----------------------------------------------------
+def _write_cases(d, cases):
+    out = []
+    for i, (fq, params) in enumerate(cases):
+        fqp = os.path.join(d, f"reads{i}.fq")
+        open(fqp, "wb").write(fq)
+        out.append(dict(params, fastq=fqp))
+    cfgp = os.path.join(d, "cfg.json")
+    json.dump({"cases": out}, open(cfgp, "w"))
+    return cfgp
+
+
+def _oracle_jsons(fq, params):
+    from util import run_oracle
+    o = run_oracle([fq], k=params["k"], min_count=params["min_count"], min_qual=params["min_qual"], do_fit=params.get("do_fit", False),
+                   no_bubble_collapse=params.get("no_bubble_collapse", False), no_dead_end_removal=params.get("no_dead_end_removal", False))
+    o.assemble()
+    return o.preprocessing_json(), o.assembly_json()
+
+
+def _graph_cases(seed, n, first_case=0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle import _random_graph_case
+    rng = np.random.default_rng(seed)
+    cases = []
+    for case in range(first_case, first_case + n):
+        fq, k, min_count, flags = _random_graph_case(rng, case)
+        cases.append((fq, dict(k=k, min_count=min_count, min_qual=0, **flags)))
+    return cases
+
+
+@pytest.mark.gpu
+def test_sharded_graph_one_rank_random_graphs():
+    """The sharded assembly (local contraction -> stitching -> tips / bubbles on the UNITIG graph -> emission) with a
+    one-rank RCCL communicator, in this process: 120 small random graphs with errors, repeats, hairpins, plasmids and
+    tandem rings (the inputs that pin the oracle in test_oracle.py) must give the oracle's bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    from sparrowhawk_amd import AssemblyHelper, pack_fastq
+    from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+    dev = torch.device("cuda", 0)
+    comm = LibComm(0, 1)
+    try:
+        for fq, pr in _graph_cases(8100, 120):
+            bases, seg, nb, nr = pack_fastq(fq, pr["k"], 0)
+            d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+            d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+            torch.cuda.synchronize()
+            h = AssemblyHelper.new(pr["k"], False, pr["min_count"], 0, 0, False, False, pr["no_bubble_collapse"], pr["no_dead_end_removal"])
+            sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm)
+            h.assemble()
+            pre, asm = _oracle_jsons(fq, pr)
+            assert h.get_preprocessing_info() == pre
+            assert h.get_assembly() == asm, pr
+            assert "shard_graph_stitch" in h.timings()
+            h.free()
+    finally:
+        comm.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_graph_several_ranks(world):
+    """The graph sharded over 2, 3 and 4 ranks (on the one GPU, bytes through tests/mock_rccl): neighbour queries and
+    answers across ranks, half links, local chains stitched across ranks, rings that span ranks, tips and bubbles on
+    the unitig graph, every rank emitting its own bases.  30 random small graphs, a circular chromosome with two
+    plasmids, an error-rich linear genome with the fitted threshold and a two-word k: every rank ends with the
+    oracle's bytes."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset
+    from sparrowhawk_amd import synth
+    cases = _graph_cases(8200 + world, 30, first_case=world)
+    # a circular chromosome + plasmids (rings across ranks), clean and with errors
+    for seed, err, k, mc in ((31, 0.0, 31, 3), (32, 0.01, 31, 2), (33, 0.005, 51, 2)):
+        chrom = synth.random_genome(60000, seed)
+        p1, p2 = synth.random_genome(5000, seed + 100), synth.random_genome(700, seed + 200)
+        fqs = []
+        for j, (g, cov) in enumerate(((chrom, 40), (p1, 60), (p2, 80))):
+            codes, quals = synth.sample_reads(g, len(g) * cov // 150, 150, seed * 10 + j, err=err, circular=True)
+            fqs.append(synth.to_fastq(codes, quals))
+        # (the worker deals the records out by rank, cutting the text at "@r")
+        recs = []
+        for fqx in fqs:
+            recs.extend(fqx.decode().split("@r")[1:])
+        fq = ("@r" + "@r".join(recs)).encode()
+        cases.append((fq, dict(k=k, min_count=mc, min_qual=20)))
+    g, fq = make_dataset(150000, 40, err=0.01, seed=8300 + world)
+    cases.append((fq, dict(k=31, min_count=3, min_qual=20, do_fit=True)))
+    g, fq = make_dataset(50000, 30, err=0.01, seed=8400 + world)
+    cases.append((fq, dict(k=63, min_count=2, min_qual=0, P=64)))
+    os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            cfgp = _write_cases(d, cases)
+            out = os.path.join(d, "res")
+            launch(world, ["rccl_many", out, cfgp], 29800 + world, timeout=420)
+            res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    finally:
+        os.environ.pop("SHK_RCCL_LIBRARY", None)
+    for i, (fq, pr) in enumerate(cases):
+        pre, asm = _oracle_jsons(fq, pr)
+        for r in range(world):
+            assert "error" not in res[r][i], (i, r, res[r][i])
+            assert res[r][i]["pre"] == pre, (i, r)
+            assert res[r][i]["asm"] == asm, (i, r, pr)
+        if i >= 30:
+            assert sum(res[r][i]["n_solid_local"] for r in range(world)) == json.loads(pre)["nkmers"]      # nobody holds the whole set
+
+
+@pytest.mark.gpu
+def test_sharded_graph_work_per_rank_falls_with_the_rank_count():
+    """'per-rank graph + collapse kernel time falls ~ 1/N'.  A 3 Mbp genome at 30x through 1 and 4 ranks.
+    What can be asserted on a ONE-GPU box: every rank holds about a quarter of the rows (nobody holds the solid set),
+    the local chains are cut at rank edges (about one node in ten ends one) and the results are identical.  The four
+    ranks SHARE the one GPU here, so their node-level kernels run interleaved and a rank's elapsed kernel time is
+    inflated by up to the number of ranks: it is printed, and only bounded loosely (measured: 0.87 ms alone, 1.2 ms
+    elapsed per rank with four ranks on the card, i.e. ~0.3 ms of GPU time each)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset
+    g, fq = make_dataset(3000000, 30, seed=8500)
+    pr = dict(k=31, min_count=3, min_qual=20, timings=True)
+    keys = ("graph_table_kernel", "adjacency_kernel", "collapse_succ_split", "collapse_walk", "collapse_rank_device")
+    os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    per_world = {}
+    try:
+        for world in (1, 4):
+            with tempfile.TemporaryDirectory() as d:
+                cfgp = _write_cases(d, [(fq, pr), (fq, pr)])          # (twice: the second run is warm)
+                out = os.path.join(d, "res")
+                launch(world, ["rccl_many", out, cfgp], 29810 + world, timeout=420)
+                per_world[world] = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    finally:
+        os.environ.pop("SHK_RCCL_LIBRARY", None)
+    assert per_world[1][0][1]["asm"] == per_world[4][0][1]["asm"] == per_world[4][3][1]["asm"]
+    t1 = sum(per_world[1][0][1]["timings"][k] for k in keys)
+    t4 = [sum(per_world[4][r][1]["timings"][k] for k in keys) for r in range(4)]
+    rows = [per_world[4][r][1]["n_solid_local"] for r in range(4)]
+    chains = [per_world[4][r][1]["timings"]["shard_graph_local_chains_x1e-3"] * 1e3 for r in range(4)]
+    print("node-level kernel ms: one rank", t1, "four ranks sharing the GPU", t4, "rows", rows, "local chains", chains)
+    assert max(rows) < 0.3 * sum(rows), rows
+    assert all(0.03 * r < c < 0.25 * r for r, c in zip(rows, chains)), (rows, chains)
+    assert max(t4) / 4 < 0.5 * t1, (t1, t4)        # GPU time per rank ~ elapsed / ranks on the card
