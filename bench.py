@@ -134,6 +134,7 @@ def main():
                     "(min_qual): reads are cut into error-free segments before they reach the device entry point")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed leg (packed reads in host pinned memory)")
+    ap.add_argument("--no-inflight-leg", action="store_true", help="skip the leg with two handles in flight")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a one-GPU box together with --one-gpu)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -295,6 +296,32 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         iso_leg = float(tt.item()) / args.steps
         del ib, iseg
+    # ---- two handles in flight (N = 1): a batch of isolates keeps the GPU busy while a handle's host side reads counters
+    # back and writes the FASTA / GFA text — each handle on its own host thread and stream (sparrowhawk_amd/batch.py does
+    # the same).  Reported beside `value` (which stays one handle at a time: its kernel timings are undisturbed).
+    inflight_leg = None
+    if world == 1 and not sharded and not args.no_inflight_leg:
+        import threading
+        n_fl, todo_lock, todo = 2, threading.Lock(), [0]
+
+        def fl_worker(n_total):
+            while True:
+                with todo_lock:
+                    if todo[0] >= n_total:
+                        return
+                    todo[0] += 1
+                one_step()
+        for n_total in (max(2, args.warmup), args.steps):          # warm-up (second stream, second set of pooled blocks), then timed
+            todo[0] = 0
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            ths = [threading.Thread(target=fl_worker, args=(n_total,)) for _ in range(n_fl)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            inflight_leg = (time.perf_counter() - tf) / n_total
     # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
     # strings on the host; the upload rides in front of pass 1 on the library's stream
     host_leg = None
@@ -369,8 +396,11 @@ def main():
                                f"({n_reads} reads, {n_bases} bases per GPU), k={args.k}, min_count={args.min_count}, "
                                f"{'error-free' if args.err == 0 else ('%g substitution errors%s' % (args.err, ', masked by quality' if args.mask_errors else ''))}, packed 2-bit in HBM",
                    "parallelism": ("single GPU" if world == 1 else
-                                   ("one pooled sample, k-mer space sharded by minimiser partition, one RCCL pairwise exchange "
-                                    "inside the library (shk_shard_preprocess), graph phases replicated" if args.collectives == "lib"
+                                   ("one pooled sample, k-mer space sharded by minimiser partition, one RCCL pairwise exchange of the "
+                                    "records inside the library (shk_shard_preprocess), " +
+                                    ("solid set gathered, graph phases replicated on every rank (SHK_SHARD_GRAPH=0)" if os.environ.get("SHK_SHARD_GRAPH") == "0"
+                                     else "graph phases sharded too (collective shk_assemble: neighbour queries, half links, stitched chains, "
+                                          "unitig-level correction, per-rank emission)") if args.collectives == "lib"
                                     else "one pooled sample, sharded, collectives by torch.distributed (" + args.backend + ")" +
                                          ("" if not lib_error else " — SECOND PATH: the library's RCCL communicator failed: " + str(lib_error)))
                                    if sharded else "one isolate per rank (batch of isolates), no data-path collective"),
@@ -394,7 +424,12 @@ def main():
         line["value_isolates_mode"] = n_bases * world / iso_leg / 1e9
         line["ms_per_step_isolates_mode"] = iso_leg * 1e3
         line["isolates_mode_note"] = ("comparison point: every rank assembles an isolate of its own (no data-path collective); "
-                                      "`value` is the sharded path, whose graph phases are replicated on every rank (DESIGN.md section 6)")
+                                      "`value` is the sharded path (DESIGN.md section 6)")
+    if inflight_leg is not None:
+        line["value_two_in_flight"] = n_bases / inflight_leg / 1e9
+        line["ms_per_step_two_in_flight"] = inflight_leg * 1e3
+        line["two_in_flight_note"] = ("the same steps with two handles in flight (two host threads, two streams): the kernels of one "
+                                      "handle fill the host gaps of the other — a batch of isolates on one GPU (sparrowhawk_amd/batch.py)")
     if host_leg is not None:
         line["value_host_pinned"] = n_bases / host_leg / 1e9
         line["ms_per_step_host_pinned"] = host_leg * 1e3

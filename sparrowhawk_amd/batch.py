@@ -6,7 +6,8 @@ one preprocess, one assemble); a batch is a loop over handles.  Two ways to spre
 
   rounds    one isolate per round, ALL ranks work on it: every rank holds 1/world of the isolate's reads,
             the k-mer space is sharded by minimiser partition and the records cross in one pairwise RCCL
-            exchange (shk_shard_preprocess); the graph phases then run on every rank (identical output).
+            exchange (shk_shard_preprocess); with the library's communicator the graph stays sharded too and
+            shk_assemble runs collectively (csrc/shard_graph.h); every rank ends with the identical output.
             Isolates never share a table, so no isolate id has to ride in the keys.
   replicas  isolate i belongs to rank i % world, which assembles it alone: independent objects, no
             data-path collective — the comparison point.
@@ -22,7 +23,7 @@ def isolates_of_rank(n_isolates, rank, world):
 
 
 def assemble_batch(n_isolates, reads_for, params, mode="rounds", rank=0, world=1, comm=None, torch_comm=None,
-                   keep=True, on_result=None):
+                   keep=True, on_result=None, inflight=2):
     """Assembles isolates 0..n_isolates-1.
 
     reads_for(i, share_rank, share_world) -> object with .words/.seg_off device tensors and n_seg / n_bases /
@@ -30,9 +31,13 @@ def assemble_batch(n_isolates, reads_for, params, mode="rounds", rank=0, world=1
     params: dict(k, min_count, min_qual, do_fit, no_bubble_collapse, no_dead_end_removal).
     comm: sparrowhawk_amd.dist.LibComm (RCCL inside the library) — or torch_comm: dist.Comm (the torch/gloo
         rehearsal of the same pieces) — for mode 'rounds' with world > 1.
+    inflight: replicas — handles kept in flight on this rank's GPU.  A handle's stream idles while its host side reads
+        counters back, sizes the next phase and writes the FASTA / GFA text (about a fifth of an isolate's wall time);
+        with two handles, each driven by its own host thread on its own stream, the kernels of one fill the gaps of the
+        other.  The reads are still produced one isolate after the other, by the calling thread.
     Returns {isolate: (preprocessing_json, assembly_json, timings)} for the isolates this rank finished
     (rounds: every isolate on every rank; replicas: this rank's own).  on_result(i, helper) is called before
-    the handle is freed (for stage inspection)."""
+    the handle is freed (for stage inspection; with inflight > 1 from a worker thread)."""
     if mode not in ("rounds", "replicas"):
         raise ValueError("mode must be 'rounds' or 'replicas'")
     out = {}
@@ -44,8 +49,8 @@ def assemble_batch(n_isolates, reads_for, params, mode="rounds", rank=0, world=1
 
     if mode == "replicas" or world == 1:
         mine = isolates_of_rank(n_isolates, rank, world) if mode == "replicas" else list(range(n_isolates))
-        for i in mine:
-            d = reads_for(i, 0, 1)
+
+        def one(i, d):
             h = new_helper()
             h.preprocess_packed_device(d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads)
             h.assemble()
@@ -53,7 +58,45 @@ def assemble_batch(n_isolates, reads_for, params, mode="rounds", rank=0, world=1
                 on_result(i, h)
             out[i] = (h.get_preprocessing_info(), h.get_assembly() if keep else None, h.timings())
             h.free()
-            del d
+
+        if inflight <= 1 or len(mine) <= 1:
+            for i in mine:
+                d = reads_for(i, 0, 1)
+                one(i, d)
+                del d
+            return out
+        # several handles in flight: the library's calls block, so every handle gets a host thread of its own
+        # (ctypes releases the interpreter lock inside them) and — inside the library — a stream of its own
+        import queue
+        import threading
+        todo = queue.Queue(maxsize=inflight)          # bounded: at most `inflight` isolates' reads wait on the device
+        errors = []
+
+        def worker():
+            while True:
+                item = todo.get()
+                if item is None:
+                    return
+                try:
+                    if not errors:
+                        one(*item)
+                except BaseException as e:             # noqa: BLE001 (handed to the caller below)
+                    errors.append(e)
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(inflight)]
+        for t in threads:
+            t.start()
+        try:
+            for i in mine:
+                if errors:
+                    break
+                todo.put((i, reads_for(i, 0, 1)))
+        finally:
+            for _ in threads:
+                todo.put(None)
+            for t in threads:
+                t.join()
+        if errors:
+            raise errors[0]
         return out
 
     from .dist import sharded_preprocess, sharded_preprocess_rccl

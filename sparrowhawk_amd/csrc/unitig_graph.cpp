@@ -214,10 +214,16 @@ template <int W> struct UG {
             if (!alive[r] || R[r].circ || pred[r] != UG_NIL || seen[r]) continue;
             UnitigContig c;
             for (uint32_t cur = r; cur != UG_NIL; cur = succ[cur]) { c.recs.push_back(cur); seen[cur] = 1; }
-            // the mirror strand is a chain of its own: the one whose first record has the smaller id speaks for both
-            const uint32_t mirror_first = mirror[c.recs.back()];
+            // the mirror strand is a chain of its own, covered here too.  SPEC S10 emits min(spelling, revcomp(spelling)),
+            // which the first k-mers decide (this chain's against its mirror's: two different oriented nodes): the smaller
+            // strand is the one handed on, so the writer never has to reverse-complement a chromosome
             for (uint32_t x : c.recs) seen[mirror[x]] = 1;
-            (void)mirror_first;
+            const uint32_t mirror_first = mirror[c.recs.back()];
+            if (km_less<W>(F[mirror_first], F[c.recs[0]])) {
+                std::vector<uint32_t> m;
+                for (size_t i = c.recs.size(); i-- > 0;) m.push_back(mirror[c.recs[i]]);
+                c.recs.swap(m);
+            }
             finish(c);
         }
         for (uint32_t r = 0; r < n; r++) {                           // what is left closes on itself: a ring made of several records
