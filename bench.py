@@ -119,6 +119,105 @@ def cpu_baseline(k, min_count, host_words, host_seg, n_bases, gpu_fasta):
                       f"build's CPU restatement, not upstream sparrowhawk-asm"}
 
 
+def run_legs(torch, dev, args, raw_get_assembly):
+    """BASELINE configs[2] and the FASTQ entry point, each timed like the headline (warm-up, then `--leg-steps` steps
+    bracketed by device synchronisation).  Gbases/s counts the bases of the READS (3 333 334 x 150) in every leg."""
+    import ctypes
+    from sparrowhawk_amd import AssemblyHelper, synth
+    legs = {}
+    n_reads = (args.genome * args.coverage + args.read_len - 1) // args.read_len
+    input_bases = n_reads * args.read_len
+
+    def timed(step, steps):
+        step()                                            # warm-up (allocations of this shape come from the pool afterwards)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ts = [step() for _ in range(steps)]
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, ts
+
+    def packed_leg(name, k, dr, bloom, note):
+        W = (2 * k + 63) // 64
+        state = {}
+
+        def step():
+            h = AssemblyHelper.new(k, False, args.min_count, 20, 0, bloom, False, False, False)
+            h.preprocess_packed_device(dr.words.data_ptr(), dr.seg_off.data_ptr(), dr.n_seg, dr.n_bases, dr.n_reads)
+            h.assemble()
+            ptr = raw_get_assembly(h._h)
+            assert ptr
+            if "ncontigs" not in state:
+                state["ncontigs"] = json.loads(ctypes.string_at(ptr))["ncontigs"]
+                state["n_solid"], state["n_distinct"] = h.n_solid, h.n_distinct
+            t = h.timings()
+            h.free()
+            return t
+        dt, ts = timed(step, args.leg_steps)
+        c_ms = sum(t.get("count_kernel", 0.0) for t in ts) / len(ts)
+        p_ms = sum(t.get("partition_kernel", 0.0) for t in ts) / len(ts)
+        alg = dr.n_bases * 0.25 + dr.n_seg * 4 + state["n_distinct"] * (8 * W + 4)
+        dom, k_ms = ("k_partition", p_ms) if p_ms > c_ms else ("count (k_count_partitions + k_ovf_scatter + k_count_buckets)", c_ms)
+        legs[name] = {
+            "workload": note, "value": input_bases / dt / 1e9, "unit": "Gbases/s", "ms_per_step": dt * 1e3, "steps": args.leg_steps,
+            "k": k, "segments": int(dr.n_seg), "bases_on_device": int(dr.n_bases), "n_distinct_kmers": state["n_distinct"],
+            "n_solid_kmers": state["n_solid"], "ncontigs": state["ncontigs"],
+            "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": k_ms, "count_step_ms": c_ms + p_ms,
+                         "algorithmic_bytes_per_launch": alg, "bytes_per_base": alg / max(1, dr.n_bases),
+                         "achieved": alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if k_ms > 0 else 0.0,
+                         "count_step_frac": (alg / ((c_ms + p_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if c_ms + p_ms > 0 else 0.0},
+            "stage_ms": {kk: sum(t.get(kk, 0.0) for t in ts) / len(ts) for kk in sorted(ts[-1]) if not kk.endswith("_x1")},
+        }
+
+    base = f"{args.genome} bp isolate, {args.coverage}x {args.read_len} bp reads ({n_reads} reads), "
+    dr = synth.device_reads(torch, dev, args.genome, n_reads, args.read_len, 51, 0xEC03, err=0.01, mask_errors=True)
+    packed_leg("config2_masked", 51, dr, False, base + "k=51, 1 %% substitution errors masked by quality (min_qual cuts the reads into "
+               "error-free segments before the device entry point), min_count=%d" % args.min_count)
+    del dr
+    dr = synth.device_reads(torch, dev, args.genome, n_reads, args.read_len, 51, 0xEC03, err=0.01, mask_errors=False)
+    packed_leg("config2_errors_left_in", 51, dr, False, base + "k=51, 1 %% substitution errors LEFT IN (every partition goes through the "
+               "k-mer-level repartition), min_count=%d" % args.min_count)
+    packed_leg("config2_errors_left_in_bloom", 51, dr, True, base + "k=51, 1 %% errors left in, do_bloom (Bloom pre-filter in front of the "
+               "repartition: singletons never stored), min_count=%d" % args.min_count)
+    del dr
+    torch.cuda.empty_cache()
+    # FASTQ text in host memory -> shk_preprocess (device parser, text uploaded in pieces under the parse) -> contigs
+    g = torch.Generator(device=dev); g.manual_seed(0xEC02)
+    genome = torch.randint(0, 4, (args.genome,), generator=g, device=dev, dtype=torch.int32)
+    parts = []
+    ar = torch.arange(args.read_len, device=dev)
+    for r0 in range(0, n_reads, 1 << 19):
+        r1 = min(n_reads, r0 + (1 << 19))
+        starts = torch.randint(0, args.genome - args.read_len + 1, (r1 - r0,), generator=g, device=dev)
+        strand = torch.randint(0, 2, (r1 - r0,), generator=g, device=dev).bool()
+        codes = genome[starts[:, None] + ar[None, :]]
+        codes = torch.where(strand[:, None], (3 - codes).flip(1), codes)
+        parts.append(synth.device_fastq_fixed(torch, codes).cpu())
+    fq = torch.cat(parts).numpy().tobytes()
+    del parts, genome
+    state = {}
+
+    def fq_step():
+        h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+        h.preprocess(fq)
+        h.assemble()
+        ptr = raw_get_assembly(h._h)
+        assert ptr
+        if "ncontigs" not in state:
+            state["ncontigs"] = json.loads(ctypes.string_at(ptr))["ncontigs"]
+        t = h.timings()
+        h.free()
+        return t
+    dt, ts = timed(fq_step, args.leg_steps)
+    legs["fastq_text"] = {
+        "workload": base + f"k={args.k}, error-free, as {len(fq) / 1e9:.2f} GB of FASTQ text in host (pageable) memory -> shk_preprocess "
+                    "(device parser, upload in pieces under the parse) -> shk_assemble -> contigs on the host; PCIe-inclusive",
+        "value": input_bases / dt / 1e9, "unit": "Gbases/s", "ms_per_step": dt * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
+        "stage_ms": {kk: sum(t.get(kk, 0.0) for t in ts) / len(ts) for kk in sorted(ts[-1]) if not kk.endswith("_x1")},
+    }
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +234,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the second timed leg (packed reads in host pinned memory)")
     ap.add_argument("--no-inflight-leg", action="store_true", help="skip the leg with two handles in flight")
+    ap.add_argument("--no-legs", action="store_true", help="skip the configs[2] and FASTQ-text legs")
+    ap.add_argument("--leg-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "the N>1 code path on a one-GPU box together with --one-gpu)")
     ap.add_argument("--one-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -322,6 +423,11 @@ def main():
                 t.join()
             torch.cuda.synchronize()
             inflight_leg = (time.perf_counter() - tf) / n_total
+    # ---- the other driver-timed legs (N = 1): BASELINE configs[2] (k = 51, 1 % errors: masked by quality, left in, and
+    # left in with the Bloom pre-filter) and the drop-in entry point on FASTQ text in host memory
+    legs = None
+    if world == 1 and not sharded and args.err == 0 and not args.no_legs and args.genome == 5_000_000:
+        legs = run_legs(torch, dev, args, raw_get_assembly)
     # ---- second leg (N = 1): the clock of SURVEY.md 8(d) — packed reads resident in host PINNED memory -> contig
     # strings on the host; the upload rides in front of pass 1 on the library's stream
     host_leg = None
@@ -425,6 +531,8 @@ def main():
         line["ms_per_step_isolates_mode"] = iso_leg * 1e3
         line["isolates_mode_note"] = ("comparison point: every rank assembles an isolate of its own (no data-path collective); "
                                       "`value` is the sharded path (DESIGN.md section 6)")
+    if legs is not None:
+        line["legs"] = legs
     if inflight_leg is not None:
         line["value_two_in_flight"] = n_bases / inflight_leg / 1e9
         line["ms_per_step_two_in_flight"] = inflight_leg * 1e3

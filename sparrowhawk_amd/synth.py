@@ -293,3 +293,27 @@ def isolate_batch_spec(n_isolates=96, lo=2_000_000, hi=7_000_000, seed=0xEC04):
     """SURVEY.md 8d cfg 4: 96 genomes with lengths uniform in [2 M, 7 M] bp; isolate i is generated from seed + i."""
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.integers(lo, hi + 1, size=n_isolates).astype(np.int64)
+
+
+def device_fastq_fixed(torch, codes, qual_char=ord("I"), low_mask=None, low_char=ord("+")):
+    """FASTQ text built ON THE DEVICE for large inputs (bench.py's FASTQ leg): fixed-width records
+    '@r%09d\\n<seq>\\n+\\n<qual>\\n' — the layout of to_fastq_fixed.  codes: int tensor [n, L] of base codes on the device;
+    low_mask (optional, bool [n, L]): bases that get the low quality character.  Returns a uint8 device tensor."""
+    n, L = codes.shape
+    dev = codes.device
+    rec = 11 + 1 + L + 1 + 2 + L + 1
+    out = torch.empty((n, rec), dtype=torch.uint8, device=dev)
+    out[:, 0] = ord("@"); out[:, 1] = ord("r")
+    ids = torch.arange(n, device=dev, dtype=torch.int64)
+    for d in range(9):
+        out[:, 2 + d] = ((ids // (10 ** (8 - d))) % 10 + 48).to(torch.uint8)
+    out[:, 11] = 10
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    out[:, 12:12 + L] = lut[codes.long()]
+    out[:, 12 + L] = 10
+    out[:, 13 + L] = ord("+"); out[:, 14 + L] = 10
+    out[:, 15 + L:15 + 2 * L] = qual_char
+    if low_mask is not None:
+        out[:, 15 + L:15 + 2 * L][low_mask] = low_char
+    out[:, 15 + 2 * L] = 10
+    return out.reshape(-1)

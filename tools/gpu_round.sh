@@ -16,12 +16,12 @@ fi
 timeout -k 10 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench_line.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 cat "$OUT/bench_line.json"
 # per-kernel time
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o s -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg > "$OUT/prof_stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_stats" -o s -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/prof_stats.log" 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (TCC slots), then SQ counters
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg > "$OUT/pmc_fetch.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg > "$OUT/pmc_write.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg > "$OUT/pmc_sq.log" 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq2" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg > "$OUT/pmc_sq2.log" 2>&1 || true
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/pmc_fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/pmc_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d "$OUT/pmc_sq" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/pmc_sq.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/pmc_sq2" -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/pmc_sq2.log" 2>&1 || true
 find "$OUT" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 python tools/pmc_summary.py "$OUT/pmc_*/**/*counter_collection.csv" > "$OUT/pmc_summary.txt" 2>&1 || true
 # keep the merge-back small: drop the raw traces
