@@ -198,6 +198,12 @@ int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0
  * bounds, kc[n] their k-mer count sums.  Returns a malloc'd NUL-terminated JSON (shk_host_free) or NULL. */
 char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k);
 void shk_host_free(void *p);
+/* host-only: the gzip reader of shk_preprocess alone (fastx_wasm.rs:53-70: gz sniff, multi-member) — BGZF blocks in
+ * parallel, a large plain member by the multi-threaded two-pass inflater (csrc/inflate_mt.cpp), the rest by zlib.  *out is
+ * malloc'd (shk_host_free); plain input is copied through.  *mt_members (optional): members the multi-threaded inflater
+ * has handled in this process so far; *reader_seconds (optional): the time the reader itself took (without the copy into
+ * *out).  SHK_GUNZIP_THREADS (environment): its thread count, 0 or 1 = zlib only. */
+int shk_host_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, uint64_t *mt_members, double *reader_seconds);
 /* SPEC S9 (tips, bubbles) and S10 (chains of simple links, the circular cut) on UNITIG records instead of k-mers — what the
  * sharded assembly runs on every rank's host once the k-mer-level contraction is done on the GPUs (csrc/unitig_graph.h:
  * one record per strand of a unitig; first / last: [n_recs][W] words of its first / last k-mer as spelled; min_*: the

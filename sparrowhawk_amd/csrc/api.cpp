@@ -14,6 +14,7 @@
 
 #include "fastq.h"
 #include "fastq_gpu.h"
+#include "inflate_mt.h"
 #include "outputs.h"
 #include "pipeline.h"
 #include "shard_comm.h"
@@ -415,12 +416,14 @@ static int preprocess_impl(shk_handle *h, const uint8_t *fq1, size_t n1, const u
     // packed by streaming kernels.  Irregular input and every malformed record go to the host parser
     // below, which owns the error messages.
     // gzip (plain members: one thread per file; BGZF: block-parallel) is inflated once, for either parser
-    std::vector<uint8_t> st1, st2;
+    ByteVec st1, st2;
     const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
     {
+        const uint64_t mt0 = inflate_mt_members();
         int rc = maybe_inflate_pair(fq1, n1, fq2, n2, st1, st2, t1, l1, t2, l2, err);
         if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : SHK_E_OOM, err);
         h->pipe->times().add("gunzip_host_clock", now_ms() - t0);
+        h->pipe->times().add("gunzip_mt_members_x1", (double)(inflate_mt_members() - mt0));     // members the multi-threaded inflater took
     }
     const size_t text_total = l1 + (fq2 ? l2 : 0);
     const char *force_host = getenv("SHK_HOST_PARSER");
@@ -509,7 +512,7 @@ static int push_reads_impl(shk_handle *h, const uint8_t *chunk, size_t n) {
         const char *mv = getenv("SHK_STREAM_DEVICE_MIN");
         const size_t dev_min = (mv && *mv) ? (size_t)strtoull(mv, nullptr, 10) : ((size_t)8 << 20);
         if (!(force_host && *force_host == '1') && n >= dev_min) {
-            std::vector<uint8_t> st;
+            ByteVec st;
             const uint8_t *t = nullptr; size_t l = 0;
             int rc = maybe_inflate(chunk, n, st, t, l, err);
             if (rc) return fail(h, rc == -3 ? SHK_E_PARSE : SHK_E_OOM, err);
@@ -1069,6 +1072,22 @@ char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const ui
     } catch (...) { return nullptr; }
 }
 void shk_host_free(void *p) { free(p); }
+int shk_host_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, uint64_t *mt_members, double *reader_seconds) {
+    try {
+        if (!gz || !out || !out_n) return SHK_E_PARAM;
+        ByteVec st; const uint8_t *p = nullptr; size_t pn = 0; std::string err;
+        const double t0 = now_ms();
+        const int rc = maybe_inflate(gz, n, st, p, pn, err);
+        if (reader_seconds) *reader_seconds = (now_ms() - t0) * 1e-3;
+        if (rc) return rc == -3 ? SHK_E_PARSE : SHK_E_OOM;
+        *out = (uint8_t *)malloc(pn ? pn : 1);
+        if (!*out) return SHK_E_OOM;
+        if (pn) memcpy(*out, p, pn);
+        *out_n = pn;
+        if (mt_members) *mt_members = inflate_mt_members();
+        return SHK_OK;
+    } catch (...) { return SHK_E_OOM; }
+}
 char *shk_host_unitig_assemble(uint32_t k, uint64_t n_recs, const uint64_t *first, const uint64_t *last, const uint64_t *len,
                                const uint64_t *kc, const uint8_t *circ, const uint64_t *min_key, const uint8_t *min_o,
                                const uint64_t *min_pos, int tips, int bubbles) {

@@ -1,6 +1,8 @@
 // fastq.cpp — see fastq.h
 #include "fastq.h"
+#include "inflate_mt.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <algorithm>
 #include <zlib.h>
@@ -27,12 +29,25 @@ void PackedReads::finish() {
     b.push_back(0u);
 }
 
-static int inflate_all(const uint8_t *in, size_t n, std::vector<uint8_t> &out, std::string &err) {
+static int inflate_all(const uint8_t *in, size_t n, ByteVec &out, std::string &err) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 16) != Z_OK) { err = "zlib init failed"; return -3; }
-    out.resize(n * 4 + 4096);
     size_t produced = 0, consumed = 0;
+    // a large member first goes to the multi-threaded inflater (inflate_mt.cpp: block starts found speculatively, chunks
+    // decoded with markers for the unknown window, CRC checked); whatever it declines is zlib's
+    {
+        const char *tv = getenv("SHK_GUNZIP_THREADS");
+        unsigned T = std::thread::hardware_concurrency();
+        if (T > 128) T = 128;
+        if (tv && *tv) T = (unsigned)std::max(0, atoi(tv));
+        size_t used = 0;
+        if (T >= 2 && n >= ((size_t)2 << 20) && inflate_member_parallel(in, n, out, 0, used, T) == 0) {
+            produced = out.size(); consumed = used;
+            if (consumed >= n) { inflateEnd(&zs); return 0; }
+        } else out.clear();
+    }
+    out.resize(produced + (n - consumed) * 4 + 4096);
     for (;;) {
         if (produced == out.size()) out.resize(out.size() * 2);
         size_t in_chunk = n - consumed; if (in_chunk > (1u << 30)) in_chunk = 1u << 30;
@@ -72,7 +87,7 @@ static bool bgzf_block(const uint8_t *b, size_t n, size_t &bsize) {
     return false;
 }
 
-static int inflate_bgzf(const uint8_t *in, size_t n, std::vector<uint8_t> &out, std::string &err, bool &is_bgzf) {
+static int inflate_bgzf(const uint8_t *in, size_t n, ByteVec &out, std::string &err, bool &is_bgzf) {
     struct Blk { size_t in_off, in_len, out_off, out_len, hdr; };
     std::vector<Blk> blocks;
     size_t p = 0, total = 0;
@@ -118,7 +133,7 @@ static int inflate_bgzf(const uint8_t *in, size_t n, std::vector<uint8_t> &out, 
     return 0;
 }
 
-int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,
+int maybe_inflate(const uint8_t *buf, size_t n, ByteVec &storage, const uint8_t *&p, size_t &pn,
                   std::string &err) {
     p = buf; pn = n;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
@@ -131,8 +146,8 @@ int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, c
 }
 
 // both files of a pair at once (a plain gzip member cannot be split, two files can)
-int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, std::vector<uint8_t> &s1,
-                       std::vector<uint8_t> &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
+int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, ByteVec &s1,
+                       ByteVec &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
                        std::string &err) {
     p2 = nullptr; l2 = 0;
     if (!b2) return maybe_inflate(b1, n1, s1, p1, l1, err);
@@ -172,7 +187,7 @@ inline void append_run(PackedReads &o, const uint8_t *codes, size_t len) {
 int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, PackedReads &out,
                std::string &err, uint64_t every, const ProgressFn &progress,
                uint64_t flush_reads, uint64_t flush_bases, const FlushFn &flush, uint64_t rec_base) {
-    std::vector<uint8_t> inflated;
+    ByteVec inflated;
     if (n >= 2 && buf[0] == 0x1F && buf[1] == 0x8B) {
         const uint8_t *q = nullptr; size_t qn = 0;
         if (int rc = maybe_inflate(buf, n, inflated, q, qn, err)) return rc;

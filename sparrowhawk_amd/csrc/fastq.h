@@ -7,6 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include "bytebuf.h"
 
 namespace shk {
 
@@ -37,11 +38,11 @@ int pack_fastq(const uint8_t *buf, size_t n, uint32_t k, uint32_t min_qual, Pack
                uint64_t rec_base = 0 /* records of this file that came before buf: numbering of the error messages */);
 
 // gzip sniff (1F 8B) + multi-member inflate; plain input is passed through (p/n point at buf or at `storage`)
-int maybe_inflate(const uint8_t *buf, size_t n, std::vector<uint8_t> &storage, const uint8_t *&p, size_t &pn,
+int maybe_inflate(const uint8_t *buf, size_t n, ByteVec &storage, const uint8_t *&p, size_t &pn,
                   std::string &err);
 // the two files of a pair in two threads (b2 may be null); BGZF input is inflated block-parallel either way
-int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, std::vector<uint8_t> &s1,
-                       std::vector<uint8_t> &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
+int maybe_inflate_pair(const uint8_t *b1, size_t n1, const uint8_t *b2, size_t n2, ByteVec &s1,
+                       ByteVec &s2, const uint8_t *&p1, size_t &l1, const uint8_t *&p2, size_t &l2,
                        std::string &err);
 
 }  // namespace shk

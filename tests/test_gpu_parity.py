@@ -181,6 +181,26 @@ def test_paired_gzip_and_streaming_equal_single_file():
     compare_all(b, o)
 
 
+def test_large_single_member_gzip_goes_through_the_multithreaded_reader():
+    """a single-member .fastq.gz of >= 64 MB of text (the reference's real input: fastx_wasm.rs:53-70,
+    docs/src/assembly.md:28) is inflated by csrc/inflate_mt.cpp; the assembly equals the one from the plain text and, as
+    file 2 of a pair next to a plain file 1, the pooled result equals the oracle's."""
+    g = synth.random_genome(300000, 5)
+    codes, quals = synth.sample_reads(g, 230000, 150, 6, err=0.01)
+    fq = bytes(synth.to_fastq_fixed(codes, quals))
+    assert len(fq) >= 64_000_000
+    z = gzip.compress(fq, compresslevel=6)
+    a = product(fq, k=31, min_count=3)
+    b = product(z, k=31, min_count=3)
+    assert a.get_assembly() == b.get_assembly() and a.get_preprocessing_info() == b.get_preprocessing_info()
+    assert b.timings().get("gunzip_mt_members_x1", 0) == 1, b.timings()
+    g2, small = make_dataset(20000, 30, err=0.005, seed=35)
+    c = product(small, z, k=31, min_count=3)
+    assert c.timings().get("gunzip_mt_members_x1", 0) == 1
+    o = run_oracle([small, fq], k=31, min_count=3)
+    compare_all(c, o, check_graph=False)
+
+
 def test_metamorphic_read_order_and_strand():
     g, fq = make_dataset(20000, 30, err=0.005, seed=32)
     lines = fq.decode().strip().split("\n")
