@@ -98,7 +98,7 @@ template <typename F> static int guarded(shk_handle *h, Poison poison, F &&body)
 
 extern "C" {
 
-void shk_release_cached_memory(void) { device_pool_trim(); }
+void shk_release_cached_memory(void) { device_pool_trim(); big_trim(); }
 int shk_measure_stream_read(size_t bytes, int iters, double *gbs) {
     std::string err;
     const int rc = stream_read_gbs(bytes, iters, gbs, err);

@@ -13,22 +13,23 @@
 
 namespace shk {
 
+// Blocks of >= 4 MiB are 2 MiB-aligned, advised to use huge pages and — up to a few gigabytes — kept for the next caller
+// when they are freed: a fresh gigabyte costs the kernel a gigabyte of page zeroing on first touch (0.3 s per .fastq.gz of
+// the bench isolate), a recycled one costs nothing.  big_trim() returns the kept blocks (shk_release_cached_memory).
+void *big_alloc(size_t bytes);
+void big_free(void *p, size_t bytes);
+void big_trim();
+
 template <typename T> struct NoInitAlloc {
     using value_type = T;
     NoInitAlloc() = default;
     template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
     T *allocate(size_t n) {
-        const size_t bytes = n * sizeof(T);
-        void *p;
-        if (bytes >= ((size_t)4 << 20)) {
-            const size_t want = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
-            p = aligned_alloc((size_t)2 << 20, want);
-            if (p) (void)madvise(p, want, MADV_HUGEPAGE);
-        } else p = malloc(bytes ? bytes : 1);
+        void *p = big_alloc(n * sizeof(T));
         if (!p) throw std::bad_alloc();
         return (T *)p;
     }
-    void deallocate(T *p, size_t) { free(p); }
+    void deallocate(T *p, size_t n) { big_free(p, n * sizeof(T)); }
     template <typename U, typename... A> void construct(U *p, A &&...a) {
         if constexpr (sizeof...(A) == 0) (void)p;          // default construction: leave the memory as it is
         else ::new ((void *)p) U(std::forward<A>(a)...);

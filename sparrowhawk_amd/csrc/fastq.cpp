@@ -2,14 +2,70 @@
 #include "fastq.h"
 #include "inflate_mt.h"
 
+#include <malloc.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <algorithm>
 #include <zlib.h>
 #include <atomic>
 #include <thread>
 
 namespace shk {
+
+// ---- large host blocks (bytebuf.h) ---------------------------------------------------------------------------------
+namespace {
+struct BigPool {
+    std::mutex mu;
+    std::vector<std::pair<size_t, void *>> kept;          // (bytes, block)
+    size_t kept_bytes = 0;
+    static constexpr size_t MIN_BIG = (size_t)4 << 20, KEEP_MAX = (size_t)8 << 30;
+};
+BigPool &big_pool() { static BigPool *p = new BigPool(); return *p; }     // never destroyed (process teardown order)
+inline size_t big_round(size_t bytes) { return (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); }
+}  // namespace
+void *big_alloc(size_t bytes) {
+    if (bytes < BigPool::MIN_BIG) return malloc(bytes ? bytes : 1);
+    const size_t want = big_round(bytes);
+    {
+        BigPool &bp = big_pool();
+        std::lock_guard<std::mutex> lk(bp.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < bp.kept.size(); i++)
+            if (bp.kept[i].first >= want && bp.kept[i].first <= want * 2 && (best == (size_t)-1 || bp.kept[i].first < bp.kept[best].first)) best = i;
+        if (best != (size_t)-1) {
+            void *p = bp.kept[best].second;
+            bp.kept_bytes -= bp.kept[best].first;
+            // the block keeps its real size in a header-less way: callers free with THEIR size, so remember the real one
+            bp.kept[best] = bp.kept.back(); bp.kept.pop_back();
+            return p;
+        }
+    }
+    void *p = aligned_alloc((size_t)2 << 20, want);
+    if (p) (void)madvise(p, want, MADV_HUGEPAGE);
+    return p;
+}
+void big_free(void *p, size_t bytes) {
+    if (!p) return;
+    if (bytes < BigPool::MIN_BIG) { free(p); return; }
+    // (a recycled block may be larger than `bytes`: malloc_usable_size tells what it really holds)
+    const size_t real = malloc_usable_size(p) & ~(((size_t)2 << 20) - 1);
+    BigPool &bp = big_pool();
+    {
+        std::lock_guard<std::mutex> lk(bp.mu);
+        if (real >= BigPool::MIN_BIG && bp.kept_bytes + real <= BigPool::KEEP_MAX && bp.kept.size() < 64) {
+            bp.kept.emplace_back(real, p); bp.kept_bytes += real;
+            return;
+        }
+    }
+    free(p);
+}
+void big_trim() {
+    BigPool &bp = big_pool();
+    std::lock_guard<std::mutex> lk(bp.mu);
+    for (auto &kv : bp.kept) free(kv.second);
+    bp.kept.clear(); bp.kept_bytes = 0;
+}
 
 void PackedReads::clear() {
     bases.clear(); seg_off.clear(); n_bases = n_reads = n_input_bases = 0; cur = 0;
