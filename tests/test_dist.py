@@ -400,6 +400,18 @@ def test_sharded_graph_several_ranks(world):
             recs.extend(fqx.decode().split("@r")[1:])
         fq = ("@r" + "@r".join(recs)).encode()
         cases.append((fq, dict(k=k, min_count=mc, min_qual=20)))
+    # a small metagenome (configs[4] in miniature): 60 genomes of 4-12 kbp at log-normal abundances, 0.5 % errors, min_count 2 —
+    # hundreds of unitigs, tips and bubbles in the unitig graph, low-coverage genomes falling apart
+    rng = np.random.default_rng(8250 + world)
+    recs = []
+    for gi in range(60):
+        gl = int(rng.integers(4000, 12001))
+        gm = synth.random_genome(gl, 9000 + gi)
+        cov = float(np.exp(rng.normal(np.log(12.0), 1.0)))
+        nr = max(1, int(gl * cov / 150))
+        codes, quals = synth.sample_reads(gm, nr, 150, 9100 + gi, err=0.005, circular=bool(gi % 3 == 0))
+        recs.extend(synth.to_fastq(codes, quals).decode().split("@r")[1:])
+    cases.append((("@r" + "@r".join(recs)).encode(), dict(k=31, min_count=2, min_qual=0)))
     g, fq = make_dataset(150000, 40, err=0.01, seed=8300 + world)
     cases.append((fq, dict(k=31, min_count=3, min_qual=20, do_fit=True)))
     g, fq = make_dataset(50000, 30, err=0.01, seed=8400 + world)
