@@ -19,7 +19,7 @@ struct BigPool {
     std::mutex mu;
     std::vector<std::pair<size_t, void *>> kept;          // (bytes, block)
     size_t kept_bytes = 0;
-    static constexpr size_t MIN_BIG = (size_t)4 << 20, KEEP_MAX = (size_t)8 << 30;
+    static constexpr size_t MIN_BIG = (size_t)4 << 20, KEEP_MAX = (size_t)12 << 30;
 };
 BigPool &big_pool() { static BigPool *p = new BigPool(); return *p; }     // never destroyed (process teardown order)
 inline size_t big_round(size_t bytes) { return (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); }
@@ -53,7 +53,7 @@ void big_free(void *p, size_t bytes) {
     BigPool &bp = big_pool();
     {
         std::lock_guard<std::mutex> lk(bp.mu);
-        if (real >= BigPool::MIN_BIG && bp.kept_bytes + real <= BigPool::KEEP_MAX && bp.kept.size() < 64) {
+        if (real >= BigPool::MIN_BIG && bp.kept_bytes + real <= BigPool::KEEP_MAX && bp.kept.size() < 512) {
             bp.kept.emplace_back(real, p); bp.kept_bytes += real;
             return;
         }

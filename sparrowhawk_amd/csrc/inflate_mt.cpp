@@ -283,7 +283,7 @@ int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t ou
         Bits b{def, dn};
         b.seek(st[c]);
         const uint64_t stop_at = c + 1 < C ? st[c + 1] : ~0ull;
-        sym[c].reserve((size_t)((c + 1 < C ? st[c + 1] : (uint64_t)dn * 8) - st[c]) / 8 * 8 + 65536);   // (FASTQ text deflates 3-5x)
+        sym[c].reserve((size_t)((c + 1 < C ? st[c + 1] : (uint64_t)dn * 8) - st[c]) / 8 * 6 + 65536);   // (FASTQ text deflates 3-5x; a vector that runs out grows)
         how[c] = inflate_blocks(b, sym[c], c == 0, stop_at, false, &endpos[c]);
     });
     for (unsigned c = 0; c < C; c++) if (how[c] != (c + 1 < C ? Stop::AtStop : Stop::Final)) return 1;

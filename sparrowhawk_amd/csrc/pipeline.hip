@@ -1757,20 +1757,29 @@ public:
         times_.add("shard_graph_unitig_host_clock", now_ms_() - t_host0);
         // ---- 6. emission
         EvTimer te(stream_);
-        const uint64_t text_words = (text_bytes + 7) / 8;
-        DevBuf<ULayout> d_lay; DevBuf<char> d_text;
+        const uint64_t text_w32 = ((text_bytes + 15) / 16 + 1) & ~1ull;           // 2-bit words (16 bases each), an even number: all-reduced as u64
+        DevBuf<ULayout> d_lay; DevBuf<char> d_text; DevBuf<uint32_t> d_pack;
         if (int rc = d_lay.alloc(n_u + 1, err)) return rc;
-        if (int rc = d_text.alloc(text_words * 8 + 8, err)) return rc;
-        if (int rc = hout_.alloc(text_words * 8 + 8, err)) return rc;
+        if (int rc = d_text.alloc(text_w32 * 16 + 16, err)) return rc;
+        if (int rc = d_pack.alloc(text_w32 + 2, err)) return rc;
+        if (int rc = hout_.alloc(text_w32 * 16 + 16, err)) return rc;
         if (text_bytes) {
-            HIPCHK(hipMemsetAsync(d_text.p, 0, text_words * 8, stream_));
+            HIPCHK(hipMemsetAsync(d_text.p, 0, text_w32 * 16, stream_));
             HIPCHK(hipMemcpyAsync(d_lay.p, lay.data(), (size_t)(n_u + 1) * sizeof(ULayout), hipMemcpyHostToDevice, stream_));
             if (n) {
                 hipLaunchKernelGGL(k_shard_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, cs.ol.p, fin.p, (uint32_t)lbase[rank], uid_of_slot.p, d_lay.p, d_text.p);
                 HIPCHK(hipGetLastError());
             }
-            if (int rc = comm_allreduce_u64(c, d_text.p, text_words, stream_, err)) return rc;      // (the ranks' bytes are disjoint: sum = merge)
-            HIPCHK(hipMemcpyAsync(hout_.p, d_text.p, text_words * 8, hipMemcpyDeviceToHost, stream_));
+            if (world > 1) {
+                // every base is written by exactly one rank: packed 2 bits per base (A = 0 = "not mine") the ranks' words add up
+                hipLaunchKernelGGL(k_text_pack2, dim3(grid_for(text_w32)), dim3(256), 0, stream_, d_text.p, text_bytes, d_pack.p, text_w32);
+                HIPCHK(hipGetLastError());
+                if (int rc = comm_allreduce_u64(c, d_pack.p, text_w32 / 2, stream_, err)) return rc;
+                hipLaunchKernelGGL(k_text_unpack2, dim3(grid_for(text_w32)), dim3(256), 0, stream_, d_pack.p, text_w32, d_text.p);
+                HIPCHK(hipGetLastError());
+                times_.add("shard_graph_text_allreduce_MB", (double)(text_w32 * 4) / 1e6);
+            }
+            HIPCHK(hipMemcpyAsync(hout_.p, d_text.p, text_bytes, hipMemcpyDeviceToHost, stream_));
         }
         HIPCHK(stream_wait(stream_));
         times_.add("shard_graph_emit", te.stop());

@@ -367,3 +367,39 @@ __global__ __launch_bounds__(256) void k_shard_emit(Graph<W> g, const uint2 *__r
         }
     }
 }
+
+// The contig text crosses the ranks 2 bits per base: every position is written by exactly one rank, the others hold zero
+// bytes there; packed (A = 0 = "not mine"), the ranks' words add up to the whole text, a quarter of the bytes on the links.
+__global__ __launch_bounds__(256) void k_text_pack2(const char *__restrict__ text, uint64_t n_bytes, uint32_t *__restrict__ words, uint64_t n_words) {
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(text + 16 * w);              // (the text buffer is padded to 16 bytes and zeroed)
+        const uint32_t q[4] = {v.x, v.y, v.z, v.w};
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const uint32_t c = (q[j] >> (8 * b)) & 0xFFu;                            // 0, 'A' 0x41, 'C' 0x43, 'G' 0x47, 'T' 0x54
+                const uint32_t code = c == 0x43u ? 1u : (c == 0x47u ? 2u : (c == 0x54u ? 3u : 0u));
+                out |= code << (2 * (4 * j + b));
+            }
+        words[w] = out;
+    }
+    (void)n_bytes;
+}
+__global__ __launch_bounds__(256) void k_text_unpack2(const uint32_t *__restrict__ words, uint64_t n_words, char *__restrict__ text) {
+    const uint32_t ACGT = 0x54474341u;
+    for (uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; w < n_words; w += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t x = words[w];
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) o |= ((ACGT >> (8 * ((x >> (2 * (4 * j + b))) & 3u))) & 0xFFu) << (8 * b);
+            q[j] = o;
+        }
+        uint4 v; v.x = q[0]; v.y = q[1]; v.z = q[2]; v.w = q[3];
+        *reinterpret_cast<uint4 *>(text + 16 * w) = v;
+    }
+}
