@@ -2,13 +2,48 @@
 #include "unitig_graph.h"
 
 #include <algorithm>
+#include <atomic>
 #include <map>
-#include <unordered_map>
+#include <thread>
 
 #include "kmer.h"
 
 namespace shk {
 namespace {
+
+// A metagenome leaves millions of unitig records (an isolate a handful): the passes over ALL records — sorting the ends,
+// looking up every record's out-neighbours once, finding the tip / bubble candidates of a round — run on several host threads
+// from a size on; the walks themselves start from the few candidates.
+unsigned ug_threads(size_t n) {
+    if (n < 65536) return 1;
+    unsigned t = std::thread::hardware_concurrency();
+    return t < 1 ? 1 : (t > 32 ? 32 : t);
+}
+template <typename F> void par_ranges(size_t n, F &&fn) {
+    const unsigned T = ug_threads(n);
+    if (T == 1) { fn((size_t)0, n, 0u); return; }
+    std::vector<std::thread> ts;
+    for (unsigned t = 1; t < T; t++) ts.emplace_back([&fn, n, t, T] { fn(n * t / T, n * (t + 1) / T, t); });
+    fn((size_t)0, n / T, 0u);
+    for (auto &t : ts) t.join();
+}
+template <typename It, typename Less> void par_sort(It b, It e, Less less) {
+    const size_t n = (size_t)(e - b);
+    unsigned C = 1;
+    while (C * 2 <= ug_threads(n) && n / (C * 2) >= 32768) C *= 2;
+    if (C == 1) { std::sort(b, e, less); return; }
+    std::vector<size_t> edge(C + 1);
+    for (unsigned c = 0; c <= C; c++) edge[c] = n * c / C;
+    { std::vector<std::thread> ts;
+      for (unsigned c = 0; c < C; c++) ts.emplace_back([&, c] { std::sort(b + edge[c], b + edge[c + 1], less); });
+      for (auto &t : ts) t.join(); }
+    for (unsigned w = 1; w < C; w *= 2) {
+        std::vector<std::thread> ts;
+        for (unsigned j = 0; j < C / (2 * w); j++)
+            ts.emplace_back([&, j, w] { std::inplace_merge(b + edge[2 * w * j], b + edge[2 * w * j + w], b + edge[2 * w * j + 2 * w], less); });
+        for (auto &t : ts) t.join();
+    }
+}
 
 template <int W> struct UG {
     const int k;
@@ -19,6 +54,7 @@ template <int W> struct UG {
     std::vector<uint8_t> alive;
     struct PE { Kmer<W> p; uint32_t r; };
     std::vector<PE> by_prefix;                   // linear records by the first k-1 bases of their first k-mer
+    std::vector<uint32_t> outn;                  // [n][4] the records whose first k-mer overlaps a record's last k-mer (UG_NIL padded), looked up once
     uint64_t T_LEN;                              // T_TIP = T_BUB = 2k nodes
 
     UG(int k_, const std::vector<UnitigRec> &recs) : k(k_), R(recs), n((uint32_t)recs.size()), T_LEN(2ull * (uint64_t)k_) {}
@@ -47,17 +83,26 @@ template <int W> struct UG {
         std::vector<PE> by_first;
         for (uint32_t r = 0; r < n; r++) if (!R[r].circ) { by_first.push_back(PE{F[r], r}); by_prefix.push_back(PE{prefix(F[r]), r}); }
         auto less = [](const PE &a, const PE &b) { return km_less<W>(a.p, b.p) || (km_eq<W>(a.p, b.p) && a.r < b.r); };
-        std::sort(by_first.begin(), by_first.end(), less);
-        std::sort(by_prefix.begin(), by_prefix.end(), less);
+        par_sort(by_first.begin(), by_first.end(), less);
+        par_sort(by_prefix.begin(), by_prefix.end(), less);
         for (size_t i = 1; i < by_first.size(); i++)
             if (km_eq<W>(by_first[i].p, by_first[i - 1].p)) { err = "unitig graph: two chains start at the same oriented node"; return -1; }
-        for (uint32_t r = 0; r < n; r++) {
-            if (R[r].circ) continue;
-            const Kmer<W> want = km_revcomp<W>(T[r], k);
-            auto it = std::lower_bound(by_first.begin(), by_first.end(), PE{want, 0}, less);
-            if (it == by_first.end() || !km_eq<W>(it->p, want)) { err = "unitig graph: a chain without its mirror strand"; return -1; }
-            mirror[r] = it->r;
-        }
+        std::atomic<int> bad{0};
+        outn.assign((size_t)n * 4, UG_NIL);
+        par_ranges(n, [&](size_t a, size_t b, unsigned) {
+            for (size_t r = a; r < b; r++) {
+                if (R[r].circ) continue;
+                const Kmer<W> want = km_revcomp<W>(T[r], k);
+                auto it = std::lower_bound(by_first.begin(), by_first.end(), PE{want, 0}, less);
+                if (it == by_first.end() || !km_eq<W>(it->p, want)) { bad = 1; continue; }
+                mirror[r] = it->r;
+                const Kmer<W> sfx = suffix(T[r]);
+                auto jt = std::lower_bound(by_prefix.begin(), by_prefix.end(), PE{sfx, 0}, less);
+                int c = 0;
+                for (; jt != by_prefix.end() && km_eq<W>(jt->p, sfx) && c < 4; ++jt) outn[r * 4 + c++] = jt->r;
+            }
+        });
+        if (bad.load()) { err = "unitig graph: a chain without its mirror strand"; return -1; }
         for (uint32_t r = 0; r < n; r++)
             if (!R[r].circ && mirror[mirror[r]] != r) { err = "unitig graph: mirror strands do not pair up"; return -1; }
         return 0;
@@ -66,11 +111,8 @@ template <int W> struct UG {
     // out-neighbours of r's last node: the alive records whose first k-mer overlaps its last k-mer by k-1
     int outs(uint32_t r, uint32_t (&o)[4]) const {
         if (R[r].circ) return 0;
-        const Kmer<W> s = suffix(T[r]);
-        auto it = std::lower_bound(by_prefix.begin(), by_prefix.end(), PE{s, 0}, [](const PE &a, const PE &b) {
-            return km_less<W>(a.p, b.p) || (km_eq<W>(a.p, b.p) && a.r < b.r); });
         int c = 0;
-        for (; it != by_prefix.end() && km_eq<W>(it->p, s); ++it) if (alive[it->r] && c < 4) o[c++] = it->r;
+        for (int i = 0; i < 4; i++) { const uint32_t s = outn[(size_t)r * 4 + i]; if (s == UG_NIL) break; if (alive[s]) o[c++] = s; }
         return c;
     }
     int outdeg(uint32_t r) const { uint32_t o[4]; return outs(r, o); }
@@ -83,6 +125,16 @@ template <int W> struct UG {
     }
     int indeg(uint32_t r) const { uint32_t o[4]; return ins(r, o); }
 
+    // the records a round starts from, ascending (found by several threads on a large graph)
+    template <typename P> std::vector<uint32_t> candidates(P &&pred) const {
+        const unsigned T = ug_threads(n);
+        std::vector<std::vector<uint32_t>> part(T);
+        par_ranges(n, [&](size_t a, size_t b, unsigned t) { for (size_t r = a; r < b; r++) if (pred((uint32_t)r)) part[t].push_back((uint32_t)r); });
+        std::vector<uint32_t> all;
+        for (auto &p : part) all.insert(all.end(), p.begin(), p.end());
+        return all;
+    }
+
     void kill(const std::vector<uint32_t> &doomed, uint64_t &nodes) {
         for (uint32_t r : doomed) {
             if (!alive[r]) continue;
@@ -94,8 +146,7 @@ template <int W> struct UG {
     uint64_t tip_round() {
         struct Tip { uint64_t len, sum; std::vector<uint32_t> path; };
         std::map<uint32_t, std::vector<Tip>> attached;               // junction record (its first node) -> tips
-        for (uint32_t v = 0; v < n; v++) {
-            if (!alive[v] || R[v].circ || indeg(v) != 0) continue;
+        for (uint32_t v : candidates([&](uint32_t r) { return alive[r] && !R[r].circ && indeg(r) == 0; })) {
             Tip t; t.path.push_back(v); t.len = R[v].len; t.sum = R[v].kc;
             if (t.len > T_LEN) continue;                             // |P| > T inside the first chain: not a tip
             uint32_t cur = v;
@@ -135,11 +186,9 @@ template <int W> struct UG {
 
     uint64_t bubble_round() {
         std::vector<uint32_t> doomed;
-        for (uint32_t S = 0; S < n; S++) {
-            if (!alive[S] || R[S].circ) continue;
+        for (uint32_t S : candidates([&](uint32_t r) { return alive[r] && !R[r].circ && outdeg(r) >= 2; })) {
             uint32_t ob[4];
             const int no = outs(S, ob);
-            if (no < 2) continue;
             struct Branch { std::vector<uint32_t> path; uint64_t len = 0, sum = 0; uint32_t end = UG_NIL; bool ok = false; };
             Branch br[4];
             for (int b = 0; b < no; b++) {

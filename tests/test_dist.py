@@ -416,6 +416,9 @@ def test_sharded_graph_several_ranks(world):
     cases.append((fq, dict(k=31, min_count=3, min_qual=20, do_fit=True)))
     g, fq = make_dataset(50000, 30, err=0.01, seed=8400 + world)
     cases.append((fq, dict(k=63, min_count=2, min_qual=0, P=64)))
+    g, fq = make_dataset(40000, 30, err=0.005, seed=8450 + world, circular=True)       # three- and four-word keys
+    cases.append((fq, dict(k=89, min_count=2, min_qual=20)))
+    cases.append((fq, dict(k=127, min_count=1, min_qual=0)))
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     try:
         with tempfile.TemporaryDirectory() as d:

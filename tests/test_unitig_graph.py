@@ -129,3 +129,56 @@ def test_unitig_level_correction_equals_the_oracle(block):
         assert removed == (o.tips_removed, o.bubbles_removed), f"case {case}"
         n_removed += sum(removed)
     assert n_removed > 0
+
+
+def test_large_unitig_graph_takes_the_threaded_passes():
+    """A metagenome leaves millions of unitig records: from 65 536 records on, the sorting of the ends, the lookup of every
+    record's out-neighbours and the search for a round's candidates run on several host threads.  70 000 synthetic unitigs
+    (both strands: 140 000 records): most isolated, 10 000 pairs joined by a simple link (they must merge), 2 000 forks
+    with a dead-end branch of 5 nodes beside a long one (the short one is a tip and must go)."""
+    L = _lib.load()
+    k, W = 31, 1
+    rng = np.random.default_rng(5)
+
+    def rnd(n):
+        return "".join(rng.choice(list("ACGT"), n))
+    units = []                                              # (first k-mer, last k-mer, nodes, kc) of one strand each
+    expect = {}                                             # frozenset of unit indices -> nodes of the contig
+    for i in range(46000):                                  # isolated
+        units.append((rnd(k), rnd(k), 40, 400))
+        expect[frozenset([len(units) - 1])] = 40
+    for i in range(10000):                                  # A -> B simple link: one contig of 30 + 50 nodes
+        x = rnd(k - 1)
+        units.append((rnd(k), rnd(1) + x, 30, 300)); a = len(units) - 1
+        units.append((x + rnd(1), rnd(k), 50, 500)); b = len(units) - 1
+        expect[frozenset([a, b])] = 80
+    for i in range(2000):                                   # J has two in-edges: a long chain and a 5-node dead end (a tip: removed)
+        x = rnd(k - 2)
+        j_first = rnd(1) + x + rnd(1)                        # J's first k-mer; predecessors end with ? + j_first[:-1]
+        pre = j_first[:-1]
+        units.append((j_first, rnd(k), 100, 1000)); j = len(units) - 1
+        units.append((rnd(k), "A" + pre, 200, 2000)); long_ = len(units) - 1
+        units.append((rnd(k), "C" + pre, 5, 50)); tip = len(units) - 1
+        expect[frozenset([long_, j])] = 300                 # after the tip is gone the link long -> J is simple
+    n = 2 * len(units)
+    first = np.zeros((n, W), dtype=np.uint64); last = np.zeros((n, W), dtype=np.uint64)
+    ln = np.zeros(n, dtype=np.uint64); kc = np.zeros(n, dtype=np.uint64); circ = np.zeros(n, dtype=np.uint8)
+    for u, (f, l, nn, c) in enumerate(units):
+        first[2 * u] = kmer_words(f, W); last[2 * u] = kmer_words(l, W)
+        first[2 * u + 1] = kmer_words(rc(l), W); last[2 * u + 1] = kmer_words(rc(f), W)
+        ln[2 * u] = ln[2 * u + 1] = nn; kc[2 * u] = kc[2 * u + 1] = c
+    ptr = L.shk_host_unitig_assemble(k, n, first.ctypes.data, last.ctypes.data, ln.ctypes.data, kc.ctypes.data, circ.ctypes.data,
+                                     None, None, None, 1, 1)
+    assert ptr
+    text = C.string_at(ptr).decode()
+    L.shk_host_free(ptr)
+    assert not text.startswith("error:"), text[:200]
+    lines = text.strip().split("\n")
+    assert lines[0] == "removed %d 0" % (2000 * 5)
+    got = {}
+    for line in lines[1:]:
+        head, ids = line.split(":")
+        ring, rot, nodes, kc_ = (int(x) for x in head.split())
+        assert ring == 0
+        got[frozenset(int(r) // 2 for r in ids.split())] = nodes
+    assert got == expect
