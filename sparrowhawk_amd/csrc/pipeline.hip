@@ -1433,41 +1433,46 @@ public:
         DevBuf<uint64_t> send, recv; DevBuf<uint32_t> sidx;
         std::vector<uint64_t> send_cnt, recv_cnt; uint64_t n_send = 0, n_recv = 0;
     };
+    // (the size exchange happens on the device: the row of counts is gathered by RCCL and read back ONCE, world x (world + 1)
+    // words; `extra` rides along — a word of the caller's, e.g. "my local step failed" — and comes back as extra_all[world])
     template <int PW>
-    int route_exchange(ShardComm *c, const uint32_t *dest, const uint64_t *pay, uint32_t n_items, Routed &r, std::string &err) {
+    int route_exchange(ShardComm *c, const uint32_t *dest, const uint64_t *pay, uint32_t n_items, Routed &r, std::string &err,
+                       uint64_t extra = 0, std::vector<uint64_t> *extra_all = nullptr) {
         const uint32_t world = sh_world_;
-        DevBuf<uint32_t> d_cnt; DevBuf<unsigned long long> d_cur;
-        if (int rc = d_cnt.alloc(ROUTE_MAX_WORLD, err)) return rc;
-        if (int rc = d_cur.alloc(ROUTE_MAX_WORLD, err)) return rc;
-        std::vector<uint32_t> h_cnt(ROUTE_MAX_WORLD, 0);
+        const uint32_t row = world + 1;
+        if (int rc = rt_row_.alloc(ROUTE_MAX_WORLD + 1, err)) return rc;
+        if (int rc = rt_all_.alloc((size_t)row * world + 1, err)) return rc;
+        if (int rc = rt_cur_.alloc(ROUTE_MAX_WORLD, err)) return rc;
+        HIPCHK(hipMemsetAsync(rt_row_.p, 0, (ROUTE_MAX_WORLD + 1) * 8, stream_));
         if (n_items) {
-            HIPCHK(hipMemsetAsync(d_cnt.p, 0, ROUTE_MAX_WORLD * 4, stream_));
-            hipLaunchKernelGGL(k_route_count, dim3(grid_for(n_items)), dim3(256), 0, stream_, dest, n_items, d_cnt.p);
+            hipLaunchKernelGGL(k_route_count, dim3(grid_for(n_items)), dim3(256), 0, stream_, dest, n_items, rt_row_.p);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(h_cnt.data(), d_cnt.p, ROUTE_MAX_WORLD * 4, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
         }
+        HIPCHK(hipMemcpyAsync(rt_row_.p + world, &extra, 8, hipMemcpyHostToDevice, stream_));
+        if (int rc = comm_allgather(c, rt_row_.p, rt_all_.p, (size_t)row * 8, stream_, err)) return rc;
+        std::vector<uint64_t> all((size_t)row * world);
+        HIPCHK(hipMemcpyAsync(all.data(), rt_all_.p, all.size() * 8, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(stream_wait(stream_));
         r.send_cnt.assign(world, 0); r.recv_cnt.assign(world, 0); r.n_send = 0; r.n_recv = 0;
-        std::vector<unsigned long long> cur(ROUTE_MAX_WORLD, 0);
-        for (uint32_t d = 0; d < world; d++) { r.send_cnt[d] = h_cnt[d]; cur[d] = r.n_send; r.n_send += h_cnt[d]; }
-        // the size exchange: every rank's row of counts
-        std::vector<uint64_t> all((size_t)world * world);
-        if (int rc = comm_allgather_host_u64(c, r.send_cnt.data(), world, all.data(), stream_, err)) return rc;
-        for (uint32_t s = 0; s < world; s++) { r.recv_cnt[s] = all[(size_t)s * world + sh_rank_]; r.n_recv += r.recv_cnt[s]; }
+        std::vector<unsigned long long> &cur = rt_cur_host_;           // (a member: the asynchronous copy below may read it after this call has returned)
+        cur.assign(ROUTE_MAX_WORLD, 0);
+        for (uint32_t d = 0; d < world; d++) { r.send_cnt[d] = all[(size_t)sh_rank_ * row + d]; cur[d] = r.n_send; r.n_send += r.send_cnt[d]; }
+        for (uint32_t s = 0; s < world; s++) { r.recv_cnt[s] = all[(size_t)s * row + sh_rank_]; r.n_recv += r.recv_cnt[s]; }
+        if (extra_all) { extra_all->assign(world, 0); for (uint32_t s = 0; s < world; s++) (*extra_all)[s] = all[(size_t)s * row + world]; }
         if (int rc = r.send.alloc(r.n_send * PW + 1, err)) return rc;
         if (int rc = r.recv.alloc(r.n_recv * PW + 1, err)) return rc;
         if (int rc = r.sidx.alloc(n_items, err)) return rc;
         if (n_items) {
-            HIPCHK(hipMemcpyAsync(d_cur.p, cur.data(), ROUTE_MAX_WORLD * 8, hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(rt_cur_.p, cur.data(), ROUTE_MAX_WORLD * 8, hipMemcpyHostToDevice, stream_));
             hipLaunchKernelGGL((k_route_pack<PW>), dim3((n_items + ROUTE_CH - 1) / ROUTE_CH), dim3(256), 0, stream_, dest, pay, n_items,
-                               d_cur.p, r.send.p, r.sidx.p);
+                               rt_cur_.p, r.send.p, r.sidx.p);
             HIPCHK(hipGetLastError());
         }
         std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
         uint64_t a = 0, b = 0;
         for (uint32_t q = 0; q < world; q++) { so[q] = a; sb[q] = r.send_cnt[q] * PW * 8; a += sb[q]; ro[q] = b; rb[q] = r.recv_cnt[q] * PW * 8; b += rb[q]; }
         if (int rc = comm_alltoallv(c, r.send.p, so.data(), sb.data(), r.recv.p, ro.data(), rb.data(), stream_, err)) return rc;
-        HIPCHK(stream_wait(stream_));                      // (d_cur / cur go out of scope; the caller reads r.recv next)
+        // (no wait: what follows is ordered on the same stream, and every buffer involved outlives the call)
         times_.add("shard_graph_exchanged_MB", (double)(r.n_send * PW * 8) / 1e6);
         return 0;
     }
@@ -1478,9 +1483,7 @@ public:
         std::vector<uint64_t> so(world), sb(world), ro(world), rb(world);
         uint64_t a = 0, b = 0;
         for (uint32_t q = 0; q < world; q++) { so[q] = a; sb[q] = r.recv_cnt[q] * 8; a += sb[q]; ro[q] = b; rb[q] = r.send_cnt[q] * 8; b += rb[q]; }
-        if (int rc = comm_alltoallv(c, ans, so.data(), sb.data(), back.p, ro.data(), rb.data(), stream_, err)) return rc;
-        HIPCHK(stream_wait(stream_));
-        return 0;
+        return comm_alltoallv(c, ans, so.data(), sb.data(), back.p, ro.data(), rb.data(), stream_, err);
     }
 
     int shard_assemble(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) override {
@@ -1500,34 +1503,38 @@ public:
         };
         const double t_all0 = now_ms_();
         // ---- 1. adjacency: local tables, local candidates, then the candidates of other ranks
+        // (every buffer a collective or a kernel of this call touches lives until the call's last wait: no wait is needed for
+        // a buffer's sake; the waits that remain are the ones whose RESULT the host needs)
         xq_n_ = 0;
         EvTimer tg(stream_);
-        int rc_local = build_graph(err);
-        if (int rc = agree(rc_local, "the local graph build")) return rc;
+        const int rc_local = build_graph(err);
+        if (world == 1 && rc_local) return rc_local;
         Graph<W> g = graph_view();
         DevBuf<unsigned long long> xnb;                  // per cross query: the neighbour's oriented global id (~0: not a solid k-mer)
-        Routed rq;
-        DevBuf<uint32_t> xq_sidx_keep;
+        Routed rq, hl;
+        DevBuf<unsigned long long> xans, xback;
+        DevBuf<uint32_t> hdest; DevBuf<uint64_t> hpay;
         if (world > 1) {
-            if (int rc = route_exchange<W + 1>(c, xq_dest_.p, xq_pay_.p, xq_n_, rq, err)) return rc;
-            DevBuf<unsigned long long> ans, back;
-            if (int rc = ans.alloc(rq.n_recv + 1, err)) return rc;
+            // (the result of the local build travels with the size exchange of the first routed exchange)
+            std::vector<uint64_t> flags;
+            const int rc_x = rc_local ? rc_local : 0;
+            if (int rc = route_exchange<W + 1>(c, xq_dest_.p, xq_pay_.p, rc_x ? 0u : xq_n_, rq, err, rc_x ? 1u : 0u, &flags)) { if (rc_x) return rc_x; return rc; }
+            if (rc_x) return rc_x;
+            for (uint64_t f : flags) if (f) { err = "sharded assembly: another rank failed during the local graph build"; return -5; }
+            if (int rc = xans.alloc(rq.n_recv + 1, err)) return rc;
             if (rq.n_recv) {
-                hipLaunchKernelGGL(k_xq_answer<W>, dim3(grid_for(rq.n_recv)), dim3(256), 0, stream_, g.keys, g.gt, rq.recv.p, rq.n_recv, gbase, ans.p);
+                hipLaunchKernelGGL(k_xq_answer<W>, dim3(grid_for(rq.n_recv)), dim3(256), 0, stream_, g.keys, g.gt, rq.recv.p, rq.n_recv, gbase, xans.p);
                 HIPCHK(hipGetLastError());
             }
-            if (int rc = reply_exchange(c, rq, ans.p, back, err)) return rc;
+            if (int rc = reply_exchange(c, rq, xans.p, xback, err)) return rc;
             if (int rc = xnb.alloc(xq_n_ + 1, err)) return rc;
             if (xq_n_) {
-                hipLaunchKernelGGL(k_xq_apply, dim3(grid_for(xq_n_)), dim3(256), 0, stream_, xq_meta_.p, rq.sidx.p, back.p, xq_n_, adj_.p, nb_.p, xnb.p);
+                hipLaunchKernelGGL(k_xq_apply, dim3(grid_for(xq_n_)), dim3(256), 0, stream_, xq_meta_.p, rq.sidx.p, xback.p, xq_n_, adj_.p, nb_.p, xnb.p);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));    // (stage inspection: the complete initial adjacency)
             }
-            HIPCHK(stream_wait(stream_));                // (ans / back go out of scope)
-            rq.send.release(); rq.recv.release();
-            xq_pay_.release(); xq_dest_.release();
         } else if (int rc = xnb.alloc(1, err)) return rc;
-        times_.add("shard_graph_adjacency_total", tg.stop());
+        tg.stop_later("shard_graph_adjacency_total", pending_timers_);
         times_.add("shard_graph_cross_queries_x1e-3", xq_n_ * 1e-3);
         // ---- 2. half links: which links across ranks are simple
         EvTimer th(stream_);
@@ -1535,9 +1542,7 @@ public:
         if (int rc = xpred.alloc(2ull * n + 2, err)) return rc;
         HIPCHK(hipMemsetAsync(xpred.p, 0xFF, (2ull * n + 2) * 4, stream_));
         HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
-        Routed hl;
         if (world > 1) {
-            DevBuf<uint32_t> hdest; DevBuf<uint64_t> hpay;
             if (int rc = hdest.alloc(2ull * n + 1, err)) return rc;
             if (int rc = hpay.alloc(4ull * n + 2, err)) return rc;
             if (n) {
@@ -1549,10 +1554,8 @@ public:
                 hipLaunchKernelGGL(k_hl_apply, dim3(grid_for(hl.n_recv)), dim3(256), 0, stream_, hl.recv.p, hl.n_recv, gbase, n, adj_.p, xpred.p, (uint32_t *)(ctl_.p + 13));
                 HIPCHK(hipGetLastError());
             }
-            HIPCHK(stream_wait(stream_));
-            hl.send.release();
         } else if (int rc = hl.recv.alloc(2, err)) return rc;
-        times_.add("shard_graph_half_links", th.stop());
+        th.stop_later("shard_graph_half_links", pending_timers_);
         // ---- 3. the chains of simple links that stay on this rank (the single-GPU contraction)
         ChainState cs;
         int rc_chain = 0;
@@ -1577,9 +1580,9 @@ public:
         if (int rc = gsegs.alloc(M + 1, err)) return rc;
         if (int rc = d_gbases.alloc(world + 1, err)) return rc;
         HIPCHK(hipMemcpyAsync(d_gbases.p, sh_gbase_.data(), (size_t)(world + 1) * 8, hipMemcpyHostToDevice, stream_));
+        DevBuf<uint32_t> ldest; DevBuf<uint64_t> lpay; DevBuf<unsigned long long> lans, lback;
+        Routed ls;
         {
-            DevBuf<uint32_t> ldest; DevBuf<uint64_t> lpay; DevBuf<unsigned long long> lans, lback;
-            Routed ls;
             if (int rc = ldest.alloc(n_lch + 1, err)) return rc;
             if (int rc = lpay.alloc(n_lch + 1, err)) return rc;
             if (n_lch) {
@@ -1605,9 +1608,6 @@ public:
             std::vector<uint64_t> off(world), len(world);
             for (uint32_t r = 0; r < world; r++) { off[r] = lbase[r] * sizeof(SegRec); len[r] = lcnt[r] * sizeof(SegRec); }
             if (int rc = comm_allgatherv(c, lsegs.p, gsegs.p, off.data(), len.data(), stream_, err)) return rc;
-            unsigned int fl = 0;
-            if (int rc = read_ctl(fl, 13, err)) return rc;         // (also: the staging buffers above are idle when they go)
-            if (fl) { err = fl == 1 ? "sharded assembly: a record reached a rank that does not own its k-mer (ownership rules disagree)" : "sharded assembly: the two sides of a link across ranks disagree"; return -6; }
         }
         // rank the gathered list: unitigs (rings across ranks in the same pass: collapse.h)
         DevBuf<RankRec> Ra, Rb; DevBuf<uint32_t> slot_of, uid_of_slot; DevBuf<FinRec> fin; DevBuf<UHead> d_uheads; DevBuf<unsigned int> d_M;
@@ -1633,8 +1633,15 @@ public:
             hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, gsegs.p, (const unsigned int *)d_M.p, Ri, slot_of.p, fin.p);
             HIPCHK(hipGetLastError());
             unsigned int hM2[2] = {0, 0};
+            unsigned long long h_fl = 0;
             HIPCHK(hipMemcpyAsync(hM2, d_M.p, 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(&h_fl, ctl_.p + 13, 8, hipMemcpyDeviceToHost, stream_));      // (flags of k_hl_apply / k_ls_answer, read with the counts)
             HIPCHK(stream_wait(stream_));
+            if ((uint32_t)h_fl) {
+                err = (uint32_t)h_fl == 1 ? "sharded assembly: a record reached a rank that does not own its k-mer (ownership rules disagree)"
+                                         : "sharded assembly: the two sides of a link across ranks disagree";
+                return -6;
+            }
             n_u = hM2[1];
             uheads.resize(n_u);
             if (n_u) HIPCHK(hipMemcpy(uheads.data(), d_uheads.p, (size_t)n_u * sizeof(UHead), hipMemcpyDeviceToHost));
@@ -1682,7 +1689,10 @@ public:
         }
         UnitigGraphResult res;
         int rc_ug = unitig_assemble(k_, recs, tips, bubbles, res, err);
-        if (int rc = agree(rc_ug ? -6 : 0, "the unitig graph")) return rc;
+        // (the same code on the same records: it fails on every rank or on none — an agreement round is only paid where the
+        // graph is large enough for one host to run out of memory alone)
+        if (n_u >= (1u << 20)) { if (int rc = agree(rc_ug ? -6 : 0, "the unitig graph")) return rc; }
+        else if (rc_ug) return -6;
         tips_removed_ = res.tips_removed; bubbles_removed_ = res.bubbles_removed; rounds_ = res.rounds;
         // rings: the smallest k-mer of their records — a pass over the nodes of the rings, on every rank, merged on the host
         if (!res.need_min.empty()) {
@@ -1737,7 +1747,7 @@ public:
                 mk[res.need_min[i]] = best;
             }
             int rc_rr = unitig_resolve_rings(k_, recs, mk, res, err);
-            if (int rc = agree(rc_rr ? -6 : 0, "the rings of the unitig graph")) return rc;
+            if (rc_rr) return -6;                       // (deterministic on identical input: every rank takes the same way out)
         }
         // layout: contig text offsets, and for every unitig record where its nodes go
         std::vector<ULayout> lay(n_u + 1);
@@ -1839,6 +1849,8 @@ private:
     uint64_t n_solid_global_ = 0;
     uint32_t xq_n_ = 0;                              // cross-rank neighbour queries of this rank (build_graph)
     DevBuf<uint32_t> xq_dest_; DevBuf<uint64_t> xq_pay_; DevBuf<unsigned long long> xq_meta_;
+    DevBuf<unsigned long long> rt_row_, rt_all_, rt_cur_;   // the router's small buffers (kept: no wait for their sake)
+    std::vector<unsigned long long> rt_cur_host_;
 };
 
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }

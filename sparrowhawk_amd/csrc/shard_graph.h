@@ -29,7 +29,7 @@ static constexpr int ROUTE_CH = 4096;                      // items per workgrou
 static constexpr uint32_t ROUTE_MAX_WORLD = 256;
 
 // ---- routing of fixed-size records to destination ranks (dest[i] = rank or NIL: not an item) ---------------------
-__global__ __launch_bounds__(256) void k_route_count(const uint32_t *__restrict__ dest, uint32_t n, uint32_t *__restrict__ counts) {
+__global__ __launch_bounds__(256) void k_route_count(const uint32_t *__restrict__ dest, uint32_t n, unsigned long long *__restrict__ counts) {
     __shared__ uint32_t h[ROUTE_MAX_WORLD];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void k_route_count(const uint32_t *__restrict_
         if (d < ROUTE_MAX_WORLD) atomicAdd(&h[d], 1u);
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 // send[cursor[d]...]: the records of destination d, PW words each; sidx[i] = the record index item i got.  One global
 // atomic per workgroup and destination (a workgroup owns ROUTE_CH consecutive items).
