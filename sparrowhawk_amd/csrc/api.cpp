@@ -47,7 +47,9 @@ struct shk_handle {
     IPipeline *pipe = nullptr;
     shk_progress_cb cb = nullptr;
     void *cb_user = nullptr;
-    std::string err, first_err, pre_json, asm_json, timings_json;
+    std::string err, first_err, pre_json, timings_json;
+    ByteVec asm_json;                  // NUL-terminated
+    const char *asm_json_dev = nullptr; // a fragmented assembly's JSON, written on the device: pinned memory owned by the pipeline
     uint64_t histo[SHK_HISTO_BINS] = {0};
     uint32_t used_min_count = 0;
     bool fit_ok = false;
@@ -135,7 +137,6 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
 void shk_free(shk_handle *h) {
     if (!h) return;
     DevGuard g(h->pipe ? h->pipe->device() : current_device());
-    give_big_string(std::move(h->asm_json));
     delete h->pipe;
     delete h;
 }
@@ -694,6 +695,7 @@ static int assemble_impl(shk_handle *h) {
         build_assembly_text(contigs, h->k, h->text);
         h->asm_json.swap(h->text.json);
         h->pipe->times().add("outputs_host_clock", now_ms() - t1);
+        for (auto &kv : h->text.stage_ms) h->pipe->times().add(kv.first, kv.second);
         h->st = St::Assembled;
         h->post("assembly:end");
         return SHK_OK;
@@ -707,14 +709,23 @@ static int assemble_impl(shk_handle *h) {
     h->post("assembly:collapse_graph");
     if (h->pipe->n_solid() >= (1u << 20)) writer_prewarm(3000);     // megabases of output in about a millisecond
     std::vector<RawContig> contigs;
-    rc = h->pipe->collapse(contigs, err);
+    const char *dev_json = nullptr; size_t dev_json_len = 0; uint64_t dev_nc = 0;
+    rc = h->pipe->collapse(contigs, err, &dev_json, &dev_json_len, &dev_nc);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
     h->pipe->times().add("assemble_device_total_host_clock", now_ms() - t0);
     h->post("assembly:saving");
+    if (dev_json) {                                    // a fragmented assembly: its text was written on the device (csrc/writer_gpu.h)
+        h->asm_json_dev = dev_json;
+        h->pipe->times().add("outputs_host_clock", 0.0);
+        h->st = St::Assembled;
+        h->post("assembly:end");
+        return SHK_OK;
+    }
     const double t1 = now_ms();
     build_assembly_text(contigs, h->k, h->text);
     h->asm_json.swap(h->text.json);
     h->pipe->times().add("outputs_host_clock", now_ms() - t1);
+    for (auto &kv : h->text.stage_ms) h->pipe->times().add(kv.first, kv.second);
     h->st = St::Assembled;
     h->post("assembly:end");
     return SHK_OK;
@@ -723,7 +734,8 @@ static int assemble_impl(shk_handle *h) {
 const char *shk_get_assembly(shk_handle *h) {
     if (!h) return nullptr;
     if (h->st != St::Assembled) { h->err = "get_assembly before assemble"; return nullptr; }
-    return h->asm_json.c_str();
+    if (h->asm_json_dev) return h->asm_json_dev;
+    return h->asm_json.empty() ? "" : (const char *)h->asm_json.data();
 }
 
 // ---- packer ------------------------------------------------------------------------------
@@ -1063,11 +1075,9 @@ char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const ui
         }
         AssemblyText text;
         build_assembly_text(contigs, k, text);
-        char *out = (char *)malloc(text.json.size() + 1);
+        char *out = (char *)malloc(text.json.size());        // (the JSON carries its terminator)
         if (!out) return nullptr;
         memcpy(out, text.json.data(), text.json.size());
-        out[text.json.size()] = 0;
-        give_big_string(std::move(text.json));
         return out;
     } catch (...) { return nullptr; }
 }

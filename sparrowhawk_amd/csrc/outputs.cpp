@@ -56,25 +56,6 @@ std::string preprocessing_json(uint64_t nkmers, const uint64_t *h, uint32_t used
     return j;
 }
 
-// Large output strings are recycled across handles: a fresh 15 MB std::string costs page faults
-// on every assemble (measured 1 -> 4 ms), a recycled one does not.
-static std::mutex g_pool_mu;
-static std::vector<std::string> g_pool;
-std::string take_big_string() {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.empty()) return std::string();
-    size_t best = 0;
-    for (size_t i = 1; i < g_pool.size(); i++) if (g_pool[i].capacity() > g_pool[best].capacity()) best = i;
-    std::string s = std::move(g_pool[best]);
-    g_pool.erase(g_pool.begin() + best);
-    return s;                                           // (with its old size: the writer overwrites it)
-}
-void give_big_string(std::string &&s) {
-    if (s.capacity() < (1u << 20)) return;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    if (g_pool.size() < 8) g_pool.push_back(std::move(s));
-}
-
 namespace {
 // The writers emit JSON-escaped text (NL/TAB/QUOTE are the only specials they produce) into a sink: one
 // sink measures, the other writes through a pointer — every section's size is known before a byte is
@@ -120,7 +101,10 @@ struct PtrSink {
 namespace {
 class WorkPool {
 public:
-    static WorkPool &get() { static WorkPool *p = new WorkPool(); return *p; }     // never destroyed (process teardown order)
+    static WorkPool &get() { static WorkPool *p = new WorkPool(16u, "SHK_WRITER_THREADS"); return *p; }     // never destroyed (process teardown order)
+    // a fragmented assembly (10^4 .. 10^7 contigs: a metagenome) is seconds of hashing, sorting and text on 16 threads; its
+    // jobs are coarse enough for every core of the host (created on first use)
+    static WorkPool &big() { static WorkPool *p = new WorkPool(64u, "SHK_WRITER_THREADS_BIG"); return *p; }
     unsigned size() const { return (unsigned)n_workers_ + 1u; }                   // workers + the caller
     // runs fn(task) for task in [0, n_tasks) on the pool and the calling thread; returns when all are done
     template <typename F> void run(size_t n_tasks, F &&fn) {
@@ -143,11 +127,11 @@ public:
         if (failed_) throw std::bad_alloc();
     }
 private:
-    WorkPool() {
+    WorkPool(unsigned cap, const char *env_name) {
         unsigned hc = std::thread::hardware_concurrency();
         if (hc == 0) hc = 4;
-        unsigned n = std::min(hc, 16u);
-        if (const char *v = getenv("SHK_WRITER_THREADS")) { const long t = strtol(v, nullptr, 10); if (t >= 1 && t <= 64) n = (unsigned)t; }
+        unsigned n = std::min(hc, cap);
+        if (const char *v = getenv(env_name)) { const long t = strtol(v, nullptr, 10); if (t >= 1 && t <= 256) n = (unsigned)t; }
         n_workers_ = n - 1;
         for (unsigned i = 1; i < n; i++) std::thread([this] { loop(); }).detach();
     }
@@ -224,8 +208,8 @@ std::string revcomp(const char *s, size_t n) {
 }
 
 // parallel loop over [0, n) in `pieces` contiguous ranges
-template <typename F> void par_ranges(size_t n, size_t min_per_piece, F &&fn) {
-    WorkPool &pool = WorkPool::get();
+template <typename F> void par_ranges(size_t n, size_t min_per_piece, F &&fn, WorkPool *use = nullptr) {
+    WorkPool &pool = use ? *use : WorkPool::get();
     size_t pieces = std::min<size_t>(pool.size() * 4, n / std::max<size_t>(min_per_piece, 1));
     if (pieces < 2) { fn(0, n); return; }
     pool.run(pieces, [&](size_t t) { fn(n * t / pieces, n * (t + 1) / pieces); });
@@ -239,6 +223,12 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     const size_t par_min = (pm && *pm) ? (size_t)strtoull(pm, nullptr, 10) : ((size_t)1 << 20);
     const bool many = contigs.size() >= (par_min >= ((size_t)1 << 20) ? (size_t)20000 : (size_t)2);
     const size_t grain = many && par_min < ((size_t)1 << 20) ? 1 : 2048;
+    // (many = a fragmented assembly; the forced-parallel test mode keeps the small pool)
+    WorkPool &wp = (many && contigs.size() >= 200000) ? WorkPool::big() : WorkPool::get();
+    out.stage_ms.clear();
+    auto clock_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = clock_ms();
+    auto lap = [&](const char *name) { const double t = clock_ms(); out.stage_ms.emplace_back(name, t - t_last); t_last = t; };
     // SPEC S10: each unitig is emitted as min(seq, revcomp(seq))
     auto canon = [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
@@ -246,7 +236,8 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
             if (revcomp_is_smaller(c.data(), c.size())) { c.own = revcomp(c.data(), c.size()); c.ext = nullptr; c.ext_n = 0; }
         }
     };
-    if (many) par_ranges(contigs.size(), grain, canon); else canon(0, contigs.size());
+    if (many) par_ranges(contigs.size(), grain, canon, &wp); else canon(0, contigs.size());
+    lap("outputs_canonical_strand");
     // SPEC S11: order by (length desc, sequence asc).  An index is sorted, not the records; with many contigs the
     // ranges are sorted in parallel and merged pairwise.
     const size_t nc = contigs.size();
@@ -264,7 +255,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
             order[i] = SortKey{pf, (uint32_t)std::min<size_t>(n, 0xFFFFFFFFu), (uint32_t)i};
         }
     };
-    if (many) par_ranges(nc, grain, make_keys); else make_keys(0, nc);
+    if (many) par_ranges(nc, grain, make_keys, &wp); else make_keys(0, nc);
     auto before = [&](const SortKey &x, const SortKey &y) {
         if (x.len != y.len) return x.len > y.len;
         if (x.prefix != y.prefix) return x.prefix < y.prefix;
@@ -274,7 +265,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         return c != 0 ? c < 0 : x.idx < y.idx;                          // (equal spellings cannot occur; keeps the order total)
     };
     if (many && nc >= 4) {
-        WorkPool &pool = WorkPool::get();
+        WorkPool &pool = wp;
         size_t pieces = 1; while (pieces * 2 <= pool.size() * 2 && nc / (pieces * 2) >= grain) pieces *= 2;
         std::vector<size_t> cut(pieces + 1);
         for (size_t t = 0; t <= pieces; t++) cut[t] = nc * t / pieces;
@@ -292,11 +283,12 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     {
         std::vector<RawContig> sorted(nc);
         auto place = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) sorted[i] = std::move(contigs[order[i].idx]); };
-        if (many) par_ranges(nc, grain, place); else place(0, nc);
+        if (many) par_ranges(nc, grain, place, &wp); else place(0, nc);
         contigs.swap(sorted);
     }
     std::vector<SortKey>().swap(order);
     out.ncontigs = nc;
+    lap("outputs_order");
 
     // links: first k-mer of every (contig, orientation) -> id; '+' entries win over '-'.  K-mers are handled
     // 2-bit packed (4 words hold k <= 127): a fragmented assembly has 10^4..10^7 contigs and this map is
@@ -341,7 +333,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     // what "all '+' entries first, then all '-', the first one in wins" gave the serial writer, and is order-free.
     size_t cap = 16; while (cap < 4 * nc + 4) cap <<= 1;
     std::unique_ptr<std::atomic<uint64_t>[]> hv(new std::atomic<uint64_t>[cap]);
-    par_ranges(cap, 1 << 16, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) hv[i].store(~0ull, std::memory_order_relaxed); });
+    par_ranges(cap, 1 << 16, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) hv[i].store(~0ull, std::memory_order_relaxed); }, &wp);
     const KeyHash hasher;
     auto dec_c = [](uint64_t v) { return (uint32_t)(v & ((1ull << 40) - 1)); };
     auto dec_o = [](uint64_t v) { return (uint32_t)((v >> 40) & 1); };
@@ -381,7 +373,8 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
             put2(pack_rc(contigs[i].data() + contigs[i].size() - k), i, 1);           // first k-mer of the '-' orientation
         }
     };
-    if (many) par_ranges(nc, grain, fill); else fill(0, nc);
+    if (many) par_ranges(nc, grain, fill, &wp); else fill(0, nc);
+    lap("outputs_link_table");
     typedef std::tuple<uint32_t, uint32_t, uint32_t, uint32_t> Link;
     auto find_links = [&](size_t a, size_t b, std::vector<Link> &dst) {
         for (size_t i = a; i < b; i++) for (uint32_t o = 0; o < 2; o++) {
@@ -400,7 +393,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     };
     std::vector<Link> links;
     if (many) {
-        WorkPool &pool = WorkPool::get();
+        WorkPool &pool = wp;
         const size_t pieces = std::max<size_t>(1, std::min<size_t>(pool.size() * 4, nc / grain));
         std::vector<std::vector<Link>> part(pieces);
         pool.run(pieces, [&](size_t t) { find_links(nc * t / pieces, nc * (t + 1) / pieces, part[t]); });
@@ -408,8 +401,10 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         links.reserve(tot);
         for (auto &v : part) links.insert(links.end(), v.begin(), v.end());
     } else find_links(0, nc, links);
+    lap("outputs_link_find");
     std::sort(links.begin(), links.end());
     links.erase(std::unique(links.begin(), links.end()), links.end());
+    lap("outputs_link_sort");
 
     // Straight into the JSON text in key order (a 5 Mbp contig is copied three times — FASTA, GFA1, GFA2 —
     // and never staged in per-format strings).  Every record's size is known before a byte is written, so the
@@ -488,11 +483,11 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     for (size_t p = 0; p < parts.size(); p++) {
         const size_t cnt = parts[p].count;
         if (!cnt) continue;
-        const size_t per = many ? std::max<size_t>(grain, cnt / (WorkPool::get().size() * 4) + 1) : cnt;
+        const size_t per = many ? std::max<size_t>(grain, cnt / (wp.size() * 4) + 1) : cnt;
         for (size_t a = 0; a < cnt; a += per) ranges.push_back(Range{p, a, std::min(cnt, a + per), 0, 0});
     }
     auto measure = [&](size_t r) { SizeSink z; for (size_t i = ranges[r].a; i < ranges[r].b; i++) emit_rec(z, parts[ranges[r].part].kind, i); ranges[r].bytes = z.n; };
-    if (many && ranges.size() > 1) WorkPool::get().run(ranges.size(), measure); else for (size_t r = 0; r < ranges.size(); r++) measure(r);
+    if (many && ranges.size() > 1) wp.run(ranges.size(), measure); else for (size_t r = 0; r < ranges.size(); r++) measure(r);
     {
         size_t at = 0, r = 0;
         for (size_t p = 0; p < parts.size(); p++) {
@@ -502,10 +497,13 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         part_off[parts.size()] = at;
     }
     const size_t total = part_off[parts.size()];
-    // (a recycled string keeps its size: growing it is the only time its bytes are filled twice)
-    std::string js = take_big_string();
-    if (js.size() < total) js.resize(total);
-    char *base = &js[0];
+    lap("outputs_measure");
+    // (uninitialised storage: every byte is written exactly once below, by the threads that own the ranges — a resize that
+    // zero-fills a gigabyte of JSON first cost a third of the writer on a metagenome; large blocks are recycled: bytebuf.h)
+    ByteVec js;
+    js.resize(total + 1);
+    char *base = (char *)js.data();
+    base[total] = 0;
     // sequences above `big` bytes are cut out of their record and copied in pieces by all threads
     struct Copy { const char *src; char *dst; size_t n; };
     const size_t big = std::max<size_t>(par_min / 4, 1);
@@ -518,17 +516,18 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         w.big = seq_bytes >= par_min ? big : (size_t)-1; w.deferred = &deferred; w.mu = &deferred_mu;
         for (size_t i = ranges[r].a; i < ranges[r].b; i++) emit_rec(w, parts[ranges[r].part].kind, i);
     };
-    if (ranges.size() > 1 && (many || seq_bytes >= par_min)) WorkPool::get().run(ranges.size(), write_range);
+    if (ranges.size() > 1 && (many || seq_bytes >= par_min)) wp.run(ranges.size(), write_range);
     else for (size_t r = 0; r < ranges.size(); r++) write_range(r);
     if (!deferred.empty()) {
         std::vector<Copy> copies;
         for (auto &d : deferred)
             for (size_t o = 0; o < d.second.second; o += piece)
                 copies.push_back(Copy{d.second.first + o, d.first + o, std::min(piece, d.second.second - o)});
-        WorkPool::get().run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
+        wp.run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
     }
     WorkPool::get().prewarm(0);                         // the writer is done: the workers go back to sleep
-    js.resize(total);
+    if (&wp != &WorkPool::get()) wp.prewarm(0);
+    lap("outputs_write");
     out.json = std::move(js);
     out.fasta.clear(); out.gfa1.clear(); out.gfa2.clear(); out.dot.clear();
 }

@@ -6,13 +6,16 @@
 #include <stdint.h>
 #include <string>
 #include <vector>
+#include "bytebuf.h"
 #include "pipeline.h"
 
 namespace shk {
 
 struct AssemblyText {
     uint64_t ncontigs = 0;
-    std::string fasta, dot, gfa1, gfa2, json;
+    std::string fasta, dot, gfa1, gfa2;
+    ByteVec json;                              // NUL-terminated (size() = text + 1); uninitialised storage written once by the writer's threads
+    std::vector<std::pair<std::string, double>> stage_ms;     // where the writer's time went (host clock)
 };
 
 void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out);
@@ -21,7 +24,5 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
 void writer_prewarm(long microseconds);
 std::string preprocessing_json(uint64_t nkmers, const uint64_t *histo500, uint32_t used_min_count);
 void json_escape_into(std::string &dst, const std::string &s);
-std::string take_big_string();
-void give_big_string(std::string &&s);
 
 }  // namespace shk

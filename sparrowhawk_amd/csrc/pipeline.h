@@ -58,7 +58,11 @@ public:
     // assembly (SPEC S8-S10)
     virtual int build_graph(std::string &err) = 0;
     virtual int correct(bool tips, bool bubbles, std::string &err) = 0;
-    virtual int collapse(std::vector<RawContig> &out, std::string &err) = 0;
+    // json (optional): a FRAGMENTED assembly (>= SHK_DEVICE_WRITER_MIN contigs, default 20 000) is turned into the
+    // get_assembly() JSON on the device (writer_gpu.h: order, links, FASTA / DOT / GFA1 / GFA2 text) and `out` stays empty;
+    // *json then points at the NUL-terminated text in pinned host memory owned by the pipeline, *n_contigs says how many
+    virtual int collapse(std::vector<RawContig> &out, std::string &err, const char **json = nullptr, size_t *json_len = nullptr,
+                         uint64_t *n_contigs = nullptr) = 0;
     virtual int get_adjacency(uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
                               uint64_t cap, std::string &err) = 0;
     // shard layer (one process per GPU): partition -> pack -> [all-to-all] -> count -> rows ->

@@ -12,6 +12,7 @@
 //   (count_global.h: the first, global-atomic counting path, kept as a cross-check)
 // Integer/hash work only: no MFMA anywhere on this path.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -99,6 +100,7 @@ namespace shk {
 #include "graph_part.h"
 #include "collapse.h"
 #include "shard_graph.h"
+#include "writer_gpu.h"
 
 // ------------------------------------------------------------------------------------------
 // host side
@@ -1364,8 +1366,9 @@ public:
         return 0;
     }
 
-    int collapse(std::vector<RawContig> &out, std::string &err) override {
+    int collapse(std::vector<RawContig> &out, std::string &err, const char **json, size_t *json_len, uint64_t *n_contigs) override {
         out.clear();
+        if (json) *json = nullptr;
         if (!graph_ready_) { err = "graph not built"; return -2; }
         const uint32_t n = (uint32_t)n_solid_;
         if (n == 0) return 0;
@@ -1393,6 +1396,18 @@ public:
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
+            if (json && emitted.size() >= env_u64("SHK_DEVICE_WRITER_MIN", 20000) && emitted.size() < 0x7FFFFFF0ull) {
+                // a fragmented assembly: order, links and text on the device (writer_gpu.h)
+                std::vector<WContig> wc(emitted.size());
+                for (size_t q = 0; q < emitted.size(); q++) {
+                    const uint32_t i = emitted[q];
+                    wc[q].off = head_off[i].off; wc[q].kc = heads[i].kc; wc[q].len = (uint32_t)(heads[i].len + (uint64_t)(k_ - 1)); wc[q].slot = i;
+                    if (heads[i].len + (uint64_t)(k_ - 1) > 0xFFFFFFFFull) { err = "device writer: a contig beyond 2^32 bases"; return -1; }
+                }
+                if (int rc = device_write_json(g, cs, wc, (uint32_t)heads.size(), d_out.p, out_bytes, json, json_len, err)) return rc;
+                if (n_contigs) *n_contigs = emitted.size();
+                return 0;
+            }
             auto tcp = std::chrono::steady_clock::now();
             HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
             HIPCHK(stream_wait(stream_));
@@ -1404,6 +1419,131 @@ public:
             }
             times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
         }
+        return 0;
+    }
+
+    // ---- the writer on the device (writer_gpu.h): fragmented assemblies ------------------------------------------
+    template <typename T> int scan_excl(DevBuf<T> &in, DevBuf<T> &out, uint32_t n, DevBuf<char> &tmp, std::string &err) {
+        if (int rc = out.alloc((size_t)n + 1, err)) return rc;
+        if (!n) return 0;
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in.p, out.p, (int)n, stream_));
+        if (tmp.n < bytes) if (int rc = tmp.alloc(bytes + 256, err)) return rc;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in.p, out.p, (int)n, stream_));
+        return 0;
+    }
+    int device_write_json(Graph<W> &g, ChainState &cs, const std::vector<WContig> &wc, uint32_t n_slots, const char *d_text, uint64_t text_bytes,
+                          const char **json, size_t *json_len, std::string &err) {
+        typedef unsigned long long u64;
+        const uint32_t nc = (uint32_t)wc.size();
+        EvTimer tw(stream_);
+        DevBuf<WContig> d_c; DevBuf<u64> keys, keys2, slen, skc; DevBuf<uint32_t> vals, vals2, rank_of_slot, rank_of_contig; DevBuf<char> tmp;
+        if (int rc = d_c.alloc(nc, err)) return rc;
+        if (int rc = keys.alloc(nc, err)) return rc;
+        if (int rc = keys2.alloc(nc, err)) return rc;
+        if (int rc = vals.alloc(nc, err)) return rc;
+        if (int rc = vals2.alloc(nc, err)) return rc;
+        if (int rc = rank_of_slot.alloc(n_slots + 1, err)) return rc;
+        if (int rc = rank_of_contig.alloc(nc, err)) return rc;
+        if (int rc = slen.alloc(nc, err)) return rc;
+        if (int rc = skc.alloc(nc, err)) return rc;
+        HIPCHK(hipMemcpyAsync(d_c.p, wc.data(), (size_t)nc * sizeof(WContig), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(rank_of_slot.p, 0, ((size_t)n_slots + 1) * 4, stream_));
+        // ---- order
+        hipLaunchKernelGGL(k_w_keys, dim3(grid_for(nc)), dim3(256), 0, stream_, d_text, d_c.p, nc, keys.p, vals.p);
+        {
+            size_t bytes = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, keys.p, keys2.p, vals.p, vals2.p, (int)nc, 0, 64, stream_));
+            if (int rc = tmp.alloc(bytes + 256, err)) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, keys.p, keys2.p, vals.p, vals2.p, (int)nc, 0, 64, stream_));
+        }
+        hipLaunchKernelGGL(k_w_ties, dim3(grid_for(nc)), dim3(256), 0, stream_, d_text, d_c.p, nc, keys2.p, vals2.p);
+        hipLaunchKernelGGL(k_w_rank, dim3(grid_for(nc)), dim3(256), 0, stream_, d_c.p, nc, vals2.p, rank_of_slot.p, slen.p, skc.p, rank_of_contig.p);
+        HIPCHK(hipGetLastError());
+        // ---- links
+        DevBuf<u64> links, links2; DevBuf<unsigned int> d_cnt;
+        const uint32_t link_cap = 8u * nc + 64u;
+        if (int rc = links.alloc(link_cap, err)) return rc;
+        if (int rc = links2.alloc(link_cap, err)) return rc;
+        if (int rc = d_cnt.alloc(4, err)) return rc;
+        HIPCHK(hipMemsetAsync(d_cnt.p, 0, 16, stream_));
+        hipLaunchKernelGGL(k_w_links<W>, dim3(grid_for(2ull * nc)), dim3(256), 0, stream_, g, cs.d_heads.p, cs.ol.p, d_c.p, nc, vals2.p, rank_of_slot.p,
+                           links.p, d_cnt.p, link_cap, d_cnt.p + 2);
+        HIPCHK(hipGetLastError());
+        unsigned int h_cnt[4] = {0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h_cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(stream_wait(stream_));
+        if (h_cnt[2]) { err = "device writer: the graph and the chains disagree about a link (" + std::to_string(h_cnt[2]) + ")"; return -6; }
+        if (h_cnt[0] > link_cap) { err = "device writer: more links than 8 per contig"; return -6; }
+        uint32_t nl = h_cnt[0];
+        if (nl) {
+            size_t bytes = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, links.p, links2.p, (int)nl, 0, 64, stream_));
+            if (tmp.n < bytes) if (int rc = tmp.alloc(bytes + 256, err)) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortKeys(tmp.p, bytes, links.p, links2.p, (int)nl, 0, 64, stream_));
+            bytes = 0;
+            HIPCHK(hipcub::DeviceSelect::Unique(nullptr, bytes, links2.p, links.p, d_cnt.p + 1, (int)nl, stream_));
+            if (tmp.n < bytes) if (int rc = tmp.alloc(bytes + 256, err)) return rc;
+            HIPCHK(hipcub::DeviceSelect::Unique(tmp.p, bytes, links2.p, links.p, d_cnt.p + 1, (int)nl, stream_));
+            HIPCHK(hipMemcpyAsync(h_cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(stream_wait(stream_));
+            nl = h_cnt[1];
+        }
+        // ---- sizes and offsets of the records
+        const uint32_t ov = (uint32_t)(k_ - 1);
+        DevBuf<u64> s_fa, s_dn, s_1s, s_2s, s_dl, s_1l, s_2l, o_fa, o_dn, o_1s, o_2s, o_dl, o_1l, o_2l;
+        for (DevBuf<u64> *b : {&s_fa, &s_dn, &s_1s, &s_2s}) if (int rc = b->alloc((size_t)nc + 1, err)) return rc;
+        for (DevBuf<u64> *b : {&s_dl, &s_1l, &s_2l}) if (int rc = b->alloc((size_t)nl + 1, err)) return rc;
+        hipLaunchKernelGGL(k_w_contig_sizes, dim3(grid_for(nc)), dim3(256), 0, stream_, nc, slen.p, skc.p, s_fa.p, s_dn.p, s_1s.p, s_2s.p);
+        if (nl) hipLaunchKernelGGL(k_w_link_sizes, dim3(grid_for(nl)), dim3(256), 0, stream_, nl, links.p, ov, slen.p, s_dl.p, s_1l.p, s_2l.p);
+        HIPCHK(hipGetLastError());
+        if (int rc = scan_excl(s_fa, o_fa, nc, tmp, err)) return rc;
+        if (int rc = scan_excl(s_dn, o_dn, nc, tmp, err)) return rc;
+        if (int rc = scan_excl(s_1s, o_1s, nc, tmp, err)) return rc;
+        if (int rc = scan_excl(s_2s, o_2s, nc, tmp, err)) return rc;
+        if (int rc = scan_excl(s_dl, o_dl, nl, tmp, err)) return rc;
+        if (int rc = scan_excl(s_1l, o_1l, nl, tmp, err)) return rc;
+        if (int rc = scan_excl(s_2l, o_2l, nl, tmp, err)) return rc;
+        // totals: last offset + last size of every section
+        u64 last[14] = {0};
+        {
+            DevBuf<u64> *so[7][2] = {{&s_fa, &o_fa}, {&s_dn, &o_dn}, {&s_dl, &o_dl}, {&s_1s, &o_1s}, {&s_1l, &o_1l}, {&s_2s, &o_2s}, {&s_2l, &o_2l}};
+            for (int q = 0; q < 7; q++) {
+                const uint32_t cnt = (q == 2 || q == 4 || q == 6) ? nl : nc;
+                if (!cnt) continue;
+                HIPCHK(hipMemcpyAsync(&last[2 * q], so[q][0]->p + (cnt - 1), 8, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(hipMemcpyAsync(&last[2 * q + 1], so[q][1]->p + (cnt - 1), 8, hipMemcpyDeviceToHost, stream_));
+            }
+            HIPCHK(stream_wait(stream_));
+        }
+        u64 sect[7];
+        for (int q = 0; q < 7; q++) sect[q] = last[2 * q] + last[2 * q + 1];
+        // the literals between the sections (exactly outputs.cpp's)
+        const std::string lit[8] = {"{\"outfasta\":\"",
+                                    "\",\"ncontigs\":" + std::to_string(nc) + ",\"outdot\":\"digraph sparrowhawk {\\n",
+                                    "", "}\\n\",\"outgfa\":\"H\\tVN:Z:1.0\\n", "", "\",\"outgfav2\":\"H\\tVN:Z:2.0\\n", "", "\"}"};
+        u64 at = 0, lit_at[8], base[7];
+        for (int q = 0; q < 8; q++) { lit_at[q] = at; at += lit[q].size(); if (q < 7) { base[q] = at; at += sect[q]; } }
+        const u64 total = at;
+        DevBuf<char> d_js;
+        if (int rc = d_js.alloc(total + 8, err)) return rc;
+        if (int rc = hjson_.alloc(total + 8, err)) return rc;
+        for (int q = 0; q < 8; q++) if (!lit[q].empty()) HIPCHK(hipMemcpyAsync(d_js.p + lit_at[q], lit[q].data(), lit[q].size(), hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(d_js.p + total, 0, 1, stream_));
+        WBases B; B.fasta = base[0]; B.dotn = base[1]; B.dotl = base[2]; B.g1s = base[3]; B.g1l = base[4]; B.g2s = base[5]; B.g2l = base[6];
+        hipLaunchKernelGGL(k_w_contig_recs, dim3(grid_for(nc)), dim3(256), 0, stream_, nc, slen.p, skc.p, o_fa.p, o_dn.p, o_1s.p, o_2s.p, B, d_js.p);
+        if (nl) hipLaunchKernelGGL(k_w_link_recs, dim3(grid_for(nl)), dim3(256), 0, stream_, nl, links.p, ov, slen.p, o_dl.p, o_1l.p, o_2l.p, B, d_js.p);
+        hipLaunchKernelGGL(k_w_copy_seqs, dim3(grid_for((text_bytes + 7) / 8)), dim3(256), 0, stream_, d_text, (u64)text_bytes, d_c.p, nc, rank_of_contig.p,
+                           o_fa.p, o_1s.p, o_2s.p, skc.p, B, d_js.p);
+        HIPCHK(hipGetLastError());
+        times_.add("device_writer_kernels", tw.stop());
+        const double t0 = now_ms_();
+        HIPCHK(hipMemcpyAsync(hjson_.p, d_js.p, total + 1, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(stream_wait(stream_));
+        times_.add("device_writer_d2h_host_clock", now_ms_() - t0);
+        times_.add("device_writer_json_MB", (double)total / 1e6);
+        times_.add("device_writer_links_x1e-3", nl * 1e-3);
+        *json = hjson_.p; if (json_len) *json_len = (size_t)total;
         return 0;
     }
 
@@ -1839,6 +1979,7 @@ private:
     DevBuf<uint8_t> adj_, adj0_, alive_;
     DevBuf<uint32_t> row_starts_;                    // one bit per solid row: a group of rows of one minimiser partition starts here (k_row_starts)
     PinnedBuf hout_;                  // contigs as downloaded; RawContig::ext points into it
+    PinnedBuf hjson_;                 // the JSON of a fragmented assembly, written on the device (device_write_json)
     DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;
     uint64_t tips_removed_ = 0, bubbles_removed_ = 0; int rounds_ = 0;

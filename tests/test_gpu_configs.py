@@ -255,6 +255,7 @@ def test_config4_metagenome_share_of_one_gpu(torch_dev):
         pos += (base + rng.integers(300, int(lengths[gi]) - 300 - k, size=25)).tolist()
     check_sampled_counts(torch, d, h, k, pos)
     asm = h.get_assembly()
+    print("config4 share timings:", {kk: round(v, 2) for kk, v in h.timings().items()})
     cs = contigs_of_json(asm)
     n_nodes = sum(len(c) - k + 1 for c in cs)
     assert 0 < n_nodes <= h.n_solid                                            # correction only ever removes nodes

@@ -802,3 +802,29 @@ def test_a_failure_after_counted_batches_poisons_the_handle():
     h.preprocess(fq)
     h.assemble()
     compare_all(h, run_oracle([fq], k=31, min_count=2))
+
+
+@pytest.mark.parametrize("k,err,seed", [(31, 0.02, 1), (21, 0.03, 2), (51, 0.01, 3), (89, 0.005, 4)])
+def test_device_writer_equals_the_host_writer(k, err, seed):
+    """csrc/writer_gpu.h: the get_assembly() JSON of a fragmented assembly made on the device — contigs
+    ordered by radix sort with ties settled by full comparison, links taken from the graph, FASTA / DOT / GFA1 / GFA2 records
+    sized, scanned and written in place — must be the host writer's bytes and the oracle's.  Forced on small, error-rich,
+    low-coverage inputs (hundreds to thousands of contigs, links, rings from plasmids)."""
+    rng = np.random.default_rng(100 + seed)
+    recs = []
+    for gi in range(25):
+        gl = int(rng.integers(3000, 9000))
+        gm = synth.random_genome(gl, 700 + 31 * seed + gi)
+        cov = float(np.exp(rng.normal(np.log(10.0), 0.8)))
+        codes, quals = synth.sample_reads(gm, max(1, int(gl * cov / 150)), 150, 800 + 31 * seed + gi, err=err, circular=bool(gi % 4 == 0))
+        recs.extend(synth.to_fastq(codes, quals).decode().split("@r")[1:])
+    fq = ("@r" + "@r".join(recs)).encode()
+    host = product(fq, k=k, min_count=1, min_qual=0)
+    dev = _with_env({"SHK_DEVICE_WRITER_MIN": 1}, lambda: product(fq, k=k, min_count=1, min_qual=0))
+    assert "device_writer_kernels" in dev.timings() and "device_writer_kernels" not in host.timings()
+    j = json.loads(dev.get_assembly())
+    assert j["ncontigs"] > 100 and (k > 31 or j["outgfa"].count("\nL\t") > 10)
+    assert dev.get_assembly() == host.get_assembly()
+    o = run_oracle([fq], k=k, min_count=1, min_qual=0)
+    o.assemble()
+    assert dev.get_assembly() == o.assembly_json()
