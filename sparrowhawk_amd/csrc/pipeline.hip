@@ -1273,10 +1273,12 @@ public:
         DevBuf<RingMin> ringmin;
         std::vector<HeadRec> heads;
         uint32_t seg_cap = 0;
+        unsigned int n_heads = 0;      // chains ranked (heads.size() only when they were downloaded)
+        bool heads_on_host = true;
     };
     // rings: also find the smallest k-mer of every circular chain and the strand / rotation it is spelled with (single GPU);
     // the sharded assembly settles rings across ranks itself (shard_graph.h)
-    int rank_chains(ChainState &cs, bool rings, std::string &err) {
+    int rank_chains(ChainState &cs, bool rings, std::string &err, uint32_t keep_on_device_from = 0xFFFFFFFFu) {
         const uint32_t n = (uint32_t)n_solid_;
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
@@ -1359,9 +1361,13 @@ public:
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
         times_.add("collapse_rank_device", tr.stop());
+        cs.n_heads = n_heads;
+        // (sharded assembly, and fragmented assemblies headed for the device writer: the chain records stay on the device —
+        // only their number is needed here)
+        if (!rings || n_heads >= keep_on_device_from) { heads.resize(std::min<unsigned int>(n_heads, HEADS_SPEC)); cs.heads_on_host = false; return 0; }
         heads.resize(n_heads);
-        // (sharded assembly: the chain records stay on the device — one per ~10 nodes; only their number is needed here)
-        if (rings && n_heads > HEADS_SPEC)
+        cs.heads_on_host = true;
+        if (n_heads > HEADS_SPEC)
             HIPCHK(hipMemcpy(heads.data() + HEADS_SPEC, cs.d_heads.p + HEADS_SPEC, (size_t)(n_heads - HEADS_SPEC) * sizeof(HeadRec), hipMemcpyDeviceToHost));
         return 0;
     }
@@ -1374,7 +1380,44 @@ public:
         if (n == 0) return 0;
         Graph<W> g = graph_view();
         ChainState cs;
-        if (int rc = rank_chains(cs, true, err)) return rc;
+        const uint64_t dw_min = env_u64("SHK_DEVICE_WRITER_MIN", 20000);
+        // (chains come on both strands: 2 x dw_min chain records mean at least dw_min contigs)
+        if (int rc = rank_chains(cs, true, err, json ? (uint32_t)std::min<uint64_t>(2 * dw_min, 0xFFFFFFFFull) : 0xFFFFFFFFu)) return rc;
+        if (!cs.heads_on_host) {
+            // ---- a fragmented assembly: which chains are emitted, where, and the whole get_assembly() text on the device
+            const uint32_t nh = cs.n_heads;
+            DevBuf<unsigned long long> sz, fl, off, idx; DevBuf<char> tmp; DevBuf<EmitRec> d_off2; DevBuf<WContig> d_c; DevBuf<char> d_out2;
+            if (int rc = sz.alloc((size_t)nh + 1, err)) return rc;
+            if (int rc = fl.alloc((size_t)nh + 1, err)) return rc;
+            hipLaunchKernelGGL(k_w_plan_sizes, dim3(grid_for(nh)), dim3(256), 0, stream_, cs.d_heads.p, nh, (uint32_t)k_, sz.p, fl.p);
+            HIPCHK(hipGetLastError());
+            if (int rc = scan_excl(sz, off, nh, tmp, err)) return rc;
+            if (int rc = scan_excl(fl, idx, nh, tmp, err)) return rc;
+            unsigned long long last[4] = {0, 0, 0, 0};
+            HIPCHK(hipMemcpyAsync(&last[0], sz.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(&last[1], off.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(&last[2], fl.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(&last[3], idx.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(stream_wait(stream_));
+            const uint64_t out_bytes2 = last[0] + last[1], n_emit = last[2] + last[3];
+            if (n_emit >= 0x7FFFFFF0ull) { err = "device writer: too many contigs"; return -1; }
+            if (int rc = d_off2.alloc(nh, err)) return rc;
+            if (int rc = d_c.alloc(n_emit + 1, err)) return rc;
+            if (int rc = d_out2.alloc(out_bytes2 + 16, err)) return rc;
+            HIPCHK(hipMemsetAsync(ctl_.p + 14, 0, 8, stream_));
+            hipLaunchKernelGGL(k_w_plan_fill, dim3(grid_for(nh)), dim3(256), 0, stream_, cs.d_heads.p, nh, (uint32_t)k_, off.p, idx.p, d_off2.p, d_c.p, (uint32_t *)(ctl_.p + 14));
+            EvTimer t3(stream_);
+            hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off2.p, d_out2.p);
+            HIPCHK(hipGetLastError());
+            unsigned int fl9 = 0;
+            if (int rc = read_ctl(fl9, 14, err)) return rc;
+            times_.add("collapse_emit", t3.stop());
+            if (fl9) { err = "device writer: a contig beyond 2^32 bases"; return -1; }
+            if (n_emit == 0) { if (json) *json = nullptr; return 0; }
+            if (int rc = device_write_json(g, cs, d_c, (uint32_t)n_emit, nh, d_out2.p, out_bytes2, json, json_len, err)) return rc;
+            if (n_contigs) *n_contigs = n_emit;
+            return 0;
+        }
         std::vector<HeadRec> &heads = cs.heads;
         DevBuf<EmitRec> d_off; DevBuf<char> d_out;
         // each unitig exists on both strands: keep the canonical one (decided on the device)
@@ -1396,18 +1439,6 @@ public:
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
-            if (json && emitted.size() >= env_u64("SHK_DEVICE_WRITER_MIN", 20000) && emitted.size() < 0x7FFFFFF0ull) {
-                // a fragmented assembly: order, links and text on the device (writer_gpu.h)
-                std::vector<WContig> wc(emitted.size());
-                for (size_t q = 0; q < emitted.size(); q++) {
-                    const uint32_t i = emitted[q];
-                    wc[q].off = head_off[i].off; wc[q].kc = heads[i].kc; wc[q].len = (uint32_t)(heads[i].len + (uint64_t)(k_ - 1)); wc[q].slot = i;
-                    if (heads[i].len + (uint64_t)(k_ - 1) > 0xFFFFFFFFull) { err = "device writer: a contig beyond 2^32 bases"; return -1; }
-                }
-                if (int rc = device_write_json(g, cs, wc, (uint32_t)heads.size(), d_out.p, out_bytes, json, json_len, err)) return rc;
-                if (n_contigs) *n_contigs = emitted.size();
-                return 0;
-            }
             auto tcp = std::chrono::steady_clock::now();
             HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
             HIPCHK(stream_wait(stream_));
@@ -1432,13 +1463,11 @@ public:
         HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in.p, out.p, (int)n, stream_));
         return 0;
     }
-    int device_write_json(Graph<W> &g, ChainState &cs, const std::vector<WContig> &wc, uint32_t n_slots, const char *d_text, uint64_t text_bytes,
+    int device_write_json(Graph<W> &g, ChainState &cs, DevBuf<WContig> &d_c, uint32_t nc, uint32_t n_slots, const char *d_text, uint64_t text_bytes,
                           const char **json, size_t *json_len, std::string &err) {
         typedef unsigned long long u64;
-        const uint32_t nc = (uint32_t)wc.size();
         EvTimer tw(stream_);
-        DevBuf<WContig> d_c; DevBuf<u64> keys, keys2, slen, skc; DevBuf<uint32_t> vals, vals2, rank_of_slot, rank_of_contig; DevBuf<char> tmp;
-        if (int rc = d_c.alloc(nc, err)) return rc;
+        DevBuf<u64> keys, keys2, slen, skc; DevBuf<uint32_t> vals, vals2, rank_of_slot, rank_of_contig; DevBuf<char> tmp;
         if (int rc = keys.alloc(nc, err)) return rc;
         if (int rc = keys2.alloc(nc, err)) return rc;
         if (int rc = vals.alloc(nc, err)) return rc;
@@ -1447,7 +1476,6 @@ public:
         if (int rc = rank_of_contig.alloc(nc, err)) return rc;
         if (int rc = slen.alloc(nc, err)) return rc;
         if (int rc = skc.alloc(nc, err)) return rc;
-        HIPCHK(hipMemcpyAsync(d_c.p, wc.data(), (size_t)nc * sizeof(WContig), hipMemcpyHostToDevice, stream_));
         HIPCHK(hipMemsetAsync(rank_of_slot.p, 0, ((size_t)n_slots + 1) * 4, stream_));
         // ---- order
         hipLaunchKernelGGL(k_w_keys, dim3(grid_for(nc)), dim3(256), 0, stream_, d_text, d_c.p, nc, keys.p, vals.p);
@@ -1700,7 +1728,7 @@ public:
         ChainState cs;
         int rc_chain = 0;
         if (n) rc_chain = rank_chains(cs, false, err);
-        const uint32_t n_lch = n ? (uint32_t)cs.heads.size() : 0u;
+        const uint32_t n_lch = n ? (uint32_t)cs.n_heads : 0u;
         // ---- 4. stitching: the local chains of all ranks, ranked by every rank
         EvTimer ts(stream_);
         std::vector<uint64_t> lcnt(world, 0), lbase(world + 1, 0);

@@ -75,6 +75,32 @@ template <class S> __device__ void w_g2l(S &w, unsigned long long L, uint32_t ov
     w.num(ov); w.ch('M'); w.nl();
 }
 
+// ---- which chains are emitted and where (a fragmented assembly has millions of chain records: they stay on the device) ----
+__global__ __launch_bounds__(256) void k_w_plan_sizes(const HeadRec *__restrict__ heads, uint32_t n_heads, uint32_t k,
+                                                      unsigned long long *__restrict__ sz, unsigned long long *__restrict__ fl) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_heads; i += gridDim.x * blockDim.x) {
+        const HeadRec h = heads[i];
+        sz[i] = h.emit ? h.len + (unsigned long long)(k - 1u) : 0ull;
+        fl[i] = h.emit ? 1ull : 0ull;
+    }
+}
+__global__ __launch_bounds__(256) void k_w_plan_fill(const HeadRec *__restrict__ heads, uint32_t n_heads, uint32_t k,
+                                                     const unsigned long long *__restrict__ off, const unsigned long long *__restrict__ idx,
+                                                     EmitRec *__restrict__ head_off, WContig *__restrict__ c, uint32_t *__restrict__ flags) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_heads; i += gridDim.x * blockDim.x) {
+        const HeadRec h = heads[i];
+        EmitRec e; e.off = ~0ull; e.rot = h.rot; e.len = (uint32_t)h.len;
+        if (h.emit) {
+            e.off = off[i];
+            const unsigned long long bases = h.len + (unsigned long long)(k - 1u);
+            if (bases > 0xFFFFFFFFull) flags[0] = 9;
+            WContig x; x.off = off[i]; x.kc = h.kc; x.len = (uint32_t)bases; x.slot = i;
+            c[idx[i]] = x;
+        }
+        head_off[i] = e;
+    }
+}
+
 __device__ __forceinline__ uint32_t w_code(char c) { return c == 'C' ? 1u : (c == 'G' ? 2u : (c == 'T' ? 3u : 0u)); }
 
 // ---- order: (length descending, sequence ascending) ----------------------------------------------------------------

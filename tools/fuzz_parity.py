@@ -75,6 +75,7 @@ for case in range(n_cases):
     if rng.random() < 0.3: env.update({"SHK_FASTQ_PIPELINE_MIN": "1", "SHK_FASTQ_PIECES": str(int(rng.choice([2, 3, 9])))})   # one batch parsed in pieces
     if rng.random() < 0.25: env["SHK_GP_ROWS"] = str(int(rng.choice([16, 64, 4096, 100000])))   # tiny graph partitions / partitions beyond the LDS table
     if rng.random() < 0.25: env["SHK_REGROUP_ROWS"] = str(int(rng.choice([0, 1])))   # rows moved into graph-partition order (or never)
+    if rng.random() < 0.35: env["SHK_DEVICE_WRITER_MIN"] = "1"     # the get_assembly() text made on the device (csrc/writer_gpu.h)
     if rng.random() < 0.5: env["SHK_TILE_ROWS"] = str(int(rng.choice([1, 3, 17, 64, 300, 1000, 4096])))   # collapse: many small LDS tiles
     old = {e: os.environ.get(e) for e in env}
     os.environ.update(env)
