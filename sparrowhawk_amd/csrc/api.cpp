@@ -622,12 +622,13 @@ static int shard_pack_impl(shk_handle *h, void *d_send, const uint64_t *base_rec
 }
 
 static int shard_count_impl(shk_handle *h, const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt,
-                    uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local, uint64_t *n_instances_local) {
+                    uint32_t n_owned, uint32_t n_sources, uint64_t *histo500_local, uint64_t *n_instances_local,
+                    const void *d_recv_w = nullptr /* weights of the records (deduplicated by their sources) */) {
     if (!h || !histo500_local) return SHK_E_PARAM;
     if (h->st != St::Sharding) return fail(h, SHK_E_STATE, "shard_count: call shard_partition first");
     std::string err;
     if (!h->do_bloom && h->chunk_size == 0) h->post("preprocess:bulk:sorting");
-    int rc = h->pipe->shard_count(d_recv, run_off, run_cnt, n_owned, n_sources, emit_threshold_of(h), histo500_local, err);
+    int rc = h->pipe->shard_count(d_recv, d_recv_w, run_off, run_cnt, n_owned, n_sources, emit_threshold_of(h), histo500_local, err);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
     if (n_instances_local) *n_instances_local = h->pipe->total_instances();
     return SHK_OK;
@@ -848,37 +849,79 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     }
     if (n_partitions < world) return fail(h, SHK_E_PARAM, "shard_preprocess: fewer partitions than ranks");
     const uint32_t P = n_partitions;
-    // ---- pass 1 on this rank's reads
-    std::vector<uint64_t> part((size_t)P + 1, 0);          // [P] = this rank failed
+    // ---- pass 1 on this rank's reads, then the records are deduplicated HERE, before they cross the fabric (at 100x a
+    // super-k-mer record recurs ~50 times; count_part.h: k_dedupe_partitions): distinct records + u32 weights travel.
+    // SHK_SHARD_DEDUPE: 0 = never, 1 = always, default = when the distinct records of all ranks are at most half of the raw
+    // ones (error-rich reads do not deduplicate, and their partitions need the k-mer-level repartition, which counts
+    // unweighted records).  Bloom mode counts raw records too.  The decision is taken from the gathered rows: same everywhere.
+    std::vector<uint64_t> part(2 * (size_t)P + 2, 0);      // [0,P) records to send, [P,2P) raw records, [2P] = this rank failed, [2P+1] = 0 raw / 1 auto / 2 always
     int rc_p1 = shard_partition_impl(h, d_bases, d_seg_off, n_seg, n_bases, n_reads, P, part.data());
     if (!rc_p1) rc_p1 = injected("pass1");
-    part[P] = rc_p1 ? 1u : 0u;
-    // ---- the size exchange: every rank learns what every rank holds per partition
-    std::vector<uint64_t> all_raw((size_t)world * (P + 1)), all((size_t)world * P);
-    if (int rc = comm_allgather_host_u64(c, part.data(), (size_t)P + 1, all_raw.data(), st, err)) { if (rc_p1) return rc_p1; return cfail(rc); }
-    if (rc_p1) return rc_p1;
-    for (uint32_t r = 0; r < world; r++) {
-        if (all_raw[(size_t)r * (P + 1) + P]) return peer_failed("pass 1");
-        memcpy(&all[(size_t)r * P], &all_raw[(size_t)r * (P + 1)], (size_t)P * 8);
+    if (!rc_p1) {
+        memcpy(&part[P], &part[0], (size_t)P * 8);
+        const char *dd = getenv("SHK_SHARD_DEDUPE");
+        const uint64_t mode = (dd && *dd == '0') || h->do_bloom ? 0u : ((dd && *dd == '1') ? 2u : 1u);
+        if (mode) {
+            std::vector<uint64_t> pr(part.begin(), part.begin() + P);
+            std::string e2;
+            if (int r2 = h->pipe->shard_dedupe(pr, e2)) rc_p1 = fail(h, r2 == -4 ? SHK_E_OOM : SHK_E_DEVICE, e2);
+            else memcpy(&part[0], pr.data(), (size_t)P * 8);
+        }
+        part[2 * (size_t)P + 1] = mode;
     }
+    part[2 * (size_t)P] = rc_p1 ? 1u : 0u;
+    // ---- the size exchange: every rank learns what every rank holds per partition
+    const size_t ROW = 2 * (size_t)P + 2;
+    std::vector<uint64_t> all_raw((size_t)world * ROW), all((size_t)world * P), raw_counts((size_t)world * P);
+    if (int rc = comm_allgather_host_u64(c, part.data(), ROW, all_raw.data(), st, err)) { if (rc_p1) return rc_p1; return cfail(rc); }
+    if (rc_p1) return rc_p1;
+    bool weighted = true, forced = false;
+    uint64_t sum_dd = 0, sum_raw = 0;
+    for (uint32_t r = 0; r < world; r++) {
+        const uint64_t *row = &all_raw[(size_t)r * ROW];
+        if (row[2 * (size_t)P]) return peer_failed("pass 1");
+        if (row[2 * (size_t)P + 1] == 0) weighted = false;
+        if (row[2 * (size_t)P + 1] == 2) forced = true;
+        for (uint32_t p = 0; p < P; p++) { sum_dd += row[p]; sum_raw += row[P + p]; }
+        memcpy(&raw_counts[(size_t)r * P], row + P, (size_t)P * 8);
+    }
+    if (weighted && !forced && sum_dd * 2 > sum_raw) weighted = false;
+    for (uint32_t r = 0; r < world; r++) memcpy(&all[(size_t)r * P], &all_raw[(size_t)r * ROW + (weighted ? 0 : P)], (size_t)P * 8);
+    if (!weighted) h->pipe->shard_drop_dedup();
+    h->pipe->times().add("shard_records_deduplicated_x1", weighted ? 1.0 : 0.0);
     ExchangePlan plan;
     const uint64_t rec_bytes = (uint64_t)h->pipe->rec_words() * 8u;
     uint64_t n_send = 0, n_recv = 0;
     // ---- pack (destination-major) and exchange
-    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, gk[4], gc;
+    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, send_w, recv_w, gk[4], gc;
     // (declared after the blocks, so it runs before they go back to the pool: on every way out — errors included —
     // the stream is drained first; the pool has no stream-ordering bookkeeping)
     struct DrainOnExit { void *st; ~DrainOnExit() { std::string e; (void)device_stream_sync(st, e); } } drain{st};
     {
         int rc_pack = SHK_OK;
         if (int rc = plan_exchange(all.data(), world, P, rank, plan, err)) rc_pack = cfail(rc);
+        if (!rc_pack && weighted) {
+            // (a partition's record index — and a record's multiplicity — are 32 bits wide in pass 2: the limit is on the RAW records)
+            for (uint32_t p = rank; p < P && !rc_pack; p += world) {
+                uint64_t t = 0;
+                for (uint32_t r = 0; r < world; r++) t += raw_counts[(size_t)r * P + p];
+                if (t > 0xFFFFFFF0ull) rc_pack = fail(h, SHK_E_PARAM, "a partition holds more than 2^32 records");
+            }
+        }
         if (!rc_pack) {
             for (uint32_t r = 0; r < world; r++) { n_send += plan.send_counts[r]; n_recv += plan.recv_counts[r]; }
             send.bytes = (size_t)(n_send * rec_bytes + 64); send.p = device_pool_alloc(send.bytes);
             recv.bytes = (size_t)(n_recv * rec_bytes + 64); recv.p = device_pool_alloc(recv.bytes);
-            if (!send.p || !recv.p) rc_pack = fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
+            if (weighted) {
+                send_w.bytes = (size_t)(n_send * 4 + 64); send_w.p = device_pool_alloc(send_w.bytes);
+                recv_w.bytes = (size_t)(n_recv * 4 + 64); recv_w.p = device_pool_alloc(recv_w.bytes);
+            }
+            if (!send.p || !recv.p || (weighted && (!send_w.p || !recv_w.p))) rc_pack = fail(h, SHK_E_OOM, "shard_preprocess: device memory for the record exchange");
         }
-        if (!rc_pack) rc_pack = shard_pack_impl(h, send.p, plan.base.data(), P);
+        if (!rc_pack && weighted) {
+            std::string e2;
+            if (int r2 = h->pipe->shard_pack_dedup(send.p, send_w.p, plan.base.data(), P, e2)) rc_pack = fail(h, r2 == -4 ? SHK_E_OOM : (r2 == -1 ? SHK_E_PARAM : SHK_E_DEVICE), e2);
+        } else if (!rc_pack) rc_pack = shard_pack_impl(h, send.p, plan.base.data(), P);
         if (!rc_pack) rc_pack = injected("pack");
         if (int rc = agree(rc_pack, "the packing of the records")) return rc;
     }
@@ -891,15 +934,21 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         }
         const double tx = now_ms();
         if (int rc = comm_alltoallv(c, send.p, so.data(), sb.data(), recv.p, ro.data(), rb.data(), st, err)) return cfail(rc);
+        if (weighted) {
+            // the weights: same element offsets as the records, 4 bytes each
+            for (uint32_t r = 0; r < world; r++) { so[r] = so[r] / rec_bytes * 4; sb[r] = plan.send_counts[r] * 4; ro[r] = ro[r] / rec_bytes * 4; rb[r] = plan.recv_counts[r] * 4; }
+            if (int rc = comm_alltoallv(c, send_w.p, so.data(), sb.data(), recv_w.p, ro.data(), rb.data(), st, err, 4)) return cfail(rc);
+        }
         if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
         h->pipe->times().add("shard_exchange_host_clock", now_ms() - tx);
-        h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * rec_bytes) / 1e6);
+        h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * (rec_bytes + (weighted ? 4 : 0))) / 1e6);
     }
+    if (send_w.p) { device_pool_release(send_w.p, send_w.bytes); send_w.p = nullptr; }
     device_pool_release(send.p, send.bytes); send.p = nullptr;
     // ---- pass 2 over the owned partitions, then the global histogram ([501] = ranks that failed)
     uint64_t red[SHK_HISTO_BINS + 2] = {0};
     int rc_cnt = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
-                                  &red[SHK_HISTO_BINS]);
+                                  &red[SHK_HISTO_BINS], weighted ? recv_w.p : nullptr);
     if (!rc_cnt) rc_cnt = injected("count");
     if (rc_cnt) memset(red, 0, sizeof red);
     red[SHK_HISTO_BINS + 1] = rc_cnt ? 1u : 0u;

@@ -538,7 +538,7 @@ __device__ __forceinline__ int lds_insert(KmerTable<W> &tb, CountCtlCore &ctl, c
 
 // phase A: count a whole record; false = table saturated (the caller then expands it directly)
 template <int W, typename RT>
-__device__ __forceinline__ bool rec_insert(RT &rt, CountCtlCore &ctl, const Rec<2 * W> &rec) {
+__device__ __forceinline__ bool rec_insert(RT &rt, CountCtlCore &ctl, const Rec<2 * W> &rec, uint32_t weight = 1u) {
     constexpr uint32_t SR = RT::SR;
     uint32_t h = 0x9E3779B9u;
 #pragma unroll
@@ -558,7 +558,7 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtlCore &ctl, const Rec<
             if (st == 0) {
 #pragma unroll
                 for (int o = 0; o < 2 * W; o++) rt.w[slot][o] = rec.w[o];
-                __hip_atomic_fetch_add(&rt.rst[slot], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 3
+                __hip_atomic_fetch_add(&rt.rst[slot], 1u + weight, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // 1 -> 2 + weight
                 atomicAdd(&ctl.rec_used, 1u);
                 return true;
             }
@@ -567,7 +567,7 @@ __device__ __forceinline__ bool rec_insert(RT &rt, CountCtlCore &ctl, const Rec<
         bool eq = true;
 #pragma unroll
         for (int o = 0; o < 2 * W; o++) eq = eq && rt.w[slot][o] == rec.w[o];
-        if (eq) { atomicAdd(&rt.rst[slot], 1u); return true; }
+        if (eq) { atomicAdd(&rt.rst[slot], weight); return true; }
         slot = slot + 1 == SR ? 0 : slot + 1;
         probes++;
     }
@@ -670,6 +670,10 @@ struct RunView {
     uint32_t S;            // runs per partition (<= 256)
     int k;
     uint32_t dbg;          // timing experiments only (SHK_DEBUG_P2)
+    // sharded counting with records deduplicated by their source rank (k_dedupe_partitions): the record at address
+    // 16 * (rec_base16 + i * W) stands for weights[i] identical records.  nullptr: every record counts once.
+    const uint32_t *weights = nullptr;
+    unsigned long long rec_base16 = 0;
 };
 
 // run table of the local layout recs[p][g][slice_cap]
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(256) void k_merge_runs(RunView rvw, const unsigned 
     }
 }
 
-template <int W>
+template <int W, bool WEIGHTED = false /* sharded counting: records carry multiplicities (RunView::weights) */>
 __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     RunView rvw, uint32_t n_parts, uint32_t threshold,
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
    [&]() {                                              // one partition; `return` = done with it
     const uint32_t R = ctl.pre[S_runs];
     // a k-mer count can only reach 2^32 (SPEC S4: saturating) in a partition of >= 2^32 instances = R x (<= 64 per record)
-    const bool sat = R >= (1u << 26);
+    const bool sat = R >= (1u << 26) || WEIGHTED;
     if (SHK_DBG(rvw.dbg) == 5) return;                            // timing experiment: launch + run prefix only
 
     // hand the whole partition to the k-mer-level repartition (k_ovf_scatter / k_count_buckets): report the
@@ -864,7 +868,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             uint32_t lo = 0, hi = S_runs;
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
             const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[lo] << 4) + (uint64_t)(r - ctl.pre[lo]) * RW;
-            inst += (src[RW - 1] >> 58) + 1ull;
+            unsigned long long wgt = 1ull;
+            if constexpr (WEIGHTED) wgt = rvw.weights[(ctl.roff[lo] - rvw.rec_base16) / W + (r - ctl.pre[lo])];
+            inst += ((src[RW - 1] >> 58) + 1ull) * wgt;
         }
         for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
         if (lane == 0 && inst) atomicAdd(&ctl.part_inst, inst);
@@ -907,10 +913,12 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
             run_lo = lo; run_next = ctl.pre[lo + 1];
         }
-        auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
+        auto fetch = [&](uint32_t r, Rec<RW> &rec, uint32_t &wgt) -> uint32_t {
+            wgt = 1u;
             if (r >= w_end) return 0u;
             while (r >= run_next) { run_lo++; run_next = ctl.pre[run_lo + 1]; }
             const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[run_lo] << 4) + (uint64_t)(r - ctl.pre[run_lo]) * RW;
+            if constexpr (WEIGHTED) wgt = rvw.weights[(ctl.roff[run_lo] - rvw.rec_base16) / W + (r - ctl.pre[run_lo])];
 #pragma unroll
             for (int o = 0; o < RW; o += 2) {
                 const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
@@ -952,8 +960,9 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
         Rec<RW> nxt, nxt2;
 #pragma unroll
         for (int o = 0; o < RW; o++) { nxt.w[o] = 0; nxt2.w[o] = 0; }
-        uint32_t have_nxt = fetch(w_begin + (uint32_t)lane, nxt);
-        uint32_t have_nxt2 = fetch(w_begin + 64u + (uint32_t)lane, nxt2);
+        uint32_t w_nxt, w_nxt2;
+        uint32_t have_nxt = fetch(w_begin + (uint32_t)lane, nxt, w_nxt);
+        uint32_t have_nxt2 = fetch(w_begin + 64u + (uint32_t)lane, nxt2, w_nxt2);
         if (threadIdx.x == 0) ctl.prog_den = R ? R : 1u;
         for (uint32_t r0 = w_begin; r0 < (SHK_DBG(rvw.dbg) == 6 ? w_begin : w_end); r0 += 64) {
             // the table filled up: stop early (every insert into a full table walks a long probe chain);
@@ -963,19 +972,20 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
             // one spelling per locus (pass 1 is bound by its instruction issue, this pass by latencies: done here)
             if (n && SHK_DBG(rvw.dbg) != 11) rec_canonicalise<RW>(rec.w, n, k);
-            nxt = nxt2; have_nxt = have_nxt2;
-            have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
+            const uint32_t wgt = w_nxt;
+            nxt = nxt2; have_nxt = have_nxt2; w_nxt = w_nxt2;
+            have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2, w_nxt2);
             // phase A: identical records (the same genomic run seen in many reads) are counted
             // once here and expanded once, with their multiplicity, in phase B
             if (SHK_DBG(rvw.dbg) == 4) { if (n && rec.w[0] == 0x123456789ull) ctl.overflow = 1; }   // timing experiment: fetch only
-            else if (SHK_DBG(rvw.dbg) == 2) { if (n) expand(rec, n, 1u); }
-            else if (SHK_DBG(rvw.dbg) == 7) { if (n) (void)rec_insert<W>(tb.rt, ctl, rec); }      // timing experiment: dedupe only
-            else if (n && !rec_insert<W>(tb.rt, ctl, rec)) {
+            else if (SHK_DBG(rvw.dbg) == 2) { if (n) expand(rec, n, wgt); }
+            else if (SHK_DBG(rvw.dbg) == 7) { if (n) (void)rec_insert<W>(tb.rt, ctl, rec, wgt); }      // timing experiment: dedupe only
+            else if (n && !rec_insert<W>(tb.rt, ctl, rec, wgt)) {
                 // the record table is saturated.  If that happens in the first half of the records, most of
                 // them are unique (error-rich reads): their k-mers cannot fit the k-mer table either, so the
                 // round is given up at once when the k-mer-level repartition can take over (always correct)
                 if (ovf && mod == 1 && (r0 - w_begin) * 2u < (w_end - w_begin)) ctl.overflow = 1;
-                else expand(rec, n, 1u);
+                else expand(rec, n, wgt);
             }
         }
         if (SHK_DBG(rvw.dbg) == 10) return;                          // timing experiment: phase A only, no phase B
@@ -1054,6 +1064,139 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
     if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
 }
 
+
+// ---- sharded counting: records deduplicated BEFORE they cross the fabric -----------------------------------------------
+// At 100x an isolate's super-k-mer records recur ~50 times, and they are what the shard layer exchanges (16W bytes each:
+// 6x the packed reads they were cut from).  Phase A of pass 2 — canonical spelling, record-level dedupe in LDS — therefore
+// runs on the SENDER, over every partition of its own slices: out go the distinct records of partition p (any order) at
+// out_recs[base[p] ..), their multiplicities at out_w[base[p] ..), their number at n_out[p].  base[] = exclusive prefix of
+// the raw record counts, so a partition always fits.  A record that finds the table saturated (error-rich reads) is
+// passed through with weight 1.  Persistent workgroups, partitions handed out by a work counter.
+template <int W> struct DedupeShared {
+    RecTable<W, (W == 1 ? 6144u : ((135168u / (16u * W + 6u)) & ~63u))> rt;   // 6144 / 3520 / 2496 / 1920 records
+};
+template <int W>
+__global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw, uint32_t n_parts,
+                                                                     const unsigned long long *__restrict__ base,
+                                                                     uint64_t *__restrict__ out_recs, uint32_t *__restrict__ out_w,
+                                                                     uint32_t *__restrict__ n_out, uint32_t *__restrict__ work_counter) {
+    constexpr int RW = 2 * W;
+    __shared__ DedupeShared<W> tb;
+    __shared__ CountCtl ctl;
+    __shared__ uint32_t wtot[4];
+    constexpr uint32_t SR = decltype(tb.rt)::SR;
+    const int lane = threadIdx.x & 63;
+    const int k = rvw.k;
+    const uint32_t S_runs = rvw.S;
+    uint32_t pi_next = 0;
+    for (uint32_t pi = blockIdx.x; pi < n_parts; pi = pi_next) {
+        const uint32_t p = pi;
+        uint32_t f = 0; unsigned long long addr = 0;
+        if (threadIdx.x < S_runs) { f = rvw.run_cnt[(uint64_t)p * S_runs + threadIdx.x]; addr = rvw.run_addr16[(uint64_t)p * S_runs + threadIdx.x]; }
+        uint32_t incl = f;
+        if (threadIdx.x < 256) {
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+            if (lane == 63) wtot[threadIdx.x >> 6] = incl;
+        }
+        __syncthreads();                                 // (also: the previous partition is done with ctl / the table)
+        if (threadIdx.x < 256) {
+            uint32_t off = 0;
+            for (uint32_t w = 0; w < (threadIdx.x >> 6); w++) off += wtot[w];
+            if (threadIdx.x < S_runs) { ctl.pre[threadIdx.x] = off + incl - f; ctl.roff[threadIdx.x] = addr; }
+        }
+        if (threadIdx.x == 0) {
+            ctl.pre[S_runs] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+            ctl.rec_used = 0; ctl.n_emit = 0;
+            ctl.next_pi = gridDim.x + atomicAdd(work_counter, 1u);
+        }
+        for (uint32_t s = threadIdx.x; s < SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
+        __syncthreads();
+        pi_next = ctl.next_pi;
+        const uint32_t R = ctl.pre[S_runs];
+        uint64_t *dst = out_recs + base[p] * RW;
+        uint32_t *dst_w = out_w + base[p];
+        const uint32_t per_wave = (((R + (COUNT_THREADS / 64) - 1) / (COUNT_THREADS / 64)) + 63u) & ~63u;
+        const uint32_t w_begin = min(R, (threadIdx.x >> 6) * per_wave), w_end = min(R, w_begin + per_wave);
+        uint32_t run_lo = 0, run_next = 0;
+        {
+            uint32_t lo = 0, hi = S_runs;
+            const uint32_t r = min(w_begin + (uint32_t)lane, R ? R - 1u : 0u);
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; }
+            run_lo = lo; run_next = ctl.pre[lo + 1];
+        }
+        auto fetch = [&](uint32_t r, Rec<RW> &rec) -> uint32_t {
+            if (r >= w_end) return 0u;
+            while (r >= run_next) { run_lo++; run_next = ctl.pre[run_lo + 1]; }
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[run_lo] << 4) + (uint64_t)(r - ctl.pre[run_lo]) * RW;
+#pragma unroll
+            for (int o = 0; o < RW; o += 2) {
+                const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
+                rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
+            }
+            return 1u;
+        };
+        Rec<RW> nxt, nxt2;
+#pragma unroll
+        for (int o = 0; o < RW; o++) { nxt.w[o] = 0; nxt2.w[o] = 0; }
+        uint32_t have_nxt = fetch(w_begin + (uint32_t)lane, nxt);
+        uint32_t have_nxt2 = fetch(w_begin + 64u + (uint32_t)lane, nxt2);
+        for (uint32_t r0 = w_begin; r0 < w_end; r0 += 64) {
+            Rec<RW> rec = nxt;
+            const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
+            if (n) rec_canonicalise<RW>(rec.w, n, k);
+            nxt = nxt2; have_nxt = have_nxt2;
+            have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
+            // (the table is saturated and holds no copy within a few probes: passed through, once)
+            const bool pass = n && !rec_insert<W>(tb.rt, ctl, rec);
+            const unsigned long long m = __ballot(pass);
+            if (m) {
+                uint32_t at = 0;
+                if (lane == (int)__builtin_ctzll(m)) at = atomicAdd(&ctl.n_emit, (uint32_t)__popcll(m));
+                at = __shfl(at, (int)__builtin_ctzll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (pass) { part_store_record<RW>(rec.w, dst + (uint64_t)at * RW); dst_w[at] = 1u; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t s0 = 0; s0 < SR; s0 += COUNT_THREADS) {
+            const uint32_t s = s0 + threadIdx.x;
+            const uint32_t st = s < SR ? tb.rt.rst[s] : 0u;
+            const bool have = st >= 3u;
+            const unsigned long long m = __ballot(have);
+            if (m) {
+                uint32_t at = 0;
+                if (lane == (int)__builtin_ctzll(m)) at = atomicAdd(&ctl.n_emit, (uint32_t)__popcll(m));
+                at = __shfl(at, (int)__builtin_ctzll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (have) {
+                    uint64_t r[RW];
+#pragma unroll
+                    for (int o = 0; o < RW; o++) r[o] = tb.rt.w[s][o];
+                    part_store_record<RW>(r, dst + (uint64_t)at * RW);
+                    dst_w[at] = st - 2u;
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) n_out[p] = ctl.n_emit;
+    }
+}
+
+// the deduplicated records of partition p (one contiguous run at src[src_base[p] ..)) and their weights go to their place
+// in the destination-major send buffers
+template <int RW>
+__global__ __launch_bounds__(256) void k_pack_dedup(const uint64_t *__restrict__ src, const uint32_t *__restrict__ src_w,
+                                                    const unsigned long long *__restrict__ src_base, const uint32_t *__restrict__ n_out,
+                                                    const unsigned long long *__restrict__ dst_base,
+                                                    uint64_t *__restrict__ dst, uint32_t *__restrict__ dst_w) {
+    const uint32_t p = blockIdx.x, R = n_out[p];
+    const uint64_t *sp = src + src_base[p] * RW;
+    uint64_t *dp = dst + dst_base[p] * RW;
+    for (uint32_t r = threadIdx.x; r < R; r += blockDim.x) {
+#pragma unroll
+        for (int o = 0; o < RW; o += 2)
+            *reinterpret_cast<ulonglong2 *>(dp + (uint64_t)r * RW + o) = *reinterpret_cast<const ulonglong2 *>(sp + (uint64_t)r * RW + o);
+        dst_w[dst_base[p] + r] = src_w[src_base[p] + r];
+    }
+}
 
 // k-mer-level repartition of one overflowed partition: every canonical k-mer of its records goes to
 // bucket (hash bits 12..) of the item's region; cursors live in LDS, the fills are published at the end

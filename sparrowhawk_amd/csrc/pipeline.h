@@ -71,8 +71,14 @@ public:
                                 uint32_t n_partitions, std::vector<uint64_t> &part_records, std::string &err) = 0;
     virtual uint32_t rec_words() const = 0;
     virtual int shard_pack(void *d_send, const uint64_t *base_records, uint32_t n_partitions, std::string &err) = 0;
-    virtual int shard_count(const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt, uint32_t n_owned,
-                            uint32_t n_sources, uint32_t emit_threshold, uint64_t histo[500], std::string &err) = 0;
+    // records deduplicated by their SOURCE before the exchange (count_part.h: k_dedupe_partitions): part_records in = raw
+    // counts of shard_partition, out = distinct records per partition; shard_pack_dedup then fills the send buffers
+    // (records and their u32 weights, same element offsets); shard_drop_dedup forgets them (the raw records travel instead: shard_pack)
+    virtual int shard_dedupe(std::vector<uint64_t> &part_records, std::string &err) = 0;
+    virtual int shard_pack_dedup(void *d_send, void *d_send_w, const uint64_t *base_records, uint32_t n_partitions, std::string &err) = 0;
+    virtual void shard_drop_dedup() = 0;
+    virtual int shard_count(const void *d_recv, const void *d_recv_w /* nullable: weights */, const uint64_t *run_off, const uint32_t *run_cnt,
+                            uint32_t n_owned, uint32_t n_sources, uint32_t emit_threshold, uint64_t histo[500], std::string &err) = 0;
     virtual int shard_rows(uint32_t threshold, const void **keys_soa, const void **cnt, uint64_t *n, std::string &err) = 0;
     virtual int shard_set_solid(const void *const *keys_soa, const void *cnt, uint64_t n, const uint64_t histo[500],
                                 uint64_t total_instances, std::string &err) = 0;

@@ -642,7 +642,9 @@ public:
                              uint64_t cap_hint, double &ms_out, std::string &err) {
         if (n_parts == 0) { n_rows = 0; inst_out = 0; memset(hist_out, 0, 500 * 8); ms_out = 0; return 0; }
         constexpr uint32_t S = CountShared<W>::S;
-        const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0;
+        // (weighted records — sharded counting, deduplicated by their sources — stay in k_count_partitions: the bucket path
+        // counts one per entry; a partition that does not fit is re-run by residue classes there)
+        const bool repartition = env_u64("SHK_NO_REPARTITION", 0) == 0 && rv.weights == nullptr;
         DevBuf<unsigned long long> dh;
         DevBuf<OvfRec> d_ovf; DevBuf<OvfItem> d_items; DevBuf<uint32_t> d_fill, d_list, d_maxfill, d_new; DevBuf<uint64_t> d_kmers; DevBuf<BucketRef> d_blist; DevBuf<unsigned long long> d_sumfill;
         const bool bloom = bloom_ && !bloom_off_once_;          // (do_bloom: Bloom pre-filter in the k-mer-level repartition)
@@ -667,7 +669,8 @@ public:
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
             // (persistent workgroups, one per CU: the tables take the whole LDS)
-            hipLaunchKernelGGL(k_count_partitions<W>, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
+            auto kern = rv.weights ? k_count_partitions<W, true> : k_count_partitions<W, false>;
+            hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
                                dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
                                (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
                                (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_probe / 2, n_probe / 8);
@@ -988,8 +991,58 @@ public:
         return 0;
     }
 
-    // d_recv: records received from all sources; run tables [n_owned][n_sources] on the host
-    int shard_count(const void *d_recv, const uint64_t *run_off, const uint32_t *run_cnt, uint32_t n_owned,
+    // Records deduplicated on the sender (k_dedupe_partitions): part_records comes in with the raw record counts of
+    // shard_partition and goes out with the numbers of distinct records; the records wait in dd_recs_ / dd_w_ for
+    // shard_pack_dedup (which releases the slices) or shard_drop_dedup (the raw records travel: shard_pack).
+    int shard_dedupe(std::vector<uint64_t> &part_records, std::string &err) override {
+        if (!have_parts_) return 0;
+        if (part_records.size() < pp_.P) { err = "partition count mismatch"; return -1; }
+        std::vector<unsigned long long> base(pp_.P);
+        unsigned long long n_raw = 0;
+        for (uint32_t p = 0; p < pp_.P; p++) { base[p] = n_raw; n_raw += part_records[p]; }
+        if (int rc = dd_base_.alloc(pp_.P, err)) return rc;
+        if (int rc = dd_n_.alloc(pp_.P, err)) return rc;
+        if (int rc = dd_recs_.alloc(n_raw * 2 * W + 2, err)) return rc;
+        if (int rc = dd_w_.alloc(n_raw + 2, err)) return rc;
+        HIPCHK(hipMemcpyAsync(dd_base_.p, base.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p + 12, 0, 8, stream_));
+        EvTimer t(stream_);
+        hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
+                           run_view_, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12));
+        HIPCHK(hipGetLastError());
+        t.mark();
+        std::vector<uint32_t> h(pp_.P);
+        HIPCHK(hipMemcpyAsync(h.data(), dd_n_.p, (size_t)pp_.P * 4, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(stream_wait(stream_));
+        times_.add("shard_dedupe_kernel", t.elapsed());
+        unsigned long long n_dd = 0;
+        for (uint32_t p = 0; p < pp_.P; p++) { part_records[p] = h[p]; n_dd += h[p]; }
+        times_.add("shard_dedupe_records_in_x1e-6", (double)n_raw * 1e-6);
+        times_.add("shard_dedupe_records_out_x1e-6", (double)n_dd * 1e-6);
+        have_dedup_ = true;                              // (the slices stay until the caller has decided what travels)
+        return 0;
+    }
+    void shard_drop_dedup() override { dd_recs_.release(); dd_w_.release(); dd_base_.release(); dd_n_.release(); have_dedup_ = false; }
+    int shard_pack_dedup(void *d_send, void *d_send_w, const uint64_t *base_records, uint32_t n_partitions, std::string &err) override {
+        if (!have_dedup_) return 0;
+        if (n_partitions != pp_.P) { err = "partition count mismatch"; return -1; }
+        DevBuf<unsigned long long> base;
+        if (int rc = base.alloc(pp_.P, err)) return rc;
+        HIPCHK(hipMemcpyAsync(base.p, base_records, (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
+        EvTimer t(stream_);
+        hipLaunchKernelGGL((k_pack_dedup<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, dd_recs_.p, dd_w_.p, dd_base_.p, dd_n_.p, base.p,
+                           (uint64_t *)d_send, (uint32_t *)d_send_w);
+        HIPCHK(hipGetLastError());
+        times_.add("shard_pack_kernel", t.stop());
+        HIPCHK(stream_wait(stream_));
+        shard_drop_dedup();
+        recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
+        return 0;
+    }
+
+    // d_recv: records received from all sources (d_recv_w: their weights when the sources deduplicated them, else null);
+    // run tables [n_owned][n_sources] on the host
+    int shard_count(const void *d_recv, const void *d_recv_w, const uint64_t *run_off, const uint32_t *run_cnt, uint32_t n_owned,
                     uint32_t n_sources, uint32_t emit_threshold, uint64_t histo[500], std::string &err) override {
         if (n_sources < 1 || n_sources > 256) { err = "1..256 sources"; return -1; }
         const uint64_t n_runs = (uint64_t)n_owned * n_sources;
@@ -1004,6 +1057,7 @@ public:
         shard_recv_ = d_recv;
         run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
         run_view_.S = n_sources; run_view_.k = k_; n_count_parts_ = n_owned; run_view_.dbg = 0;
+        run_view_.weights = (const uint32_t *)d_recv_w; run_view_.rec_base16 = (unsigned long long)(uintptr_t)d_recv >> 4;
         uint64_t total_recs = 0;
         for (uint32_t j = 0; j < n_owned; j++) {          // a partition's record index is 32 bits wide in pass 2
             uint64_t r = 0;
@@ -1991,6 +2045,8 @@ private:
     bool global_mode_ = env_u64("SHK_COUNT_MODE_GLOBAL", 0) != 0;
     bool bloom_ = false, bloom_off_once_ = false;
     bool have_parts_ = false;
+    bool have_dedup_ = false;                        // shard_dedupe ran: dd_* hold the distinct records of every partition
+    DevBuf<uint64_t> dd_recs_; DevBuf<uint32_t> dd_w_, dd_n_; DevBuf<unsigned long long> dd_base_;
     PartParams pp_{};
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
     DevBuf<unsigned long long> run_off_; DevBuf<uint32_t> run_cnt_;

@@ -37,7 +37,7 @@ int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes,
 // from rank s at d_recv + recv_off[s] — ONE grouped ncclSend/ncclRecv set, every xGMI link of the GPU busy at once
 // (all byte counts and offsets are multiples of 8)
 int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
-                   void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err);
+                   void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err, uint32_t elem = 8 /* 8: u64 elements, 4: u32 */);
 // rank s contributes bytes[s] bytes that end up at d_recv + off[s] on every rank (d_send: this rank's part)
 int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64_t *off, const uint64_t *bytes,
                     void *stream, std::string &err);

@@ -127,8 +127,8 @@ ShardComm *comm_create(const uint8_t id[SHARD_UNIQUE_ID_BYTES], int rank, int wo
         err = std::string("ncclCommInitRank: ") + (R.GetErrorString ? R.GetErrorString(r) : "?");
         delete c; return nullptr;
     }
-    // room for the largest small collective: world x (PART_MAX_P + 2) counts, plus this rank's contribution
-    c->stage_bytes = ((size_t)world + 1) * (16384 + 8) * 8;
+    // room for the largest small collective: world x (2 PART_MAX_P + 2) counts (raw and deduplicated records per partition), plus this rank's contribution
+    c->stage_bytes = ((size_t)world + 1) * (2 * 16384 + 8) * 8;
     if (hipMalloc(&c->stage, c->stage_bytes) != hipSuccess) {
         (void)hipGetLastError();
         err = "out of device memory (communicator staging)";
@@ -180,17 +180,19 @@ int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes,
 }
 
 int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, const uint64_t *send_bytes,
-                   void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err) {
+                   void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err, uint32_t elem) {
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (elem != 8 && elem != 4) { err = "comm_alltoallv: elements of 4 or 8 bytes"; return -1; }
     for (int p = 0; p < c->world; p++)
-        if ((send_off[p] | send_bytes[p] | recv_off[p] | recv_bytes[p]) % 8) { err = "comm_alltoallv: offsets and sizes must be multiples of 8"; return -1; }
+        if ((send_off[p] | send_bytes[p] | recv_off[p] | recv_bytes[p]) % elem) { err = "comm_alltoallv: offsets and sizes must be multiples of the element size"; return -1; }
+    const ncclDataType_t ty = elem == 8 ? ncclUint64 : ncclUint32;
     RCCLCHK(R.GroupStart());
     for (int p = 0; p < c->world; p++) {
         if (send_bytes[p])
-            RCCLCHK(R.Send((const char *)d_send + send_off[p], send_bytes[p] / 8, ncclUint64, p, c->comm, (hipStream_t)stream));
+            RCCLCHK(R.Send((const char *)d_send + send_off[p], send_bytes[p] / elem, ty, p, c->comm, (hipStream_t)stream));
         if (recv_bytes[p])
-            RCCLCHK(R.Recv((char *)d_recv + recv_off[p], recv_bytes[p] / 8, ncclUint64, p, c->comm, (hipStream_t)stream));
+            RCCLCHK(R.Recv((char *)d_recv + recv_off[p], recv_bytes[p] / elem, ty, p, c->comm, (hipStream_t)stream));
     }
     RCCLCHK(R.GroupEnd());
     return 0;

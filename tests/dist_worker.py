@@ -19,6 +19,18 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def set_dedupe(cfg, rank):
+    """cfg["dedupe"]: "0" / "1" (SHK_SHARD_DEDUPE: records deduplicated by the sender never / always), absent = the library decides;
+    a list gives every rank its own setting (the ranks must still agree on what travels)."""
+    v = cfg.get("dedupe")
+    if isinstance(v, list):
+        v = v[rank % len(v)]
+    if v is None or v == "auto":
+        os.environ.pop("SHK_SHARD_DEDUPE", None)
+    else:
+        os.environ["SHK_SHARD_DEDUPE"] = str(v)
+
+
 def main():
     mode, out_path = sys.argv[1], sys.argv[2]
     import torch
@@ -109,6 +121,7 @@ def main():
             torch.cuda.synchronize()
             h = AssemblyHelper.new(k, bool(cs.get("verbose", False)), cs["min_count"], cs["min_qual"], 0, False, bool(cs.get("do_fit", False)),
                                    bool(cs.get("no_bubble_collapse", False)), bool(cs.get("no_dead_end_removal", False)))
+            set_dedupe(cs, rank)
             try:
                 sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr, comm, n_partitions=cs.get("P") or 0)
                 h.assemble()
@@ -145,6 +158,7 @@ def main():
         d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
         torch.cuda.synchronize()
         h = AssemblyHelper.new(k, True, cfg["min_count"], cfg["min_qual"], 0, False, cfg["do_fit"], False, False)
+        set_dedupe(cfg, rank)
         if cfg.get("replicated"):                      # round 2's path: gather the solid set, every rank assembles the whole graph
             os.environ["SHK_SHARD_GRAPH"] = "0"
         inj = cfg.get("inject")                        # {"rank": r, "step": s}: that rank's local step fails (SHK_FAULT_INJECT)

@@ -230,13 +230,16 @@ def mock_rccl_library():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,k,do_fit,P,replicated", [(2, 31, False, 0, False), (3, 51, True, 64, False), (4, 31, False, 128, False),
-                                                         (3, 31, True, 0, True)])
-def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P, replicated):
+@pytest.mark.parametrize("world,k,do_fit,P,replicated,dedupe", [(2, 31, False, 0, False, "1"), (3, 51, True, 64, False, "1"), (4, 31, False, 128, False, "0"),
+                                                                (3, 31, True, 0, True, "auto"), (3, 31, False, 64, False, ["1", "0", "1"]),
+                                                                (2, 89, False, 64, False, "1")])
+def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P, replicated, dedupe):
     """shk_shard_preprocess with 2, 3 and 4 ranks on the one GPU: the library's own multi-rank code (size exchange,
     plan, pack, the pairwise exchange with its offsets, histogram all-reduce, gather of the solid rows) runs exactly
     as on a node, only the bytes travel through tests/mock_rccl instead of RCCL (which refuses two ranks on one
-    device).  Every rank must end with the oracle's bytes."""
+    device).  Every rank must end with the oracle's bytes.  dedupe: the records cross deduplicated by their sender, with
+    weights ("1"), raw ("0"), as the library decides ("auto"), or with ranks that were told different things (they must
+    still agree: raw)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_dataset, run_oracle
     g, fq = make_dataset(60000, 40, err=0.01, seed=900 + world)
@@ -246,9 +249,9 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
             fqp = os.path.join(d, "reads.fq")
             open(fqp, "wb").write(fq)
             cfgp = os.path.join(d, "cfg.json")
-            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P, "replicated": replicated}, open(cfgp, "w"))
+            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P, "replicated": replicated, "dedupe": dedupe}, open(cfgp, "w"))
             out = os.path.join(d, "res")
-            launch(world, ["rccl", out, cfgp], 29760 + world + (10 if replicated else 0), timeout=300)
+            launch(world, ["rccl", out, cfgp], 29760 + world + (10 if replicated else 0) + (20 if isinstance(dedupe, list) else 0) + (40 if k == 89 else 0), timeout=300)
             res = [json.load(open(f"{out}.{r}")) for r in range(world)]
     finally:
         os.environ.pop("SHK_RCCL_LIBRARY", None)
@@ -259,6 +262,7 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
         assert r["pre"] == o.preprocessing_json() and r["asm"] == o.assembly_json()
         assert r["total_instances"] == o.total_instances
         assert r["timings"]["shard_exchange_sent_MB"] > 0
+        assert r["timings"]["shard_records_deduplicated_x1"] == (1.0 if dedupe == "1" else 0.0 if dedupe != "auto" else r["timings"]["shard_records_deduplicated_x1"])
 
 
 @pytest.mark.gpu
@@ -320,7 +324,8 @@ def _write_cases(d, cases):
     for i, (fq, params) in enumerate(cases):
         fqp = os.path.join(d, f"reads{i}.fq")
         open(fqp, "wb").write(fq)
-        out.append(dict(params, fastq=fqp))
+        # (records deduplicated by their sender / raw / the library's choice, in turn: dist_worker.set_dedupe)
+        out.append(dict({"dedupe": ("1", "0", "auto")[i % 3]}, **dict(params, fastq=fqp)))
     cfgp = os.path.join(d, "cfg.json")
     json.dump({"cases": out}, open(cfgp, "w"))
     return cfgp
