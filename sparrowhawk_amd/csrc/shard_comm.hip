@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <algorithm>
 #include <mutex>
 #include <stdlib.h>
 #include <string.h>
@@ -166,7 +167,12 @@ int comm_allreduce_u64(ShardComm *c, void *d_buf, size_t n, void *stream, std::s
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
     if (!n) return 0;
-    RCCLCHK(R.AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
+    // (pieces of <= 256 MiB per call, as everywhere in this file: see comm_alltoallv)
+    constexpr size_t PIECE_N = (256ull << 20) / 8;
+    for (size_t o = 0; o < n; o += PIECE_N) {
+        uint64_t *at = (uint64_t *)d_buf + o;
+        RCCLCHK(R.AllReduce(at, at, std::min(PIECE_N, n - o), ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
+    }
     return 0;
 }
 
@@ -175,7 +181,20 @@ int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes,
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
     if (!bytes) return 0;
     if (bytes % 8) { err = "comm_allgather: bytes must be a multiple of 8"; return -1; }
-    RCCLCHK(R.AllGather(d_send, d_recv, bytes / 8, ncclUint64, c->comm, (hipStream_t)stream));
+    constexpr size_t PIECE = 256ull << 20;
+    if (bytes <= PIECE) {
+        RCCLCHK(R.AllGather(d_send, d_recv, bytes / 8, ncclUint64, c->comm, (hipStream_t)stream));
+        return 0;
+    }
+    // a large contribution travels as grouped broadcasts of <= 256 MiB (an all-gather cannot be cut without changing its layout)
+    RCCLCHK(R.GroupStart());
+    for (int s = 0; s < c->world; s++)
+        for (size_t o = 0; o < bytes; o += PIECE) {
+            char *dst = (char *)d_recv + (size_t)s * bytes + o;
+            RCCLCHK(R.Broadcast(s == c->rank ? (const void *)((const char *)d_send + o) : (const void *)dst, dst, std::min(PIECE, bytes - o) / 8,
+                                ncclUint64, s, c->comm, (hipStream_t)stream));
+        }
+    RCCLCHK(R.GroupEnd());
     return 0;
 }
 
@@ -187,12 +206,27 @@ int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, c
     for (int p = 0; p < c->world; p++)
         if ((send_off[p] | send_bytes[p] | recv_off[p] | recv_bytes[p]) % elem) { err = "comm_alltoallv: offsets and sizes must be multiples of the element size"; return -1; }
     const ncclDataType_t ty = elem == 8 ? ncclUint64 : ncclUint32;
+    // The part a rank keeps for itself never touches the fabric: a device copy on the same stream.  (It also has to be one: a
+    // grouped ncclSend / ncclRecv of a rank to ITSELF delivered only part of a 1.2 GB block on the GPU box — the rest of
+    // the receive buffer kept what the pool block held before; found with the configs[4] share through a one-rank
+    // communicator, round 3.)  Blocks for other ranks go out in pieces of <= 256 MiB: several sends to one peer inside a
+    // group are matched in order.
+    const int me = c->rank;
+    if (send_bytes[me] != recv_bytes[me]) { err = "comm_alltoallv: a rank's block for itself must have one size"; return -1; }
+    if (send_bytes[me] &&
+        hipMemcpyAsync((char *)d_recv + recv_off[me], (const char *)d_send + send_off[me], send_bytes[me], hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess) {
+        err = std::string("comm_alltoallv: ") + hipGetErrorString(hipGetLastError()); return -5;
+    }
+    if (c->world == 1) return 0;
+    constexpr uint64_t PIECE = 256ull << 20;
     RCCLCHK(R.GroupStart());
     for (int p = 0; p < c->world; p++) {
-        if (send_bytes[p])
-            RCCLCHK(R.Send((const char *)d_send + send_off[p], send_bytes[p] / elem, ty, p, c->comm, (hipStream_t)stream));
-        if (recv_bytes[p])
-            RCCLCHK(R.Recv((char *)d_recv + recv_off[p], recv_bytes[p] / elem, ty, p, c->comm, (hipStream_t)stream));
+        if (p == me) continue;
+        for (uint64_t o = 0; o < send_bytes[p]; o += PIECE)
+            RCCLCHK(R.Send((const char *)d_send + send_off[p] + o, std::min<uint64_t>(PIECE, send_bytes[p] - o) / elem, ty, p, c->comm, (hipStream_t)stream));
+        for (uint64_t o = 0; o < recv_bytes[p]; o += PIECE)
+            RCCLCHK(R.Recv((char *)d_recv + recv_off[p] + o, std::min<uint64_t>(PIECE, recv_bytes[p] - o) / elem, ty, p, c->comm, (hipStream_t)stream));
     }
     RCCLCHK(R.GroupEnd());
     return 0;
@@ -205,11 +239,13 @@ int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64
     for (int s = 0; s < c->world; s++)
         if ((off[s] | bytes[s]) % 4) { err = "comm_allgatherv: offsets and sizes must be multiples of 4"; return -1; }
     RCCLCHK(R.GroupStart());
-    for (int s = 0; s < c->world; s++) {
-        if (!bytes[s]) continue;
-        RCCLCHK(R.Broadcast(s == c->rank ? d_send : (const void *)((char *)d_recv + off[s]), (char *)d_recv + off[s],
-                            bytes[s] / 4, ncclUint32, s, c->comm, (hipStream_t)stream));
-    }
+    constexpr uint64_t PIECE = 256ull << 20;
+    for (int s = 0; s < c->world; s++)
+        for (uint64_t o = 0; o < bytes[s]; o += PIECE) {
+            char *dst = (char *)d_recv + off[s] + o;
+            RCCLCHK(R.Broadcast(s == c->rank ? (const void *)((const char *)d_send + o) : (const void *)dst, dst,
+                                std::min<uint64_t>(PIECE, bytes[s] - o) / 4, ncclUint32, s, c->comm, (hipStream_t)stream));
+        }
     RCCLCHK(R.GroupEnd());
     return 0;
 }

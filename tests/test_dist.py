@@ -149,6 +149,43 @@ def test_rccl_inside_the_library_world_1(k, do_fit, P):
 
 
 @pytest.mark.gpu
+def test_record_blocks_beyond_one_gibibyte_cross_intact():
+    """Round 3: a grouped ncclSend / ncclRecv of a rank to ITSELF delivered only part of a 1.2 GB block on the GPU box (the
+    rest of the receive buffer kept stale pool memory: half the k-mers lost, duplicate rows, a broken graph — found with
+    the configs[4] share).  The block a rank keeps is a device copy now and every other block travels in pieces of
+    <= 256 MiB.  Here: 5 M reads of an isolate (76 M records = 1.22 GB, sent raw) through a one-rank communicator
+    must count exactly what the plain path counts."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from sparrowhawk_amd import AssemblyHelper
+    from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+    dev = torch.device("cuda", 0)
+    d_bases, d_seg, n_reads, n_bases, _g = bench.make_reads_on_device(torch, dev, 5_000_000, 150, 150, 0xEC07)
+    assert n_reads == 5_000_000
+    h = AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
+    h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
+    h.assemble()
+    want = (h.n_distinct, h.n_solid, h.total_instances, h.get_preprocessing_info(), h.get_assembly())
+    h.free()
+    comm = LibComm(0, 1)
+    for dedupe in ("0", "1"):
+        os.environ["SHK_SHARD_DEDUPE"] = dedupe
+        try:
+            h = AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
+            sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads, comm)
+            t = h.timings()
+            assert (t["shard_exchange_sent_MB"] > 1100.0) == (dedupe == "0"), t
+            assert (h.n_distinct, h.n_solid, h.total_instances, h.get_preprocessing_info()) == want[:4]
+            h.assemble()
+            assert h.get_assembly() == want[4]
+            h.free()
+        finally:
+            os.environ.pop("SHK_SHARD_DEDUPE", None)
+    comm.free()
+
+
+@pytest.mark.gpu
 def test_rccl_inside_the_library_two_ranks():
     """Two ranks through shk_shard_preprocess.  On a one-GPU box RCCL refuses the second rank on the same
     device (duplicate GPU): the test then skips, saying so; on a box with >= 2 GPUs it compares with the oracle."""
