@@ -13,6 +13,7 @@
 // Integer/hash work only: no MFMA anywhere on this path.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <thread>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1873,13 +1874,22 @@ public:
         times_.add("shard_graph_unitigs_x1", (double)n_u);
         // ---- 5. the unitig graph on the host (identical on every rank: the records are put in the order of their first chain)
         const double t_host0 = now_ms_();
+        // (the first chains are distinct numbers below M: a table instead of a sort — a metagenome has millions of unitigs)
         std::vector<uint32_t> order(n_u);
-        for (uint32_t i = 0; i < n_u; i++) order[i] = i;
-        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return uheads[a].root < uheads[b].root; });
+        {
+            std::vector<uint32_t> slot_at((size_t)M + 1, 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < n_u; i++) {
+                if (uheads[i].root >= M || slot_at[uheads[i].root] != 0xFFFFFFFFu) { err = "sharded assembly: two unitigs with one first chain"; return -6; }
+                slot_at[uheads[i].root] = i;
+            }
+            uint32_t at = 0;
+            for (uint32_t c0 = 0; c0 < M; c0++) if (slot_at[c0] != 0xFFFFFFFFu) order[at++] = slot_at[c0];
+        }
         std::vector<uint32_t> h_uid_of_slot(n_u);
         for (uint32_t u = 0; u < n_u; u++) h_uid_of_slot[order[u]] = u;
         // first / last k-mer of every unitig: asked of the rank that holds that chain
         std::vector<EndReq> reqs;
+        reqs.reserve(world == 1 ? 2 * (size_t)n_u : 2 * (size_t)n_u / world + 1024);
         for (uint32_t u = 0; u < n_u; u++) {
             const UHead &h = uheads[order[u]];
             if (h.root >= lbase[rank] && h.root < lbase[rank + 1]) reqs.push_back(EndReq{u, 0u, (uint32_t)(h.root - lbase[rank]), 0u});
@@ -1904,11 +1914,13 @@ public:
             HIPCHK(stream_wait(stream_));
         }
         std::vector<UnitigRec> recs(n_u);
-        for (uint32_t u = 0; u < n_u; u++) {
-            const UHead &h = uheads[order[u]];
-            for (int w = 0; w < W; w++) { recs[u].first[w] = h_ends[((size_t)u * 2 + 0) * W + w]; recs[u].last[w] = h_ends[((size_t)u * 2 + 1) * W + w]; }
-            recs[u].len = h.len; recs[u].kc = h.kc; recs[u].circ = h.circ;
-        }
+        host_par_ranges(n_u, [&](size_t a, size_t b) {
+            for (size_t u = a; u < b; u++) {
+                const UHead &h = uheads[order[u]];
+                for (int w = 0; w < W; w++) { recs[u].first[w] = h_ends[(u * 2 + 0) * W + w]; recs[u].last[w] = h_ends[(u * 2 + 1) * W + w]; }
+                recs[u].len = h.len; recs[u].kc = h.kc; recs[u].circ = h.circ;
+            }
+        });
         UnitigGraphResult res;
         int rc_ug = unitig_assemble(k_, recs, tips, bubbles, res, err);
         // (the same code on the same records: it fails on every rank or on none — an agreement round is only paid where the
@@ -2023,6 +2035,16 @@ public:
         }
         times_.add("shard_assemble_host_clock", now_ms_() - t_all0);
         return 0;
+    }
+    // a loop over millions of host records (the unitigs of a metagenome) on several threads
+    template <typename F> static void host_par_ranges(size_t n, F &&fn) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const unsigned T = n < 262144 ? 1u : std::min(16u, std::max(1u, hw));
+        if (T == 1) { fn((size_t)0, n); return; }
+        std::vector<std::thread> ts;
+        for (unsigned t = 1; t < T; t++) ts.emplace_back([&fn, n, t, T] { fn(n * t / T, n * (t + 1) / T); });
+        fn((size_t)0, n / T);
+        for (auto &t : ts) t.join();
     }
     static double now_ms_() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 

@@ -22,11 +22,11 @@ for case in range(n_cases):
     glen = int(rng.integers(GLEN_LO, GLEN_HI))
     g = synth.random_genome(glen, int(rng.integers(1 << 30)))
     if rng.random() < 0.4:                                   # planted repeats -> branching graph
-        L = int(rng.integers(k + 5, 4 * k))
+        L = min(int(rng.integers(k + 5, 4 * k)), glen - 1)           # (a genome shorter than the repeat: the repeat shrinks)
         src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
         g[dst:dst + L] = g[src:src + L]
     if rng.random() < 0.2:                                   # inverted repeat / hairpin material
-        L = int(rng.integers(k, 3 * k)); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
+        L = min(int(rng.integers(k, 3 * k)), glen - 1); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
         g[dst:dst + L] = (3 - g[src:src + L])[::-1]
     rl = int(rng.choice([max(k + 3, 60), 100, 150, 250]))
     rl = max(rl, k + 1)
