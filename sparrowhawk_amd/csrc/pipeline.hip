@@ -1874,6 +1874,9 @@ public:
         times_.add("shard_graph_unitigs_x1", (double)n_u);
         // ---- 5. the unitig graph on the host (identical on every rank: the records are put in the order of their first chain)
         const double t_host0 = now_ms_();
+        const bool ug_dbg = getenv("SHK_UG_DEBUG") != nullptr;     // stage times of this host section on stderr
+        double t_lap = t_host0;
+        auto lap = [&](const char *what) { if (ug_dbg) { const double t = now_ms_(); fprintf(stderr, "[shard_assemble host] %-14s %8.1f ms\n", what, t - t_lap); t_lap = t; } };
         // (the first chains are distinct numbers below M: a table instead of a sort — a metagenome has millions of unitigs)
         std::vector<uint32_t> order(n_u);
         {
@@ -1885,6 +1888,7 @@ public:
             uint32_t at = 0;
             for (uint32_t c0 = 0; c0 < M; c0++) if (slot_at[c0] != 0xFFFFFFFFu) order[at++] = slot_at[c0];
         }
+        lap("order");
         std::vector<uint32_t> h_uid_of_slot(n_u);
         for (uint32_t u = 0; u < n_u; u++) h_uid_of_slot[order[u]] = u;
         // first / last k-mer of every unitig: asked of the rank that holds that chain
@@ -1895,6 +1899,7 @@ public:
             if (h.root >= lbase[rank] && h.root < lbase[rank + 1]) reqs.push_back(EndReq{u, 0u, (uint32_t)(h.root - lbase[rank]), 0u});
             if (h.tail >= lbase[rank] && h.tail < lbase[rank + 1]) reqs.push_back(EndReq{u, 1u, (uint32_t)(h.tail - lbase[rank]), 0u});
         }
+        lap("requests");
         DevBuf<EndReq> d_req; DevBuf<uint64_t> d_ends;
         const size_t ends_words = (size_t)n_u * 2 * W;
         if (int rc = d_req.alloc(reqs.size() + 1, err)) return rc;
@@ -1913,6 +1918,7 @@ public:
             HIPCHK(hipMemcpyAsync(h_ends.data(), d_ends.p, ends_words * 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(stream_wait(stream_));
         }
+        lap("ends");
         std::vector<UnitigRec> recs(n_u);
         host_par_ranges(n_u, [&](size_t a, size_t b) {
             for (size_t u = a; u < b; u++) {
@@ -1921,8 +1927,10 @@ public:
                 recs[u].len = h.len; recs[u].kc = h.kc; recs[u].circ = h.circ;
             }
         });
+        lap("records");
         UnitigGraphResult res;
         int rc_ug = unitig_assemble(k_, recs, tips, bubbles, res, err);
+        lap("unitig graph");
         // (the same code on the same records: it fails on every rank or on none — an agreement round is only paid where the
         // graph is large enough for one host to run out of memory alone)
         if (n_u >= (1u << 20)) { if (int rc = agree(rc_ug ? -6 : 0, "the unitig graph")) return rc; }
@@ -1983,6 +1991,7 @@ public:
             int rc_rr = unitig_resolve_rings(k_, recs, mk, res, err);
             if (rc_rr) return -6;                       // (deterministic on identical input: every rank takes the same way out)
         }
+        lap("rings");
         // layout: contig text offsets, and for every unitig record where its nodes go
         std::vector<ULayout> lay(n_u + 1);
         for (auto &L : lay) { L.off = ~0ull; L.node_off = 0; L.ring_len = 0; L.rot = 0; }
@@ -1998,6 +2007,7 @@ public:
             }
             text_bytes += ct.len_nodes + (uint64_t)(k_ - 1);
         }
+        lap("layout");
         times_.add("shard_graph_unitig_host_clock", now_ms_() - t_host0);
         // ---- 6. emission
         EvTimer te(stream_);

@@ -82,6 +82,18 @@ Rccl &rccl() {
 
 }  // namespace
 
+// One RCCL call carries at most this many bytes (default 256 MiB; SHK_COMM_PIECE_BYTES lets the tests cut small exchanges
+// into many pieces).  A multiple of 8.
+static uint64_t piece_bytes() {
+    static const uint64_t v = [] {
+        const char *e = getenv("SHK_COMM_PIECE_BYTES");
+        unsigned long long x = e && *e ? strtoull(e, nullptr, 10) : 0ull;
+        if (x < 8) x = 256ull << 20;
+        return (uint64_t)(x & ~7ull);
+    }();
+    return v;
+}
+
 struct ShardComm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
@@ -168,7 +180,7 @@ int comm_allreduce_u64(ShardComm *c, void *d_buf, size_t n, void *stream, std::s
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
     if (!n) return 0;
     // (pieces of <= 256 MiB per call, as everywhere in this file: see comm_alltoallv)
-    constexpr size_t PIECE_N = (256ull << 20) / 8;
+    const size_t PIECE_N = (size_t)piece_bytes() / 8;
     for (size_t o = 0; o < n; o += PIECE_N) {
         uint64_t *at = (uint64_t *)d_buf + o;
         RCCLCHK(R.AllReduce(at, at, std::min(PIECE_N, n - o), ncclUint64, ncclSum, c->comm, (hipStream_t)stream));
@@ -181,7 +193,7 @@ int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes,
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
     if (!bytes) return 0;
     if (bytes % 8) { err = "comm_allgather: bytes must be a multiple of 8"; return -1; }
-    constexpr size_t PIECE = 256ull << 20;
+    const size_t PIECE = (size_t)piece_bytes();
     if (bytes <= PIECE) {
         RCCLCHK(R.AllGather(d_send, d_recv, bytes / 8, ncclUint64, c->comm, (hipStream_t)stream));
         return 0;
@@ -219,7 +231,7 @@ int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, c
         err = std::string("comm_alltoallv: ") + hipGetErrorString(hipGetLastError()); return -5;
     }
     if (c->world == 1) return 0;
-    constexpr uint64_t PIECE = 256ull << 20;
+    const uint64_t PIECE = piece_bytes();
     RCCLCHK(R.GroupStart());
     for (int p = 0; p < c->world; p++) {
         if (p == me) continue;
@@ -239,7 +251,7 @@ int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64
     for (int s = 0; s < c->world; s++)
         if ((off[s] | bytes[s]) % 4) { err = "comm_allgatherv: offsets and sizes must be multiples of 4"; return -1; }
     RCCLCHK(R.GroupStart());
-    constexpr uint64_t PIECE = 256ull << 20;
+    const uint64_t PIECE = piece_bytes();
     for (int s = 0; s < c->world; s++)
         for (uint64_t o = 0; o < bytes[s]; o += PIECE) {
             char *dst = (char *)d_recv + off[s] + o;

@@ -19,6 +19,12 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def set_piece(cfg):
+    """cfg["piece"]: SHK_COMM_PIECE_BYTES — every exchange and large collective of the library cut into pieces of that size"""
+    if cfg.get("piece"):
+        os.environ["SHK_COMM_PIECE_BYTES"] = str(cfg["piece"])
+
+
 def set_dedupe(cfg, rank):
     """cfg["dedupe"]: "0" / "1" (SHK_SHARD_DEDUPE: records deduplicated by the sender never / always), absent = the library decides;
     a list gives every rank its own setting (the ranks must still agree on what travels)."""
@@ -141,6 +147,7 @@ def main():
         dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
         torch.cuda.set_device(dev)
         cfg = json.load(open(sys.argv[3]))
+        set_piece(cfg)
         fq = open(cfg["fastq"], "rb").read()
         k = cfg["k"]
         try:

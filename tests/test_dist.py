@@ -269,7 +269,8 @@ def mock_rccl_library():
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,k,do_fit,P,replicated,dedupe", [(2, 31, False, 0, False, "1"), (3, 51, True, 64, False, "1"), (4, 31, False, 128, False, "0"),
                                                                 (3, 31, True, 0, True, "auto"), (3, 31, False, 64, False, ["1", "0", "1"]),
-                                                                (2, 89, False, 64, False, "1")])
+                                                                (2, 89, False, 64, False, "1"),
+                                                                (3, 31, False, 64, True, "piece"), (4, 31, False, 64, False, "piece")])
 def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_fit, P, replicated, dedupe):
     """shk_shard_preprocess with 2, 3 and 4 ranks on the one GPU: the library's own multi-rank code (size exchange,
     plan, pack, the pairwise exchange with its offsets, histogram all-reduce, gather of the solid rows) runs exactly
@@ -280,15 +281,18 @@ def test_shard_preprocess_several_ranks_over_a_stand_in_transport(world, k, do_f
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_dataset, run_oracle
     g, fq = make_dataset(60000, 40, err=0.01, seed=900 + world)
+    piece = 0
+    if dedupe == "piece":                                   # every exchange / gather of the library in pieces of 4 KiB (production: 256 MiB)
+        piece, dedupe = 4096, "0"
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     try:
         with tempfile.TemporaryDirectory() as d:
             fqp = os.path.join(d, "reads.fq")
             open(fqp, "wb").write(fq)
             cfgp = os.path.join(d, "cfg.json")
-            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P, "replicated": replicated, "dedupe": dedupe}, open(cfgp, "w"))
+            json.dump({"fastq": fqp, "k": k, "min_count": 3, "min_qual": 20, "do_fit": do_fit, "P": P, "replicated": replicated, "dedupe": dedupe, "piece": piece}, open(cfgp, "w"))
             out = os.path.join(d, "res")
-            launch(world, ["rccl", out, cfgp], 29760 + world + (10 if replicated else 0) + (20 if isinstance(dedupe, list) else 0) + (40 if k == 89 else 0), timeout=300)
+            launch(world, ["rccl", out, cfgp], 29760 + world + (10 if replicated else 0) + (20 if isinstance(dedupe, list) else 0) + (40 if k == 89 else 0) + (60 if piece else 0), timeout=300)
             res = [json.load(open(f"{out}.{r}")) for r in range(world)]
     finally:
         os.environ.pop("SHK_RCCL_LIBRARY", None)
