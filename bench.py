@@ -352,15 +352,21 @@ def main():
         d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
             torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
 
+    call_times = {} if os.environ.get("BENCH_CALL_TIMES") else None     # host time per C call, printed to stderr at the end
+
     def one_step(keep=False):
+        c0 = time.perf_counter()
         h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+        c1 = time.perf_counter()
         if sharded and args.collectives == "torch":
             sharded_preprocess(h, d_bases, d_seg, n_reads, n_bases, n_reads, comm)
         elif sharded:
             sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads, comm)
         else:
             h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
+        c2 = time.perf_counter()
         h.assemble()
+        c3 = time.perf_counter()
         # the JSON (contigs as FASTA/GFA/DOT) is on the host now; take the pointer without making
         # a Python copy of ~15 MB inside the timed region (copied once, after timing, for checking)
         ptr = raw_get_assembly(h._h)
@@ -368,7 +374,12 @@ def main():
         out = ctypes.string_at(ptr) if keep else None
         t = h.timings()
         info = (h.n_solid, h.n_distinct)
+        c4 = time.perf_counter()
         h.free()
+        c5 = time.perf_counter()
+        if call_times is not None:
+            for name, dt_ in (("new", c1 - c0), ("preprocess", c2 - c1), ("assemble", c3 - c2), ("get_assembly+timings", c4 - c3), ("free", c5 - c4)):
+                call_times.setdefault(name, []).append(dt_ * 1e3)
         return out, t, info
 
     def barrier():
@@ -387,6 +398,10 @@ def main():
         all_t.append(t)
     barrier()
     dt = time.perf_counter() - t0
+    if call_times is not None:
+        print("[bench] host ms per call (median of the timed steps):",
+              {k_: round(sorted(v[args.warmup:args.warmup + args.steps])[len(v[args.warmup:args.warmup + args.steps]) // 2], 3) for k_, v in call_times.items()},
+              file=sys.stderr, flush=True)
     out, _, _ = one_step(keep=True)                      # untimed: fetch the result for checking
     # ---- comparison point (N > 1, sharded): the same ranks, every one assembling an isolate of its own — independent
     # objects, no data-path collective.  Timed the same way, reported beside `value`, never as it.
@@ -492,7 +507,11 @@ def main():
     c_ms = sum(kern_ms) / max(1, len(kern_ms))
     p_ms = sum(t.get("partition_kernel", 0.0) for t in all_t) / max(1, len(all_t))
     # the dominant kernel of the k-mer-count step (two kernels: partition, count)
-    dom, k_ms = ("k_partition", p_ms) if p_ms > c_ms else ("k_count_partitions", c_ms)
+    # (pass 2 of one- and two-word keys is three kernels since round 3 — a sample of partitions through k_count_partitions, then
+    # k_dedupe_partitions + k_count_weighted — timed together as `count_kernel`; traffic.json knows kernels, so the measured
+    # fraction is only given when the dominant one is a single kernel)
+    split_pass2 = any("count_dedupe_kernel" in t for t in all_t)
+    dom, k_ms = ("k_partition", p_ms) if p_ms > c_ms else (("pass 2 (k_count_partitions sample + k_dedupe_partitions + k_count_weighted)" if split_pass2 else "k_count_partitions"), c_ms)
     traffic, traffic_src, traffic_all = None, None, {}
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
@@ -533,7 +552,7 @@ def main():
                      "measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and k_ms > 0) else None,
                      "measured_frac_other_count_kernel": (lambda o, ms: (traffic_all[o] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                                           if (o in traffic_all and ms > 0) else None)(
-                         "k_partition" if dom == "k_count_partitions" else "k_count_partitions", p_ms if dom == "k_count_partitions" else c_ms),
+                         "k_partition" if dom != "k_partition" else "k_count_partitions", p_ms if dom != "k_partition" else c_ms) if not split_pass2 else None,
                      "achievable_peak": stream_gbs, "frac_of_achievable": (achieved / stream_gbs) if stream_gbs else None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": k_ms,
                      "count_step_ms": c_ms + p_ms,

@@ -1065,21 +1065,32 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
 }
 
 
-// ---- sharded counting: records deduplicated BEFORE they cross the fabric -----------------------------------------------
-// At 100x an isolate's super-k-mer records recur ~50 times, and they are what the shard layer exchanges (16W bytes each:
-// 6x the packed reads they were cut from).  Phase A of pass 2 — canonical spelling, record-level dedupe in LDS — therefore
-// runs on the SENDER, over every partition of its own slices: out go the distinct records of partition p (any order) at
-// out_recs[base[p] ..), their multiplicities at out_w[base[p] ..), their number at n_out[p].  base[] = exclusive prefix of
-// the raw record counts, so a partition always fits.  A record that finds the table saturated (error-rich reads) is
-// passed through with weight 1.  Persistent workgroups, partitions handed out by a work counter.
+// ---- records deduplicated in a kernel of their own ------------------------------------------------------------------
+// (1) Sharded counting: at 100x an isolate's super-k-mer records recur ~50 times, and they are what the shard layer exchanges
+// (16W bytes each: 6x the packed reads they were cut from) — phase A of pass 2 runs on the SENDER, before the fabric.
+// (2) Single GPU, one- and two-word keys: phase A and the expansion (k_count_weighted) as two kernels that need half of a
+// CU's LDS each instead of one that owns it all.
+// Out go the distinct records of partition p (sorted by length) at out_recs[base[p] ..), their multiplicities at
+// out_w[base[p] ..), their number at n_out[p]; base[] leaves every partition room for all its raw records.  A record
+// that finds the table saturated is passed through with weight 1.  Persistent workgroups over the partitions
+// [p_first, n_parts), handed out by a work counter.
+// ovf != nullptr (single GPU): reads with errors do not deduplicate and their partitions do not fit the k-mer table of
+// the counting kernel.  The partitions below p_first were counted by k_count_partitions in the same stream — the sample
+// (ovf_n[1]: tried | overflowed << 16).  If most of them overflowed, every partition here is only read for its k-mer
+// count and reported in ovf[] as "not tried" (n_out[p] = 0): the k-mer-level repartition counts it from its raw records.
+// So is a partition that ends with more distinct records than the k-mer table has room for keys (kmer_cap), or that
+// lost less than half of its records as duplicates.
 template <int W> struct DedupeShared {
-    RecTable<W, (W == 1 ? 6144u : ((135168u / (16u * W + 6u)) & ~63u))> rt;   // 6144 / 3520 / 2496 / 1920 records
+    RecTable<W, (W == 1 ? 3072u : ((69632u / (16u * W + 6u)) & ~63u))> rt;   // 3072 / 1792 / 1280 / 960 records: two workgroups share a CU's LDS
 };
 template <int W>
-__global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw, uint32_t n_parts,
+__global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partitions(   // one- and two-word keys: 8 waves per SIMD = two workgroups per CU, <= 64 VGPRs
+                                                                     RunView rvw, uint32_t p_first, uint32_t n_parts,
                                                                      const unsigned long long *__restrict__ base,
                                                                      uint64_t *__restrict__ out_recs, uint32_t *__restrict__ out_w,
-                                                                     uint32_t *__restrict__ n_out, uint32_t *__restrict__ work_counter) {
+                                                                     uint32_t *__restrict__ n_out, uint32_t *__restrict__ work_counter,
+                                                                     OvfRec *__restrict__ ovf /* nullable */, uint32_t *__restrict__ ovf_n,
+                                                                     uint32_t defer_after, uint32_t kmer_cap) {
     constexpr int RW = 2 * W;
     __shared__ DedupeShared<W> tb;
     __shared__ CountCtl ctl;
@@ -1088,9 +1099,10 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw
     const int lane = threadIdx.x & 63;
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
+    const uint32_t n_here = n_parts - p_first;
     uint32_t pi_next = 0;
-    for (uint32_t pi = blockIdx.x; pi < n_parts; pi = pi_next) {
-        const uint32_t p = pi;
+    for (uint32_t pi = blockIdx.x; pi < n_here; pi = pi_next) {
+        const uint32_t p = p_first + pi;
         uint32_t f = 0; unsigned long long addr = 0;
         if (threadIdx.x < S_runs) { f = rvw.run_cnt[(uint64_t)p * S_runs + threadIdx.x]; addr = rvw.run_addr16[(uint64_t)p * S_runs + threadIdx.x]; }
         uint32_t incl = f;
@@ -1106,13 +1118,45 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw
         }
         if (threadIdx.x == 0) {
             ctl.pre[S_runs] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
-            ctl.rec_used = 0; ctl.n_emit = 0;
+            ctl.rec_used = 0; ctl.n_emit = 0; ctl.part_inst = 0;
             ctl.next_pi = gridDim.x + atomicAdd(work_counter, 1u);
+            // (the sample's verdict is final before this kernel starts: same stream)
+            uint32_t force = 0;
+            if (ovf && defer_after) {
+                const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
+                force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
+            }
+            ctl.overflow = force;
         }
         for (uint32_t s = threadIdx.x; s < SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
         __syncthreads();
         pi_next = ctl.next_pi;
         const uint32_t R = ctl.pre[S_runs];
+        // the partition goes to the k-mer-level repartition: its k-mer instances (one more pass over its records), n_out = 0
+        auto hand_over = [&]() {
+            unsigned long long inst = 0;
+            // (every wave a contiguous share of the records, its run cursor only moves forward: one search per wave)
+            const uint32_t pw = (((R + (COUNT_THREADS / 64) - 1) / (COUNT_THREADS / 64)) + 63u) & ~63u;
+            const uint32_t wb = min(R, (threadIdx.x >> 6) * pw), we = min(R, wb + pw);
+            uint32_t lo = 0, hi = S_runs;
+            { const uint32_t r = min(wb + (uint32_t)lane, R ? R - 1u : 0u);
+              while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ctl.pre[mid] <= r) lo = mid; else hi = mid; } }
+            uint32_t nx = ctl.pre[lo + 1];
+            for (uint32_t r = wb + (uint32_t)lane; r < we; r += 64) {
+                while (r >= nx) { lo++; nx = ctl.pre[lo + 1]; }
+                const uint64_t *src = reinterpret_cast<const uint64_t *>(ctl.roff[lo] << 4) + (uint64_t)(r - ctl.pre[lo]) * RW;
+                inst += (src[RW - 1] >> 58) + 1ull;
+            }
+            for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+            if (lane == 0 && inst) atomicAdd(&ctl.part_inst, inst);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                n_out[p] = 0;
+                if (R) { const uint32_t slot = atomicAdd(ovf_n, 1u); OvfRec o; o.p = p; o.est_distinct = 0u; o.instances = ctl.part_inst; ovf[slot] = o; }
+            }
+        };
+        if (ctl.overflow) { hand_over(); continue; }              // (uniform: written before the barrier above) error-rich reads: no dedupe
         uint64_t *dst = out_recs + base[p] * RW;
         uint32_t *dst_w = out_w + base[p];
         const uint32_t per_wave = (((R + (COUNT_THREADS / 64) - 1) / (COUNT_THREADS / 64)) + 63u) & ~63u;
@@ -1143,9 +1187,10 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw
         for (uint32_t r0 = w_begin; r0 < w_end; r0 += 64) {
             Rec<RW> rec = nxt;
             const uint32_t n = have_nxt ? (uint32_t)(rec.w[RW - 1] >> 58) + 1u : 0u;
-            if (n) rec_canonicalise<RW>(rec.w, n, k);
+            if (n && SHK_DBG(rvw.dbg) != 21) rec_canonicalise<RW>(rec.w, n, k);
             nxt = nxt2; have_nxt = have_nxt2;
             have_nxt2 = fetch(r0 + 128u + (uint32_t)lane, nxt2);
+            if (SHK_DBG(rvw.dbg) == 21 || SHK_DBG(rvw.dbg) == 22) { if (n && rec.w[0] == 0x123456789ull) ctl.n_emit = 1; continue; }   // timing experiments: fetch (+ canonical spelling) only
             // (the table is saturated and holds no copy within a few probes: passed through, once)
             const bool pass = n && !rec_insert<W>(tb.rt, ctl, rec);
             const unsigned long long m = __ballot(pass);
@@ -1156,28 +1201,226 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_dedupe_partitions(RunView rvw
                 if (pass) { part_store_record<RW>(rec.w, dst + (uint64_t)at * RW); dst_w[at] = 1u; }
             }
         }
+        // the table's records leave in order of their LENGTH (counting sort in LDS): the 64 records a wave of the counting
+        // kernel expands together then have (nearly) the same number of k-mers — no lanes idling behind the longest
+        auto &rt = tb.rt;
+        if (threadIdx.x < 64) rt.nhist[threadIdx.x] = 0;
         __syncthreads();
-        for (uint32_t s0 = 0; s0 < SR; s0 += COUNT_THREADS) {
-            const uint32_t s = s0 + threadIdx.x;
-            const uint32_t st = s < SR ? tb.rt.rst[s] : 0u;
-            const bool have = st >= 3u;
-            const unsigned long long m = __ballot(have);
-            if (m) {
-                uint32_t at = 0;
-                if (lane == (int)__builtin_ctzll(m)) at = atomicAdd(&ctl.n_emit, (uint32_t)__popcll(m));
-                at = __shfl(at, (int)__builtin_ctzll(m)) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (have) {
-                    uint64_t r[RW];
+        for (uint32_t s = threadIdx.x; s < SR; s += COUNT_THREADS)
+            if (rt.rst[s] >= 3u) atomicAdd(&rt.nhist[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u);
+        __syncthreads();
+        const uint32_t n_pass = ctl.n_emit;                   // (records passed through above)
+        if (threadIdx.x < 64) {
+            const uint32_t v = rt.nhist[threadIdx.x];
+            uint32_t incl2 = v;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl2, o); if (lane >= o) incl2 += u; }
+            rt.nbase[threadIdx.x] = n_pass + incl2 - v;
+            if (threadIdx.x == 63) ctl.n_recs = n_pass + incl2;
+        }
+        __syncthreads();
+        // (fewer than half of the records were duplicates: the partition count gives a partition ~20 table sizes of k-mer
+        // instances, so reads that repeat that little bring far more distinct k-mers than the table holds)
+        if (ovf && (ctl.n_recs > kmer_cap || (R > kmer_cap / 4u && 2u * ctl.n_recs > R))) { hand_over(); continue; }   // (uniform)
+        for (uint32_t s = threadIdx.x; s < (SHK_DBG(rvw.dbg) == 23 ? 0u : SR); s += COUNT_THREADS) {     // (23: timing experiment, nothing written)
+            const uint32_t st = rt.rst[s];
+            if (st < 3u) continue;
+            const uint32_t at = atomicAdd(&rt.nbase[(uint32_t)(rt.w[s][RW - 1] >> 58)], 1u);
+            uint64_t r[RW];
 #pragma unroll
-                    for (int o = 0; o < RW; o++) r[o] = tb.rt.w[s][o];
-                    part_store_record<RW>(r, dst + (uint64_t)at * RW);
-                    dst_w[at] = st - 2u;
+            for (int o = 0; o < RW; o++) r[o] = rt.w[s][o];
+            part_store_record<RW>(r, dst + (uint64_t)at * RW);
+            dst_w[at] = st - 2u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) n_out[p] = ctl.n_recs;
+    }
+}
+
+// Pass 2 over DEDUPLICATED records (k_dedupe_partitions wrote them: distinct records of partition p at recs[base[p] ..),
+// multiplicities beside them, sorted by length): every record expanded once, every k-mer added with the record's weight.
+// Needs the k-mer table alone: TWO workgroups per CU (one-word and two-word keys), so the latencies of one — the fetch of
+// its records, the barriers, the row reservation's round trip — hide behind the inserts of the other.  k_count_partitions
+// does both steps in one workgroup that owns the whole LDS, and every latency in it is exposed (derived VALUBusy 36 %).
+// A partition whose distinct k-mers do not fit is reported in ovf[] (exact instance count, estimated distinct k-mers)
+// and counted from its RAW records by the k-mer-level repartition, exactly as k_count_partitions reports it; the same
+// in-launch sample decides when later partitions are handed over untried.
+template <int W>
+__global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighted(
+    const uint64_t *__restrict__ recs, const uint32_t *__restrict__ weights, const unsigned long long *__restrict__ base,
+    const uint32_t *__restrict__ n_recs, uint32_t p_first, uint32_t n_parts, uint32_t merge /* partitions counted together in one table (1..4) */, int k, uint32_t threshold,
+    unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
+    unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
+    unsigned long long *__restrict__ n_inst, OvfRec *__restrict__ ovf, uint32_t *__restrict__ ovf_n,
+    uint32_t *__restrict__ work_counter, uint32_t probe_groups, uint32_t defer_after, uint32_t dbg_arg /* timing experiments (ABLATE builds) */) {
+    constexpr int RW = 2 * W;
+    constexpr uint32_t S = KmerTable<W>::S;
+    const uint32_t dbg = SHK_DBG(dbg_arg);
+    __shared__ KmerTable<W> tb;
+    __shared__ CountCtlCore ctl;
+    constexpr uint32_t ELIST = W == 1 ? S : 64;         // emit list: W >= 2 reuses the state words
+    __shared__ uint16_t elist[ELIST];
+    __shared__ uint32_t whist[500];
+    __shared__ uint32_t next_g_sh, force_sh;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS) whist[b] = 0;
+    if (threadIdx.x == 0) ctl.n_inst = 0;
+    // (group g = partitions g, g + n_groups, g + 2 n_groups ... — NOT neighbours: the rows of a group leave the table mixed, and
+    // the graph and collapse kernels rely on neighbouring rows sharing the low bits of their minimiser hash (k_row_starts);
+    // partitions a multiple of n_groups apart do.  Members below p_first were counted by the sample kernel.)
+    const uint32_t n_groups = (n_parts + merge - 1) / merge;
+    // The distinct k-mers of a partition load the table to ~a quarter (the partition count is sized for the RECORD table
+    // of the dedupe and for reads with errors), and every partition costs fixed latencies — table reset, the fetch of
+    // its first records, barriers, the row reservation's round trip: `merge` neighbouring partitions are counted in one
+    // table and emitted together (their rows stay side by side).  A group that does not fit is counted partition by
+    // partition; a partition that does not fit alone goes to the k-mer-level repartition.
+    unsigned long long mine = 0;
+    // counts the records of the partitions pm[0 .. nm) into the (reset) table; true = they fitted
+    auto count_range = [&](const uint32_t (&pm)[4], uint32_t nm) -> bool {
+        uint32_t Rj[4]; unsigned long long bj[4]; uint32_t Rt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool in = (uint32_t)j < nm;
+            Rj[j] = in ? n_recs[pm[j]] : 0u; bj[j] = in ? base[pm[j]] : 0ull;
+            Rt += Rj[j];
+        }
+        auto fetch = [&](uint32_t r, Rec<RW> &rec, uint32_t &wgt) {
+            if (r < Rt) {
+                unsigned long long at = bj[0] + r;
+                uint32_t pre = Rj[0];
+#pragma unroll
+                for (int j = 1; j < 4; j++) { if (r >= pre) at = bj[j] + (r - pre); pre += Rj[j]; }
+                const uint64_t *src = recs + at * RW;
+#pragma unroll
+                for (int o = 0; o < RW; o += 2) {
+                    const ulonglong2 v2 = *reinterpret_cast<const ulonglong2 *>(src + o);
+                    rec.w[o] = v2.x; rec.w[o + 1] = v2.y;
                 }
+                wgt = weights[at];
+            }
+        };
+        Rec<RW> nxt; uint32_t w_nxt = 0;
+#pragma unroll
+        for (int o = 0; o < RW; o++) nxt.w[o] = 0;
+        fetch(threadIdx.x, nxt, w_nxt);                                  // in flight during the reset below
+        __syncthreads();                                                 // the previous table's rows are out
+        if (threadIdx.x == 0) {
+            ctl.n_used = 0; ctl.overflow = 0; ctl.n_emit = 0; ctl.wave_cursor = 0; ctl.rec_used = 0;
+            ctl.prog_num = 0; ctl.prog_den = Rt ? Rt : 1u;
+        }
+        kmer_table_reset<W>(tb, ctl);                                    // (ends with a barrier)
+        mine = 0;
+        if (dbg != 31)
+        for (uint32_t r0 = 0; r0 < Rt; r0 += COUNT_THREADS) {
+            if (ctl.overflow || ctl.n_used > (S / 10) * 9) break;
+            Rec<RW> rec = nxt; const uint32_t weight = w_nxt;
+            const uint32_t r = r0 + threadIdx.x;
+            fetch(r + COUNT_THREADS, nxt, w_nxt);
+            if (r >= Rt) continue;
+            const uint32_t n = (uint32_t)(rec.w[RW - 1] >> 58) + 1u;
+            Kmer<W> f = km_zero<W>();
+            for (uint32_t s = 0; s < n; s++) {
+                if (ctl.overflow || ctl.n_used > (S / 10) * 9) break;    // the round is lost: do not walk full-table probe chains
+                if (s) {
+#pragma unroll
+                    for (int o = 0; o < RW - 1; o++) rec.w[o] = (rec.w[o] >> 2) | (rec.w[o + 1] << 62);
+                    rec.w[RW - 1] >>= 2;
+                }
+                Kmer<W> rv;
+#pragma unroll
+                for (int j = 0; j < W; j++) rv.w[j] = ~rec.w[j];
+                rv.w[W - 1] &= km_topmask<W>(k);
+                if (s) km_push_back<W>(f, (uint32_t)(rec.w[W - 1] >> ((2 * (k - 1)) & 63)) & 3u, k);
+                else f = km_revcomp<W>(rv, k);
+                const bool use_r = km_less<W>(rv, f);
+                Kmer<W> c;
+#pragma unroll
+                for (int j = 0; j < W; j++) c.w[j] = use_r ? rv.w[j] : f.w[j];
+                const uint32_t h = km_mix32<W>(c);
+                if (dbg == 33) { if (h == 0x12345u && c.w[0] == 77ull) ctl.overflow = 1; }       // timing experiment: roll + hash, no insert
+                else if (!lds_insert<W>(tb, ctl, c, h ^ __builtin_amdgcn_alignbit(h, h, 19), weight, true)) ctl.overflow = 1;
+                mine += weight;
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) n_out[p] = ctl.n_emit;
+        return !(ctl.overflow != 0 || ctl.n_used > (S / 10) * 9);
+    };
+    auto emit = [&]() {
+        if (dbg == 32) return;                                           // timing experiment: no emit
+        if constexpr (W == 1) table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, elist, 0u, whist);
+        else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, 0u, whist);
+    };
+    // hand partition p to the k-mer-level repartition: exact instances, estimated distinct k-mers (of the attempt just made)
+    auto defer = [&](uint32_t p, bool was_tried) {
+        const uint32_t R = n_recs[p];
+        const uint64_t *src = recs + base[p] * RW;
+        const uint32_t *src_w = weights + base[p];
+        __syncthreads();
+        if (threadIdx.x == 0) { ctl.tried = 0; ctl.part_inst = 0; }
+        __syncthreads();
+        unsigned long long m = was_tried ? mine : 0ull;
+        for (int o = 32; o > 0; o >>= 1) m += __shfl_down(m, o);
+        if (lane == 0 && m) atomicAdd(&ctl.tried, m);
+        unsigned long long inst = 0;
+        for (uint32_t r = threadIdx.x; r < R; r += COUNT_THREADS)
+            inst += ((src[(uint64_t)r * RW + RW - 1] >> 58) + 1ull) * (unsigned long long)src_w[r];
+        for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+        if (lane == 0 && inst) atomicAdd(&ctl.part_inst, inst);
+        __syncthreads();
+        if (threadIdx.x == 0 && R) {
+            const double est = ctl.tried ? (double)ctl.n_used * (double)ctl.part_inst / (double)ctl.tried : (double)ctl.part_inst;
+            const uint32_t slot = atomicAdd(ovf_n, 1u);
+            OvfRec o; o.p = p; o.est_distinct = !was_tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : est < 1.0 ? 1u : (uint32_t)est; o.instances = ctl.part_inst;
+            ovf[slot] = o;
+        }
+        if (threadIdx.x == 0 && was_tried && defer_after) atomicAdd(&ovf_n[1], 0x10001u);         // tried, and it overflowed
+    };
+    uint32_t g_next = 0;
+    for (uint32_t g = blockIdx.x; g < n_groups; g = g_next) {
+        uint32_t pm[4] = {0, 0, 0, 0}, nm = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            const uint32_t pj = g + j * n_groups;
+            const bool v = j < merge && pj < n_parts && pj >= p_first;
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) if (v && nm == q) pm[q] = pj;             // (register array: selects, no dynamic indexing)
+            nm += v ? 1u : 0u;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            next_g_sh = gridDim.x + atomicAdd(work_counter, 1u);
+            uint32_t force = 0;
+            if (defer_after && g >= probe_groups) {      // (probe_groups = 0 when k_count_partitions counted a sample of partitions first)
+                const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
+                force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
+            }
+            force_sh = force;
+        }
+        __syncthreads();
+        g_next = next_g_sh;
+        if (nm == 0) continue;
+        if (force_sh) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) if (j < nm) defer(pm[j], false);
+            continue;
+        }
+        if (nm > 1 && count_range(pm, nm)) {
+            emit();
+            if (threadIdx.x == 0 && defer_after) atomicAdd(&ovf_n[1], nm);                        // tried, and they fitted
+            continue;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            if (j >= nm) continue;
+            const uint32_t one[4] = {pm[j], 0, 0, 0};
+            if (count_range(one, 1u)) { emit(); if (threadIdx.x == 0 && defer_after) atomicAdd(&ovf_n[1], 1u); }
+            else defer(pm[j], true);
+        }
     }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < 500; b += COUNT_THREADS)
+        if (whist[b]) atomicAdd(&histo[b], (unsigned long long)whist[b]);
+    if (threadIdx.x == 0 && ctl.n_inst) atomicAdd(n_inst, ctl.n_inst);
 }
 
 // the deduplicated records of partition p (one contiguous run at src[src_base[p] ..)) and their weights go to their place

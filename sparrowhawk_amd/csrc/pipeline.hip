@@ -652,6 +652,16 @@ public:
         unsigned long long bloom_new = 0, bloom_kmer_bytes = 0, bloom_kmer_bytes_exact = 0;
         if (int rc = dh.alloc(500, err)) return rc;
         if (repartition) if (int rc = d_ovf.alloc(n_parts, err)) return rc;
+        // Two-kernel pass 2 (default for local reads): k_dedupe_partitions writes every partition's DISTINCT records with
+        // their multiplicities (sorted by length), k_count_weighted expands them — each needs half of a CU's LDS, so two
+        // workgroups per CU hide each other's latencies (the fused k_count_partitions owns the whole LDS: 0.87 ms on the
+        // bench workload).  SHK_COUNT_SPLIT=0 keeps the fused kernel; partitions that do not fit the k-mer table go to the
+        // k-mer-level repartition from their RAW records either way.
+        // (three- and four-word keys: the two kernels do not fit 64 registers and run one workgroup per CU like the fused one — no gain)
+        // (Bloom mode: reads with errors by design — the fused kernel's in-launch sample hands the partitions over sooner)
+        const bool split = W <= 2 && repartition && !bloom && rv.weights == nullptr && split_ready_ && split_base_.size() == n_parts && split_total_ > 0 &&
+                           env_u64("SHK_COUNT_SPLIT", 1) != 0;
+        struct DropSplit { Pipeline<W> *me; bool on; ~DropSplit() { if (on) me->shard_drop_dedup(); } } drop_split{this, split};
         uint64_t cap = cap_hint;
         // (exact modes: the second attempt knows the row count.  Bloom mode is not repeatable to the row — which
         // k-mers a false positive lifts over the threshold depends on the order of arrival — so its retries get slack)
@@ -662,26 +672,62 @@ public:
             HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
             HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
-            EvTimer t(stream_);
-            // The first workgroups of the launch act as a sample of the partitions.  When most of them do
-            // not fit the LDS table the reads are error-rich, and the later workgroups hand their partitions
-            // to the k-mer-level repartition at once instead of finding out one by one (that cost 6 ms of 23
-            // on configs[2] with the errors left in).  Decided on the device, inside the one launch.
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
-            // (persistent workgroups, one per CU: the tables take the whole LDS)
-            auto kern = rv.weights ? k_count_partitions<W, true> : k_count_partitions<W, false>;
-            hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
-                               dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
-                               (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
-                               (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_probe / 2, n_probe / 8);
+            // (two-kernel path: the sample is ONE round of the fused kernel — a partition per CU)
+            const uint32_t n_sample = split && n_probe ? std::min<uint32_t>(n_probe / 2, (uint32_t)n_cus_) : 0u;
+            EvTimer t_split(stream_);
+            EvTimer t(stream_);
+            if (split) {
+                // (every attempt: the partitions the dedupe hands over are reported in d_ovf / ctl_, which an attempt starts empty)
+                if (int rc = dd_base_.alloc(n_parts, err)) return rc;
+                if (int rc = dd_n_.alloc(n_parts, err)) return rc;
+                if (int rc = dd_recs_.alloc(split_total_ * 2 * W + 2, err)) return rc;
+                if (int rc = dd_w_.alloc(split_total_ + 2, err)) return rc;
+                HIPCHK(hipMemcpyAsync(dd_base_.p, split_base_.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_));
+                // The first n_probe partitions are counted by the fused kernel: they are the sample.  Its tallies (tried /
+                // overflowed) tell the two kernels behind it — same stream, no host round trip — whether the reads are
+                // error-rich; then the dedupe only reads its partitions for their k-mer counts and hands them over.
+                if (n_sample) {
+                    hipLaunchKernelGGL((k_count_partitions<W, false>), dim3(n_sample), dim3(COUNT_THREADS), 0, stream_, rv, n_sample, threshold,
+                                       dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
+                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, d_ovf.p,
+                                       (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_sample, n_probe / 8);
+                    HIPCHK(hipGetLastError());
+                }
+                EvTimer t_a(stream_);
+                hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(n_parts - n_sample, 2u * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
+                                   rv, n_sample, n_parts, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
+                                   d_ovf.p, (uint32_t *)(ctl_.p + 3), n_sample ? n_probe / 8 : 0u, (S / 10) * 9);
+                HIPCHK(hipGetLastError());
+                if (attempt == 0) t_a.stop_later("count_dedupe_kernel", pending_timers_);
+                const uint32_t per_cu = 2u;
+                // (groups of `merge` partitions share a table; a group is only worth it when the chip still gets >= 2 groups per workgroup)
+                // (1, 2 or 4, and the groups' stride a multiple of 256: the members of a group share the low bits of their number)
+                uint32_t merge = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_COUNT_MERGE", 2), 1), 4);
+                if (merge == 3) merge = 2;
+                while (merge > 1 && (n_parts % merge != 0 || (n_parts / merge) % 256u != 0 || n_parts / merge < 2u * per_cu * (uint32_t)n_cus_)) merge >>= 1;
+                const uint32_t n_groups = (n_parts + merge - 1) / merge;
+                hipLaunchKernelGGL(k_count_weighted<W>, dim3(std::min<uint32_t>(n_groups, per_cu * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
+                                   dd_recs_.p, dd_w_.p, dd_base_.p, dd_n_.p, n_sample, n_parts, merge, rv.k, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                                   ctl_.p + 0, ctl_.p + 1, d_ovf.p, (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 14), n_sample ? 0u : 0xFFFFFFFFu, n_sample ? n_probe / 8 : 0u,
+                                   env_dbg("SHK_DEBUG_P2"));
+            } else {
+                // (persistent workgroups, one per CU: the tables take the whole LDS)
+                auto kern = rv.weights ? k_count_partitions<W, true> : k_count_partitions<W, false>;
+                hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(n_parts, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_, rv, n_parts, threshold,
+                                   dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
+                                   (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, repartition ? d_ovf.p : (OvfRec *)nullptr,
+                                   (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_probe / 2, n_probe / 8);
+            }
             HIPCHK(hipGetLastError());
             t.mark();
+            if (split) t_split.mark();
             unsigned long long h[4];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));   // (final unless partitions overflowed)
             HIPCHK(stream_wait(stream_));          // one host round trip: counters, histogram and the timer
-            ms_out = t.elapsed();
+            ms_out = split ? t_split.elapsed() : t.elapsed();      // (dedupe + count)
             const uint32_t n_ovf = (uint32_t)h[3];
             // rows written by the bucket path are ordered by key hash, not grouped by minimiser partition (build_graph regroups)
             rows_scattered_ = (uint64_t)n_ovf * 4u > n_parts;
@@ -831,8 +877,22 @@ public:
             if (have_parts_) {
                 const uint64_t inst_ub_rows = total_rows_hint();
                 double ms = 0; uint64_t inst = 0;
+                // where k_dedupe_partitions may put the distinct records of partition p (two-kernel pass 2): at the place
+                // of p's own raw records — the slice region of p, or the sum of the batches' shares
+                split_base_.assign(n_count_parts_, 0); split_total_ = 0;
+                if (batches_.empty()) {
+                    for (uint32_t p = 0; p < n_count_parts_; p++) split_base_[p] = (unsigned long long)p * pp_.G * pp_.slice_cap;
+                    split_total_ = (unsigned long long)n_count_parts_ * pp_.G * pp_.slice_cap;
+                } else {
+                    for (uint32_t p = 0; p < n_count_parts_; p++) {
+                        split_base_[p] = split_total_;
+                        for (auto &b : batches_) split_total_ += b->part_off[p + 1] - b->part_off[p];
+                    }
+                }
+                split_ready_ = true;
                 if (int rc = run_count_partitions(run_view_, n_count_parts_, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
-                                                  inst_ub_rows, ms, err)) return rc;
+                                                  inst_ub_rows, ms, err)) { split_ready_ = false; return rc; }
+                split_ready_ = false;
                 times_.add("count_kernel", ms);
                 total_instances_ = inst;
             }
@@ -1009,7 +1069,8 @@ public:
         HIPCHK(hipMemsetAsync(ctl_.p + 12, 0, 8, stream_));
         EvTimer t(stream_);
         hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
-                           run_view_, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12));
+                           run_view_, 0u, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
+                           (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
         HIPCHK(hipGetLastError());
         t.mark();
         std::vector<uint32_t> h(pp_.P);
@@ -2078,6 +2139,8 @@ private:
     bool bloom_ = false, bloom_off_once_ = false;
     bool have_parts_ = false;
     bool have_dedup_ = false;                        // shard_dedupe ran: dd_* hold the distinct records of every partition
+    bool split_ready_ = false;                       // histogram() prepared split_base_ / split_total_ for the two-kernel pass 2
+    std::vector<unsigned long long> split_base_; unsigned long long split_total_ = 0;
     DevBuf<uint64_t> dd_recs_; DevBuf<uint32_t> dd_w_, dd_n_; DevBuf<unsigned long long> dd_base_;
     PartParams pp_{};
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
