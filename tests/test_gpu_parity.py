@@ -342,15 +342,21 @@ def _with_env(env, fn):
 
 
 def test_counting_modes_agree():
-    """The partitioned LDS counting path and the single-HBM-table path give identical tables."""
+    """The partitioned LDS counting path — pass 2 as two kernels (k_dedupe_partitions + k_count_weighted: the default for one-
+    and two-word keys), with one / two / four partitions per table, and as the fused k_count_partitions — and the
+    single-HBM-table path give identical tables."""
     g, fq = make_dataset(30000, 40, err=0.01, seed=91)
     for k in (31, 51):
         a = product(fq, k=k, min_count=0, assemble=False)
-        b = _with_env({"SHK_COUNT_MODE_GLOBAL": 1}, lambda: product(fq, k=k, min_count=0, assemble=False))
+        assert "count_dedupe_kernel" in a.timings()
         ak, ac, _ = sorted_table(*a.distinct())
-        bk, bc, _ = sorted_table(*b.distinct())
-        assert np.array_equal(ak, bk) and np.array_equal(ac, bc)
-        assert np.array_equal(a.histo(), b.histo()) and a.total_instances == b.total_instances
+        for env in ({"SHK_COUNT_MODE_GLOBAL": 1}, {"SHK_COUNT_SPLIT": 0}, {"SHK_COUNT_MERGE": 1}, {"SHK_COUNT_MERGE": 4},
+                    {"SHK_PART_P": 2048, "SHK_PROBE_PARTS": 128}, {"SHK_PART_P": 2048, "SHK_PROBE_PARTS": 128, "SHK_COUNT_SPLIT": 0}):
+            b = _with_env(env, lambda: product(fq, k=k, min_count=0, assemble=False))
+            assert ("count_dedupe_kernel" in b.timings()) == ("SHK_COUNT_SPLIT" not in env and "SHK_COUNT_MODE_GLOBAL" not in env), env
+            bk, bc, _ = sorted_table(*b.distinct())
+            assert np.array_equal(ak, bk) and np.array_equal(ac, bc), env
+            assert np.array_equal(a.histo(), b.histo()) and a.total_instances == b.total_instances, env
 
 
 @pytest.mark.parametrize("k,mode", [(31, "repartition"), (51, "repartition"), (89, "repartition"), (127, "repartition"),

@@ -77,6 +77,8 @@ for case in range(n_cases):
     if rng.random() < 0.25: env["SHK_REGROUP_ROWS"] = str(int(rng.choice([0, 1])))   # rows moved into graph-partition order (or never)
     if rng.random() < 0.35: env["SHK_DEVICE_WRITER_MIN"] = "1"     # the get_assembly() text made on the device (csrc/writer_gpu.h)
     if rng.random() < 0.6: env["SHK_SHARD_DEDUPE"] = str(int(rng.choice([0, 1, 1])))   # sharded cases: records deduplicated by the sender (weights) or raw
+    if rng.random() < 0.3: env["SHK_COUNT_SPLIT"] = "0"            # pass 2 fused (default: dedupe + weighted count as two kernels)
+    if rng.random() < 0.3: env["SHK_COUNT_MERGE"] = str(int(rng.choice([1, 4])))   # partitions per table of k_count_weighted
     if rng.random() < 0.5: env["SHK_TILE_ROWS"] = str(int(rng.choice([1, 3, 17, 64, 300, 1000, 4096])))   # collapse: many small LDS tiles
     old = {e: os.environ.get(e) for e in env}
     os.environ.update(env)
