@@ -1100,11 +1100,42 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
     const uint32_t n_here = n_parts - p_first;
+    // (the sample's verdict is final before this kernel starts: same stream)
+    __shared__ uint32_t forced_sh;
+    if (threadIdx.x == 0) {
+        uint32_t force = 0;
+        if (ovf && defer_after) {
+            const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
+            force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
+        }
+        forced_sh = force;
+    }
+    __syncthreads();
+    const bool forced = forced_sh != 0;
     uint32_t pi_next = 0;
     for (uint32_t pi = blockIdx.x; pi < n_here; pi = pi_next) {
         const uint32_t p = p_first + pi;
         uint32_t f = 0; unsigned long long addr = 0;
         if (threadIdx.x < S_runs) { f = rvw.run_cnt[(uint64_t)p * S_runs + threadIdx.x]; addr = rvw.run_addr16[(uint64_t)p * S_runs + threadIdx.x]; }
+        if (forced) {
+            // error-rich reads: no dedupe — a thread per run adds up the k-mer counts of its records, the partition is handed over
+            unsigned long long inst = 0;
+            const uint64_t *src = reinterpret_cast<const uint64_t *>(addr << 4);
+            for (uint32_t i = 0; i < f; i++) inst += (src[(uint64_t)i * RW + RW - 1] >> 58) + 1ull;
+            __syncthreads();                             // (the previous partition's report is out)
+            if (threadIdx.x == 0) { ctl.part_inst = 0; ctl.next_pi = gridDim.x + atomicAdd(work_counter, 1u); }
+            __syncthreads();
+            for (int o = 32; o > 0; o >>= 1) inst += __shfl_down(inst, o);
+            if (lane == 0 && inst) atomicAdd(&ctl.part_inst, inst);
+            __syncthreads();
+            pi_next = ctl.next_pi;
+            if (threadIdx.x == 0) {
+                n_out[p] = 0;
+                if (ctl.part_inst) { const uint32_t slot = atomicAdd(ovf_n, 1u); OvfRec o; o.p = p; o.est_distinct = 0u; o.instances = ctl.part_inst; ovf[slot] = o; }
+            }
+            continue;
+        }
         uint32_t incl = f;
         if (threadIdx.x < 256) {
             for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -1120,14 +1151,6 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
             ctl.pre[S_runs] = wtot[0] + wtot[1] + wtot[2] + wtot[3];
             ctl.rec_used = 0; ctl.n_emit = 0; ctl.part_inst = 0;
             ctl.next_pi = gridDim.x + atomicAdd(work_counter, 1u);
-            // (the sample's verdict is final before this kernel starts: same stream)
-            uint32_t force = 0;
-            if (ovf && defer_after) {
-                const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
-                force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
-            }
-            ctl.overflow = force;
         }
         for (uint32_t s = threadIdx.x; s < SR; s += COUNT_THREADS) tb.rt.rst[s] = 0;
         __syncthreads();
@@ -1156,7 +1179,6 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
                 if (R) { const uint32_t slot = atomicAdd(ovf_n, 1u); OvfRec o; o.p = p; o.est_distinct = 0u; o.instances = ctl.part_inst; ovf[slot] = o; }
             }
         };
-        if (ctl.overflow) { hand_over(); continue; }              // (uniform: written before the barrier above) error-rich reads: no dedupe
         uint64_t *dst = out_recs + base[p] * RW;
         uint32_t *dst_w = out_w + base[p];
         const uint32_t per_wave = (((R + (COUNT_THREADS / 64) - 1) / (COUNT_THREADS / 64)) + 63u) & ~63u;
