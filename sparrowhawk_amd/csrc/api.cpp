@@ -946,15 +946,22 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     if (send_w.p) { device_pool_release(send_w.p, send_w.bytes); send_w.p = nullptr; }
     device_pool_release(send.p, send.bytes); send.p = nullptr;
     // ---- pass 2 over the owned partitions, then the global histogram ([501] = ranks that failed)
-    uint64_t red[SHK_HISTO_BINS + 2] = {0};
+    // ([500] k-mer instances counted, [501] ranks that failed, [502] k-mer instances this rank's READS hold: after the
+    // all-reduce [500] must equal [502] — a record exchange that lost or duplicated data cannot pass unnoticed)
+    uint64_t red[SHK_HISTO_BINS + 3] = {0};
+    const uint64_t inst_in_reads = n_bases > n_seg * (uint64_t)(h->k - 1) ? n_bases - n_seg * (uint64_t)(h->k - 1) : 0;
     int rc_cnt = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
                                   &red[SHK_HISTO_BINS], weighted ? recv_w.p : nullptr);
     if (!rc_cnt) rc_cnt = injected("count");
     if (rc_cnt) memset(red, 0, sizeof red);
     red[SHK_HISTO_BINS + 1] = rc_cnt ? 1u : 0u;
-    if (int rc = comm_allreduce_host_u64(c, red, SHK_HISTO_BINS + 2, st, err)) { if (rc_cnt) return rc_cnt; return cfail(rc); }
+    red[SHK_HISTO_BINS + 2] = inst_in_reads;
+    if (int rc = comm_allreduce_host_u64(c, red, SHK_HISTO_BINS + 3, st, err)) { if (rc_cnt) return rc_cnt; return cfail(rc); }
     if (rc_cnt) return rc_cnt;
     if (red[SHK_HISTO_BINS + 1]) return peer_failed("pass 2");
+    if (red[SHK_HISTO_BINS] != red[SHK_HISTO_BINS + 2])
+        return fail(h, SHK_E_INTERNAL, "shard_preprocess: the ranks counted " + std::to_string(red[SHK_HISTO_BINS]) + " k-mer instances, their reads hold " +
+                                       std::to_string(red[SHK_HISTO_BINS + 2]) + ": the record exchange lost or duplicated data");
     // ---- fit / filter (identical on every rank), local solid rows
     const void *keys[4] = {nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
     uint64_t n_local = 0; uint32_t used = 0;

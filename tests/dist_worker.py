@@ -168,6 +168,8 @@ def main():
         set_dedupe(cfg, rank)
         if cfg.get("replicated"):                      # round 2's path: gather the solid set, every rank assembles the whole graph
             os.environ["SHK_SHARD_GRAPH"] = "0"
+        if cfg.get("truncate"):                        # the stand-in transport delivers only the first bytes of every received block
+            os.environ["MOCK_RCCL_TRUNCATE_BYTES"] = str(cfg["truncate"])
         inj = cfg.get("inject")                        # {"rank": r, "step": s}: that rank's local step fails (SHK_FAULT_INJECT)
         if inj and inj["rank"] == rank:
             os.environ["SHK_FAULT_INJECT"] = inj["step"]

@@ -94,7 +94,11 @@ ncclResult_t run_group(Comm *c, hipStream_t st, std::vector<Op> &ops) {
         if (o.kind == 4) {                                                   // recv from o.peer
             const Entry *e = find(o.peer, 0, c->rank, next_send);
             if (!e || e->bytes != o.bytes) { rc = ncclInvalidUsage; break; }
-            if (o.bytes && hipMemcpy(o.recv, c->data + (size_t)o.peer * OUTBOX_BYTES + e->off, o.bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
+            // MOCK_RCCL_TRUNCATE_BYTES=n: a received block delivers only its first n bytes (the rest of the buffer keeps what it
+            // held) — the fault a real library showed with blocks above 1 GiB; the tests use it to see the loss REPORTED
+            size_t deliver = o.bytes;
+            if (const char *tb = getenv("MOCK_RCCL_TRUNCATE_BYTES")) { const size_t lim = (size_t)strtoull(tb, nullptr, 10); if (lim && deliver > lim) deliver = lim; }
+            if (deliver && hipMemcpy(o.recv, c->data + (size_t)o.peer * OUTBOX_BYTES + e->off, deliver, hipMemcpyHostToDevice) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
         } else if (o.kind == 1) {                                            // all-reduce (uint64 sum)
             const size_t n = o.bytes / 8;
             acc.assign(n, 0);

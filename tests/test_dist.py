@@ -338,6 +338,33 @@ def test_a_failure_on_one_rank_ends_the_collective_call_on_every_rank(world, ste
             assert "another rank failed" in x["error"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,dedupe", [(2, "0"), (3, "1")])
+def test_a_record_exchange_that_loses_data_is_reported(world, dedupe):
+    """Round 3 found a transport that delivered only part of a large block (the rest of the receive buffer kept stale
+    bytes): counts were silently wrong.  shk_shard_preprocess now carries the k-mer instances the ranks' READS hold beside
+    the instances they COUNTED through its histogram all-reduce; here the stand-in transport truncates every received
+    block to 4 KiB — every rank must come back with that error (not hang, not hand out an assembly)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from util import make_dataset
+    g, fq = make_dataset(60000, 40, err=0.01, seed=78)
+    os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            fqp = os.path.join(d, "reads.fq")
+            open(fqp, "wb").write(fq)
+            cfgp = os.path.join(d, "cfg.json")
+            json.dump({"fastq": fqp, "k": 31, "min_count": 3, "min_qual": 20, "do_fit": False, "P": 64, "dedupe": dedupe,
+                       "truncate": 4096}, open(cfgp, "w"))
+            out = os.path.join(d, "res")
+            launch(world, ["rccl", out, cfgp], 29890 + world, timeout=180)
+            res = [json.load(open(f"{out}.{r}")) for r in range(world)]
+    finally:
+        os.environ.pop("SHK_RCCL_LIBRARY", None)
+    for r, x in enumerate(res):
+        assert "error" in x and "lost or duplicated data" in x["error"], (r, x)
+
+
 def test_a_missing_rccl_library_is_an_error_not_a_crash():
     """ADVICE r2: dlerror() clears its message when read — reading it twice handed std::string a null pointer and the
     process died instead of returning SHK_E_DEVICE.  Runs in a child (the library resolves RCCL once per process)."""
