@@ -290,4 +290,17 @@ def test_config4_metagenome_share_of_one_gpu(torch_dev):
     h.free()
     h2 = run()
     assert hashlib.sha256(h2.get_assembly().encode()).hexdigest() == sha
+    h2.free()
     print("configs[4] share: n_distinct", int(hist.sum()), "n_solid", int(hist[2:].sum()), "ncontigs", len(cs), "timings", t)
+    # the same share through the SHARDED path with a one-rank RCCL communicator (shk_shard_preprocess: 6 GB of records to
+    # itself; the collective shk_assemble: 8.4 M unitig strands through the unitig graph on the host): the same 1.5 GB of
+    # JSON.  (Round 3: this is the run that showed a transport losing part of a block above 1 GiB.)
+    from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+    comm = LibComm(0, 1)
+    h3 = AssemblyHelper.new(k, False, 2, 20, 0, False, False, False, False)
+    sharded_preprocess_rccl(h3, d.words.data_ptr(), d.seg_off.data_ptr(), d.n_seg, d.n_bases, d.n_reads, comm)
+    assert h3.total_instances == 3_000_000_000 and h3.n_distinct == int(hist.sum())
+    h3.assemble()
+    assert hashlib.sha256(h3.get_assembly().encode()).hexdigest() == sha
+    print("configs[4] share, sharded path:", {kk: round(v, 1) for kk, v in h3.timings().items() if kk.startswith("shard_") or kk.startswith("outputs_host")})
+    h3.free(); comm.free()
