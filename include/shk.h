@@ -34,7 +34,7 @@ extern "C" {
 
 #define SHK_HISTO_BINS 500 /* KmerHistogram.vue:45 */
 #define SHK_K_MIN 15
-#define SHK_K_MAX 127      /* compiled key widths: 1..4 64-bit words (SPEC S3; the UI offers 21..89) */
+#define SHK_K_MAX 255      /* compiled key widths: 1..8 64-bit words (SPEC S3; docs/src/assembly.md:13 "up until 255", the UI offers 21..89) */
 
 typedef struct shk_handle shk_handle;
 

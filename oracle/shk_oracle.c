@@ -30,9 +30,9 @@
 #include <math.h>
 #include <zlib.h>
 
-#define MAXW 4
+#define MAXW 8
 #define K_MIN 15
-#define K_MAX 127
+#define K_MAX 255
 #define QUAL_OFFSET 33          /* SPEC S2 Q1 */
 #define HISTO_BINS 500          /* SPEC S5, KmerHistogram.vue:45 */
 #define FIT_ITERS 200           /* SPEC S6 */

@@ -115,7 +115,7 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
                     int do_bloom, int do_fit, int no_bubble_collapse, int no_dead_end_removal) {
     g_new_err = 0; g_new_msg.clear();
     if ((k & 1u) == 0 || k < SHK_K_MIN || k > SHK_K_MAX) {
-        g_new_err = SHK_E_PARAM; g_new_msg = "k must be odd and within [15, 127]"; return nullptr;
+        g_new_err = SHK_E_PARAM; g_new_msg = "k must be odd and within [15, 255]"; return nullptr;
     }
     if (min_qual > 93) { g_new_err = SHK_E_PARAM; g_new_msg = "min_qual out of range"; return nullptr; }
     if (min_count >= SHK_HISTO_BINS) { g_new_err = SHK_E_PARAM; g_new_msg = "min_count out of range"; return nullptr; }
@@ -893,7 +893,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     const uint64_t rec_bytes = (uint64_t)h->pipe->rec_words() * 8u;
     uint64_t n_send = 0, n_recv = 0;
     // ---- pack (destination-major) and exchange
-    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, send_w, recv_w, gk[4], gc;
+    struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, send_w, recv_w, gk[8], gc;
     // (declared after the blocks, so it runs before they go back to the pool: on every way out — errors included —
     // the stream is drained first; the pool has no stream-ordering bookkeeping)
     struct DrainOnExit { void *st; ~DrainOnExit() { std::string e; (void)device_stream_sync(st, e); } } drain{st};
@@ -963,7 +963,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         return fail(h, SHK_E_INTERNAL, "shard_preprocess: the ranks counted " + std::to_string(red[SHK_HISTO_BINS]) + " k-mer instances, their reads hold " +
                                        std::to_string(red[SHK_HISTO_BINS + 2]) + ": the record exchange lost or duplicated data");
     // ---- fit / filter (identical on every rank), local solid rows
-    const void *keys[4] = {nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
+    const void *keys[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
     uint64_t n_local = 0; uint32_t used = 0;
     int rc_rows = shard_rows_impl(h, red, keys, &cnt, &n_local, &used);
     if (!rc_rows) rc_rows = injected("rows");
@@ -1012,7 +1012,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         if (int rc = comm_allgatherv(c, keys[j], gk[j].p, off8.data(), len8.data(), st, err)) return cfail(rc);
     if (int rc = comm_allgatherv(c, cnt, gc.p, off4.data(), len4.data(), st, err)) return cfail(rc);
     if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
-    const void *kp[4] = {gk[0].p, gk[1].p, gk[2].p, gk[3].p};
+    const void *kp[8] = {gk[0].p, gk[1].p, gk[2].p, gk[3].p, gk[4].p, gk[5].p, gk[6].p, gk[7].p};
     if (int rc = shard_set_solid_impl(h, kp, gc.p, n_total, red[SHK_HISTO_BINS])) return rc;
     h->pipe->times().add("shard_preprocess_host_clock", now_ms() - t0);
     return SHK_OK;
@@ -1116,7 +1116,7 @@ int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, u
 
 // ---- host-only self tests --------------------------------------------------------------------
 int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words, int *orient) {
-    if (!seq || !out_words || (k & 1u) == 0 || k > 127) return SHK_E_PARAM;
+    if (!seq || !out_words || (k & 1u) == 0 || k > SHK_K_MAX) return SHK_E_PARAM;
     return host_canonical(seq, k, out_words, orient) == 0 ? SHK_OK : SHK_E_PARAM;
 }
 uint64_t shk_host_nthash(const char *seq, uint32_t k) { return host_nthash(seq, k); }

@@ -291,38 +291,41 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     lap("outputs_order");
 
     // links: first k-mer of every (contig, orientation) -> id; '+' entries win over '-'.  K-mers are handled
-    // 2-bit packed (4 words hold k <= 127): a fragmented assembly has 10^4..10^7 contigs and this map is
+    // 2-bit packed (8 words hold k <= 255): a fragmented assembly has 10^4..10^7 contigs and this map is
     // the whole cost of the writer then.
+    constexpr int KW = 8;
     struct Key {
-        uint64_t w[4];
-        bool operator==(const Key &o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+        uint64_t w[KW];
+        bool operator==(const Key &o) const { for (int i = 0; i < KW; i++) if (w[i] != o.w[i]) return false; return true; }
     };
+    const int kw_used = (int)((2 * k + 63) / 64);             // words a k-mer of this k occupies: the rest stay zero
     struct KeyHash {
+        int n;
         size_t operator()(const Key &x) const {
             uint64_t h = 0x9e3779b97f4a7c15ull;
-            for (int i = 0; i < 4; i++) { h ^= x.w[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
+            for (int i = 0; i < n; i++) { h ^= x.w[i]; h *= 0xff51afd7ed558ccdull; h ^= h >> 32; }
             return (size_t)h;
         }
     };
     auto code = [](char c) -> uint64_t { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : 3; };
-    auto shl2 = [](Key &x, uint64_t b) {                       // x = x * 4 + b
-        x.w[3] = (x.w[3] << 2) | (x.w[2] >> 62); x.w[2] = (x.w[2] << 2) | (x.w[1] >> 62);
-        x.w[1] = (x.w[1] << 2) | (x.w[0] >> 62); x.w[0] = (x.w[0] << 2) | b;
+    auto shl2 = [&](Key &x, uint64_t b) {                      // x = x * 4 + b
+        for (int i = kw_used - 1; i > 0; i--) x.w[i] = (x.w[i] << 2) | (x.w[i - 1] >> 62);
+        x.w[0] = (x.w[0] << 2) | b;
     };
     auto mask_k = [&](Key &x) {                                // keep the low 2k bits
         const uint32_t used = 2 * k;
-        for (uint32_t i = 0; i < 4; i++) {
+        for (uint32_t i = 0; i < (uint32_t)KW; i++) {
             if (64 * i >= used) x.w[i] = 0;
             else if (used - 64 * i < 64) x.w[i] &= (1ull << (used - 64 * i)) - 1ull;
         }
     };
     auto pack = [&](const char *p) {                           // first base in the top 2 bits of the 2k-bit value
-        Key x{{0, 0, 0, 0}};
+        Key x{};
         for (uint32_t i = 0; i < k; i++) { const uint32_t pos = 2 * (k - 1 - i); x.w[pos >> 6] |= code(p[i]) << (pos & 63); }
         return x;
     };
     auto pack_rc = [&](const char *p) {                        // reverse complement of p[0..k)
-        Key x{{0, 0, 0, 0}};
+        Key x{};
         for (uint32_t i = 0; i < k; i++) { const uint32_t pos = 2 * i; x.w[pos >> 6] |= (3 - code(p[i])) << (pos & 63); }
         return x;
     };
@@ -334,7 +337,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     size_t cap = 16; while (cap < 4 * nc + 4) cap <<= 1;
     std::unique_ptr<std::atomic<uint64_t>[]> hv(new std::atomic<uint64_t>[cap]);
     par_ranges(cap, 1 << 16, [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) hv[i].store(~0ull, std::memory_order_relaxed); }, &wp);
-    const KeyHash hasher;
+    const KeyHash hasher{kw_used};
     auto dec_c = [](uint64_t v) { return (uint32_t)(v & ((1ull << 40) - 1)); };
     auto dec_o = [](uint64_t v) { return (uint32_t)((v >> 40) & 1); };
     auto key_of_enc = [&](uint64_t v) -> Key {

@@ -2190,6 +2190,10 @@ IPipeline *make_pipeline(int k, std::string &err) {
     else if (W == 2) { auto *q = new Pipeline<2>(k); rc = q->init(err); p = q; }
     else if (W == 3) { auto *q = new Pipeline<3>(k); rc = q->init(err); p = q; }
     else if (W == 4) { auto *q = new Pipeline<4>(k); rc = q->init(err); p = q; }
+    else if (W == 5) { auto *q = new Pipeline<5>(k); rc = q->init(err); p = q; }
+    else if (W == 6) { auto *q = new Pipeline<6>(k); rc = q->init(err); p = q; }
+    else if (W == 7) { auto *q = new Pipeline<7>(k); rc = q->init(err); p = q; }
+    else if (W == 8) { auto *q = new Pipeline<8>(k); rc = q->init(err); p = q; }
     else { err = "k too large for the compiled key widths"; return nullptr; }
     if (rc != 0) { delete p; return nullptr; }
     return p;
@@ -2274,6 +2278,10 @@ int host_canonical(const char *seq, uint32_t k, uint64_t *out, int *orient) {
     if (W == 2) return host_canon_t<2>(seq, k, out, orient);
     if (W == 3) return host_canon_t<3>(seq, k, out, orient);
     if (W == 4) return host_canon_t<4>(seq, k, out, orient);
+    if (W == 5) return host_canon_t<5>(seq, k, out, orient);
+    if (W == 6) return host_canon_t<6>(seq, k, out, orient);
+    if (W == 7) return host_canon_t<7>(seq, k, out, orient);
+    if (W == 8) return host_canon_t<8>(seq, k, out, orient);
     return -1;
 }
 uint64_t host_nthash(const char *seq, uint32_t k) {

@@ -457,6 +457,10 @@ int unitig_assemble(int k, const std::vector<UnitigRec> &recs, bool tips, bool b
         case 2: return assemble_t<2>(k, recs, tips, bubbles, out, err);
         case 3: return assemble_t<3>(k, recs, tips, bubbles, out, err);
         case 4: return assemble_t<4>(k, recs, tips, bubbles, out, err);
+        case 5: return assemble_t<5>(k, recs, tips, bubbles, out, err);
+        case 6: return assemble_t<6>(k, recs, tips, bubbles, out, err);
+        case 7: return assemble_t<7>(k, recs, tips, bubbles, out, err);
+        case 8: return assemble_t<8>(k, recs, tips, bubbles, out, err);
     }
     err = "k too large"; return -1;
 }
@@ -466,6 +470,10 @@ int unitig_resolve_rings(int k, const std::vector<UnitigRec> &recs, const std::v
         case 2: return resolve_t<2>(k, recs, min_of, out, err);
         case 3: return resolve_t<3>(k, recs, min_of, out, err);
         case 4: return resolve_t<4>(k, recs, min_of, out, err);
+        case 5: return resolve_t<5>(k, recs, min_of, out, err);
+        case 6: return resolve_t<6>(k, recs, min_of, out, err);
+        case 7: return resolve_t<7>(k, recs, min_of, out, err);
+        case 8: return resolve_t<8>(k, recs, min_of, out, err);
     }
     err = "k too large"; return -1;
 }

@@ -25,14 +25,14 @@ static constexpr uint32_t UG_NIL = 0xFFFFFFFFu;
 // a record of its own (first = revcomp(last of this one)).  K-mers: 2k-bit integers, first base most significant, in
 // W = ceil(2k/64) words, w[0] least significant (kmer.h), spelled in the orientation of the strand.
 struct UnitigRec {
-    uint64_t first[4] = {0, 0, 0, 0}, last[4] = {0, 0, 0, 0};
+    uint64_t first[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t len = 0;            // nodes
     uint64_t kc = 0;             // sum of their counts
     uint32_t circ = 0;           // the chain closes on itself: no ends, no edges to anything else
 };
 // the smallest oriented node key(x, o) = (canonical k-mer, orientation) among the nodes of a record, and where it sits
 struct UnitigMinKey {
-    uint64_t key[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    uint64_t key[8] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
     uint32_t o = 1;
     uint64_t pos = 0;            // its position in the record's chain (0 = first node)
     bool valid = false;

@@ -492,6 +492,9 @@ def test_sharded_graph_several_ranks(world):
     g, fq = make_dataset(40000, 30, err=0.005, seed=8450 + world, circular=True)       # three- and four-word keys
     cases.append((fq, dict(k=89, min_count=2, min_qual=20)))
     cases.append((fq, dict(k=127, min_count=1, min_qual=0)))
+    g, fq = make_dataset(40000, 30, read_len=400, err=0.003, seed=8460 + world, circular=True)       # six- and eight-word keys (k up to 255)
+    cases.append((fq, dict(k=161, min_count=2, min_qual=0)))
+    cases.append((fq, dict(k=255, min_count=1, min_qual=0)))
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     try:
         with tempfile.TemporaryDirectory() as d:

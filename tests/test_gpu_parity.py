@@ -40,10 +40,11 @@ def test_full_pipeline_parity(k, err, cov):
     assert out["ncontigs"] >= 1
 
 
-@pytest.mark.parametrize("k", [31, 51, 89, 127])
+@pytest.mark.parametrize("k", [31, 51, 89, 127, 129, 191, 255])
 def test_distinct_table_parity(k):
-    """Stage (a): the complete (canonical k-mer, count) table before filtering."""
-    g, fq = make_dataset(20000, 20, err=0.01, seed=40 + k)
+    """Stage (a): the complete (canonical k-mer, count) table before filtering.  (k up to 255 — docs/src/assembly.md:13 —
+    in five- to eight-word keys; reads of 400 bases there.)"""
+    g, fq = make_dataset(20000, 20, read_len=150 if k <= 127 else 400, err=0.01 if k <= 127 else 0.002, seed=40 + k)
     h = product(fq, k=k, min_count=0, min_qual=20, assemble=False)
     hk, hc, _ = sorted_table(*h.distinct())
     o = run_oracle([fq], k=k, min_count=0, min_qual=20)
@@ -57,6 +58,17 @@ def test_distinct_table_parity(k):
     for key, c in got.items():
         v = sum(key[j] << (64 * j) for j in range(W))
         assert ref[v] == c
+
+
+@pytest.mark.parametrize("k,circular", [(129, False), (161, True), (223, False), (255, True)])
+def test_wide_keys_whole_pipeline(k, circular):
+    """k = 129 ... 255 (five- to eight-word keys): counting, graph, correction, collapse and the four output formats against
+    the oracle, stage by stage; a circular replicon among them."""
+    g, fq = make_dataset(30000, 40, read_len=400, err=0.002, seed=300 + k, circular=circular)
+    for mc in (0, 3):
+        h = product(fq, k=k, min_count=mc, min_qual=0)
+        o = run_oracle([fq], k=k, min_count=mc, min_qual=0)
+        compare_all(h, o)
 
 
 def test_error_reads_with_correction_flags():

@@ -33,7 +33,7 @@ def test_version(lib):
 
 
 def test_new_rejects_bad_parameters(lib):
-    for k in (30, 13, 64, 129, 255):
+    for k in (30, 13, 64, 128, 257, 301):                   # even, or outside [15, 255] (docs/src/assembly.md:13: "up until 255")
         assert not lib.shk_new(k, 1, 5, 20, 0, 0, 0, 0, 0)
         assert lib.shk_new_error() == -1
     assert not lib.shk_new(31, 1, 1, 20, 0, 1, 0, 0, 0)       # Bloom needs min_count >= 3
@@ -81,7 +81,7 @@ def test_packer_gzip_crlf_and_errors():
     assert pack_fastq(b"", 31, 20)[2] == 0
 
 
-@pytest.mark.parametrize("k", [15, 31, 33, 51, 63, 89, 127])
+@pytest.mark.parametrize("k", [15, 31, 33, 51, 63, 89, 127, 129, 191, 255])
 def test_host_canonical_matches_python(lib, k):
     rng = np.random.default_rng(k)
     W = (2 * k + 63) // 64
@@ -245,14 +245,15 @@ def _writer_json(lib, contigs, k):
         lib.shk_host_free(p)
 
 
-@pytest.mark.parametrize("k,err,threads_forced", [(31, 0.01, False), (31, 0.01, True), (51, 0.02, True), (21, 0.03, True)])
+@pytest.mark.parametrize("k,err,threads_forced", [(31, 0.01, False), (31, 0.01, True), (51, 0.02, True), (21, 0.03, True),
+                                                  (161, 0.004, False), (255, 0.003, True)])
 def test_output_writer_equals_the_oracle_writer(lib, k, err, threads_forced, monkeypatch):
     """a13 on the CPU: the oracle's unitigs, handed to the product's writer on a random strand and in a random
     order, must come back as the oracle's JSON byte for byte — serial paths and the parallel ones (forced)."""
     from util import run_oracle
     if threads_forced:
         monkeypatch.setenv("SHK_WRITER_PAR_MIN", "1")
-    g, fq = make_dataset(30000, 14, err=err, seed=900 + k)
+    g, fq = make_dataset(30000, 14, read_len=150 if k < 128 else 400, err=err, seed=900 + k)     # (k > 127: six- / eight-word end keys in the link table)
     o = run_oracle([fq], k=k, min_count=1, min_qual=0, no_bubble_collapse=True, no_dead_end_removal=True)     # (errors stay in, the graph stays branchy)
     o.assemble()
     cs, kcs = o.contigs(), o.contig_kc()

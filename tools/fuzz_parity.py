@@ -18,7 +18,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 GLEN_LO, GLEN_HI = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (300, 30000)   # genome sizes
 t0 = time.time()
 for case in range(n_cases):
-    k = int(rng.choice([15, 21, 27, 31, 33, 41, 51, 63, 65, 77, 89, 95, 101, 127]))
+    k = int(rng.choice([15, 21, 27, 31, 33, 41, 51, 63, 65, 77, 89, 95, 101, 127, 129, 161, 191, 193, 225, 255]))   # one- to eight-word keys
     glen = int(rng.integers(GLEN_LO, GLEN_HI))
     g = synth.random_genome(glen, int(rng.integers(1 << 30)))
     if rng.random() < 0.4:                                   # planted repeats -> branching graph
@@ -28,7 +28,7 @@ for case in range(n_cases):
     if rng.random() < 0.2:                                   # inverted repeat / hairpin material
         L = min(int(rng.integers(k, 3 * k)), glen - 1); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
         g[dst:dst + L] = (3 - g[src:src + L])[::-1]
-    rl = int(rng.choice([max(k + 3, 60), 100, 150, 250]))
+    rl = int(rng.choice([max(k + 3, 60), 100, 150, 250, k + 120]))
     rl = max(rl, k + 1)
     cov = float(rng.choice([3, 8, 20, 40]))
     err = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
