@@ -820,6 +820,13 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     std::string err;
     auto cfail = [&](int rc) { return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); };
     const double t0 = now_ms();
+    // SHK_STAGE_LOG=1: after every step the stream is drained and the step's name goes to stderr (which step a fault belongs to)
+    const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;
+    auto stage = [&](const char *what) {
+        if (!stage_log) return;
+        std::string e2; const int r2 = device_stream_sync(st, e2);
+        fprintf(stderr, "[shard_preprocess rank %u] %s done%s\n", rank, what, r2 ? " (stream error)" : ""); fflush(stderr);
+    };
     // A failure on ONE rank (device memory, a slice that overflows, a partition beyond 2^32 records: all depend on that
     // rank's share of the reads) must not leave the others blocked in the next collective: every local step's result
     // travels with the next small collective — as an extra element of one that exists anyway, or as a one-word
@@ -870,6 +877,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         part[2 * (size_t)P + 1] = mode;
     }
     part[2 * (size_t)P] = rc_p1 ? 1u : 0u;
+    stage("pass 1 + dedupe");
     // ---- the size exchange: every rank learns what every rank holds per partition
     const size_t ROW = 2 * (size_t)P + 2;
     std::vector<uint64_t> all_raw((size_t)world * ROW), all((size_t)world * P), raw_counts((size_t)world * P);
@@ -923,6 +931,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
             if (int r2 = h->pipe->shard_pack_dedup(send.p, send_w.p, plan.base.data(), P, e2)) rc_pack = fail(h, r2 == -4 ? SHK_E_OOM : (r2 == -1 ? SHK_E_PARAM : SHK_E_DEVICE), e2);
         } else if (!rc_pack) rc_pack = shard_pack_impl(h, send.p, plan.base.data(), P);
         if (!rc_pack) rc_pack = injected("pack");
+        stage("pack");
         if (int rc = agree(rc_pack, "the packing of the records")) return rc;
     }
     {
@@ -943,6 +952,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
         h->pipe->times().add("shard_exchange_host_clock", now_ms() - tx);
         h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * (rec_bytes + (weighted ? 4 : 0))) / 1e6);
     }
+    stage("exchange");
     if (send_w.p) { device_pool_release(send_w.p, send_w.bytes); send_w.p = nullptr; }
     device_pool_release(send.p, send.bytes); send.p = nullptr;
     // ---- pass 2 over the owned partitions, then the global histogram ([501] = ranks that failed)
@@ -952,6 +962,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     const uint64_t inst_in_reads = n_bases > n_seg * (uint64_t)(h->k - 1) ? n_bases - n_seg * (uint64_t)(h->k - 1) : 0;
     int rc_cnt = shard_count_impl(h, recv.p, plan.run_off.data(), plan.run_cnt.data(), (uint32_t)plan.owned.size(), world, red,
                                   &red[SHK_HISTO_BINS], weighted ? recv_w.p : nullptr);
+    stage("pass 2");
     if (!rc_cnt) rc_cnt = injected("count");
     if (rc_cnt) memset(red, 0, sizeof red);
     red[SHK_HISTO_BINS + 1] = rc_cnt ? 1u : 0u;
@@ -966,6 +977,24 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     const void *keys[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; const void *cnt = nullptr;
     uint64_t n_local = 0; uint32_t used = 0;
     int rc_rows = shard_rows_impl(h, red, keys, &cnt, &n_local, &used);
+    stage("filter");
+    if (stage_log && !rc_rows && n_local && n_local < (1u << 24)) {          // (debug aid: are the rank's solid k-mers distinct?)
+        std::vector<std::vector<uint64_t>> kw(W, std::vector<uint64_t>(n_local));
+        bool ok = true;
+        for (uint32_t j = 0; j < W && ok; j++) { void *dp = const_cast<void *>(keys[j]); std::string e3; ok = device_download(kw[j].data(), dp, n_local * 8, e3) == 0; }
+        if (ok) {
+            std::vector<uint32_t> idx(n_local);
+            for (uint32_t i = 0; i < n_local; i++) idx[i] = i;
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { for (int j = (int)W - 1; j >= 0; j--) if (kw[j][a] != kw[j][b]) return kw[j][a] < kw[j][b]; return false; });
+            uint64_t dup = 0;
+            for (uint32_t i = 1; i < n_local; i++) {
+                bool eq = true; for (uint32_t j = 0; j < W; j++) eq = eq && kw[j][idx[i]] == kw[j][idx[i - 1]];
+                if (eq && dup < 4) fprintf(stderr, "[shard_preprocess rank %u]   duplicate k-mer %016llx at rows %u and %u\n", rank, (unsigned long long)kw[0][idx[i]], idx[i - 1], idx[i]);
+                dup += eq;
+            }
+            fprintf(stderr, "[shard_preprocess rank %u] %llu local solid k-mers, %llu duplicates\n", rank, (unsigned long long)n_local, (unsigned long long)dup); fflush(stderr);
+        }
+    }
     if (!rc_rows) rc_rows = injected("rows");
     // ---- all-gather of the solid rows
     std::vector<uint64_t> counts2((size_t)world * 2), counts(world);

@@ -268,18 +268,22 @@ static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 template <int W>
 __global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__ spl, uint32_t n_spl,
                                                     FragRec *__restrict__ frag, SegRec *__restrict__ segs,
-                                                    uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */) {
+                                                    uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */,
+                                                    uint32_t total /* oriented nodes */, uint32_t *__restrict__ flags) {
     unsigned long long my_cov = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
         uint32_t cur = s, len = 0, nxt, last, is_head = 0;
         unsigned long long sum = 0;
-        for (;;) {
+        for (uint32_t hops = 0;; hops++) {
             const uint4 a = *reinterpret_cast<const uint4 *>(&frag[cur]);            // next, len, last, chain_head
             if (cur == s) is_head = a.w;
             const unsigned long long fs = frag[cur].sum;
             if (cur != s) { uint2 ob; ob.x = i; ob.y = len; *reinterpret_cast<uint2 *>(&frag[cur].owner) = ob; }
             sum += fs; len += a.y; last = a.z; nxt = a.x;
+            // (an inconsistent graph — the same k-mer on two rows — can lead a walker onto a record nobody wrote: an error, never a
+            // wild access here or in the kernels that read this segment)
+            if (last >= total || (nxt != NIL && nxt >= total) || hops >= total) { flags[0] = 1; last = s; nxt = NIL; break; }
             if (nxt == NIL || node_sampled(nxt, split_mask)) break;
             cur = nxt;
         }
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ se
         const SegRec r = segs[s];
         R[s].m = s; R[s].d = 0; R[s].dK = 0;
         if (r.head) { R[s].P = s; R[s].A = 0; R[s].K = 0; }
-        if (r.next_spl != NIL) { R[r.next_spl].P = s; R[r.next_spl].A = r.len; R[r.next_spl].K = r.sum; }
+        if (r.next_spl != NIL && r.next_spl < n_spl) { R[r.next_spl].P = s; R[r.next_spl].A = r.len; R[r.next_spl].K = r.sum; }
     }
 }
 // one launch follows HOPS pointers (the reach grows HOPS-fold per launch instead of doubling: a launch

@@ -117,5 +117,6 @@ int stream_read_gbs(size_t bytes, int iters, double *gbs, std::string &err);
 void device_pool_release(void *p, size_t bytes);
 int device_stream_sync(void *stream, std::string &err);      // waits for a hipStream_t
 int device_copy_h2d_async(void *dst, const void *src, size_t bytes, void *stream, std::string &err);
+int device_download(void *host, const void *dptr, size_t bytes, std::string &err);      // blocking device -> host copy
 
 }  // namespace shk

@@ -1398,6 +1398,12 @@ public:
         const uint32_t n = (uint32_t)n_solid_;
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
+        const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;          // (see shard_assemble)
+        auto stage = [&](const char *what) {
+            if (!stage_log) return;
+            const hipError_t e = hipStreamSynchronize(stream_);
+            fprintf(stderr, "[rank_chains n=%u] %s done%s\n", n, what, e == hipSuccess ? "" : " (stream error)"); fflush(stderr);
+        };
         if (int rc = cs.winfo.alloc(total, err)) return rc;
         if (int rc = cs.frag.alloc(total, err)) return rc;
         if (int rc = cs.spl.alloc(total, err)) return rc;
@@ -1409,8 +1415,10 @@ public:
                            alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
         const uint32_t tile_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_TILE_ROWS", LF_ROWS), 1), LF_TILE / 2u);
         const int lf_grid = (int)((n + tile_rows - 1) / tile_rows);
+        stage("k_succ_split");
         hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask);
         HIPCHK(hipGetLastError());
+        stage("k_local_frag");
         unsigned int n_spl = 0;
         if (int rc = read_ctl(n_spl, 5, err)) return rc;
         times_.add("collapse_succ_split", t1.stop());
@@ -1424,8 +1432,9 @@ public:
             EvTimer t2(stream_);
             if (n_spl) {
                 hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_,
-                                   cs.spl.p, n_spl, cs.frag.p, cs.segs.p, split_mask, ctl_.p + 10);
+                                   cs.spl.p, n_spl, cs.frag.p, cs.segs.p, split_mask, ctl_.p + 10, total, (uint32_t *)(ctl_.p + 8));
             }
+            stage("k_walk_frags");
             hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, cs.winfo.p, cs.ol.p,
                                cs.frag.p, cs.spl.p, cs.segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
             HIPCHK(hipGetLastError());
@@ -1443,19 +1452,24 @@ public:
         const int gr = grid_for((uint64_t)n_spl + 65536u);
         // (a chain has at most n_spl splitters: the ones k_orphan_cycles appends are chains of their own)
         int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl + 1u) { reach *= RANK_HOPS; rounds++; } }
+        stage("k_orphan_cycles");
         EvTimer tr(stream_);
         HIPCHK(hipMemsetAsync(cs.slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
         hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, cs.Ra.p);
+        stage("k_rank_init");
         RankRec *Ri = cs.Ra.p, *Ro = cs.Rb.p;
         for (int r = 0; r < rounds; r++) {
             hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, d_nspl, Ri, Ro);
             std::swap(Ri, Ro);
         }
+        stage("k_rank_jump");
         const unsigned int *d_ncyc = (const unsigned int *)(ctl_.p + 7);
         hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, cs.segs.p, d_nspl, Ri, cs.d_heads.p, cs.slot_of.p, cs.ringmin.p,
                            (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
         hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, Ri, cs.slot_of.p, cs.fin.p);
+        stage("k_rank_tails + k_rank_fin");
         hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, cs.ol.p, cs.frag.p, cs.fin.p);
+        stage("k_tile_final");
         if (rings) {
             // rings: their smallest k-mer (these three return at once when there is none)
             hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
@@ -1771,6 +1785,14 @@ public:
     }
 
     int shard_assemble(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) override {
+        // SHK_STAGE_LOG=1: after every step the stream is drained and the step's name goes to stderr (which step a fault belongs to)
+        const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;
+        auto stage = [&](const char *what) {
+            if (!stage_log) return;
+            const hipError_t e = hipStreamSynchronize(stream_);
+            fprintf(stderr, "[shard_assemble rank %d] %s done%s\n", comm_rank(c), what, e == hipSuccess ? "" : " (stream error)");
+            fflush(stderr);
+        };
         out.clear();
         if (!sh_active_) { err = "shard_assemble: the handle was not preprocessed by the sharded path"; return -2; }
         const uint32_t world = sh_world_, rank = sh_rank_;
@@ -1820,6 +1842,7 @@ public:
         } else if (int rc = xnb.alloc(1, err)) return rc;
         tg.stop_later("shard_graph_adjacency_total", pending_timers_);
         times_.add("shard_graph_cross_queries_x1e-3", xq_n_ * 1e-3);
+        stage("1 adjacency");
         // ---- 2. half links: which links across ranks are simple
         EvTimer th(stream_);
         DevBuf<uint32_t> xpred;                          // per local oriented node: record of hl.recv that names its simple predecessor on another rank
@@ -1840,11 +1863,13 @@ public:
             }
         } else if (int rc = hl.recv.alloc(2, err)) return rc;
         th.stop_later("shard_graph_half_links", pending_timers_);
+        stage("2 half links");
         // ---- 3. the chains of simple links that stay on this rank (the single-GPU contraction)
         ChainState cs;
         int rc_chain = 0;
         if (n) rc_chain = rank_chains(cs, false, err);
         const uint32_t n_lch = n ? (uint32_t)cs.n_heads : 0u;
+        stage("3 local chains");
         // ---- 4. stitching: the local chains of all ranks, ranked by every rank
         EvTimer ts(stream_);
         std::vector<uint64_t> lcnt(world, 0), lbase(world + 1, 0);
@@ -1933,6 +1958,7 @@ public:
         times_.add("shard_graph_stitch", ts.stop());
         times_.add("shard_graph_local_chains_x1e-3", n_lch * 1e-3);
         times_.add("shard_graph_unitigs_x1", (double)n_u);
+        stage("4 stitching");
         // ---- 5. the unitig graph on the host (identical on every rank: the records are put in the order of their first chain)
         const double t_host0 = now_ms_();
         const bool ug_dbg = getenv("SHK_UG_DEBUG") != nullptr;     // stage times of this host section on stderr
@@ -2070,6 +2096,7 @@ public:
         }
         lap("layout");
         times_.add("shard_graph_unitig_host_clock", now_ms_() - t_host0);
+        stage("5 unitig graph");
         // ---- 6. emission
         EvTimer te(stream_);
         const uint64_t text_w32 = ((text_bytes + 15) / 16 + 1) & ~1ull;           // 2-bit words (16 bases each), an even number: all-reduced as u64
@@ -2096,6 +2123,7 @@ public:
             }
             HIPCHK(hipMemcpyAsync(hout_.p, d_text.p, text_bytes, hipMemcpyDeviceToHost, stream_));
         }
+        stage("6 emission kernels");
         HIPCHK(stream_wait(stream_));
         times_.add("shard_graph_emit", te.stop());
         out.reserve(res.contigs.size());
@@ -2175,6 +2203,11 @@ private:
 
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 int set_device(int dev) { int prev = 0; (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); return prev; }
+int device_download(void *host, const void *dptr, size_t bytes, std::string &err) {
+    HIPCHK(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int device_count() {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -116,7 +116,12 @@ def main():
         cfg = json.load(open(sys.argv[3]))
         comm = LibComm(rank, world)
         results = []
-        for cs in cfg["cases"]:
+        if os.environ.get("SHK_DIST_FUZZ_LOG"):          # a file per rank: the case it is in and whatever the library prints (SHK_STAGE_LOG)
+            lf = os.open(os.environ["SHK_DIST_FUZZ_LOG"] + f".{rank}", os.O_WRONLY | os.O_CREAT | os.O_APPEND, 0o644)
+            os.dup2(lf, 2)
+        for ci, cs in enumerate(cfg["cases"]):
+            if os.environ.get("SHK_DIST_FUZZ_LOG"):
+                os.write(2, f"case {ci}: {dict((a, b) for a, b in cs.items() if a != 'fastq')}\n".encode())
             fq = open(cs["fastq"], "rb").read()
             k = cs["k"]
             recs = fq.decode().split("@r")[1:]

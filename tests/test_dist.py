@@ -393,7 +393,7 @@ def _write_cases(d, cases):
         fqp = os.path.join(d, f"reads{i}.fq")
         open(fqp, "wb").write(fq)
         # (records deduplicated by their sender / raw / the library's choice, in turn: dist_worker.set_dedupe)
-        out.append(dict({"dedupe": ("1", "0", "auto")[i % 3]}, **dict(params, fastq=fqp)))
+        out.append(dict({"dedupe": os.environ.get("SHK_DIST_FUZZ_DEDUPE") or ("1", "0", "auto")[i % 3]}, **dict(params, fastq=fqp)))
     cfgp = os.path.join(d, "cfg.json")
     json.dump({"cases": out}, open(cfgp, "w"))
     return cfgp
@@ -458,7 +458,8 @@ def test_sharded_graph_several_ranks(world):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from util import make_dataset
     from sparrowhawk_amd import synth
-    cases = _graph_cases(8200 + world, 30, first_case=world)
+    # (SHK_DIST_FUZZ_CASES / SHK_DIST_FUZZ_SEED: a longer campaign of the random graphs — tools/fuzz_sharded.sh)
+    cases = _graph_cases(int(os.environ.get("SHK_DIST_FUZZ_SEED", 8200)) + world, int(os.environ.get("SHK_DIST_FUZZ_CASES", 30)), first_case=world)
     # a circular chromosome + plasmids (rings across ranks), clean and with errors
     for seed, err, k, mc in ((31, 0.0, 31, 3), (32, 0.01, 31, 2), (33, 0.005, 51, 2)):
         chrom = synth.random_genome(60000, seed)
@@ -500,7 +501,7 @@ def test_sharded_graph_several_ranks(world):
         with tempfile.TemporaryDirectory() as d:
             cfgp = _write_cases(d, cases)
             out = os.path.join(d, "res")
-            launch(world, ["rccl_many", out, cfgp], 29800 + world, timeout=420)
+            launch(world, ["rccl_many", out, cfgp], 29800 + world, timeout=420 + 2 * int(os.environ.get("SHK_DIST_FUZZ_CASES", 30)))
             res = [json.load(open(f"{out}.{r}")) for r in range(world)]
     finally:
         os.environ.pop("SHK_RCCL_LIBRARY", None)
