@@ -146,6 +146,37 @@ def main():
         with open(f"{out_path}.{rank}", "w") as f:
             json.dump(results, f)
         comm.free()
+    elif mode == "gloo_many":
+        # the same many-case list, but the five shk_shard_* pieces driven by torch.distributed collectives (gloo, staged through
+        # the host) instead of the library's communicator: no stand-in transport, no collective code of the library
+        from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
+        from sparrowhawk_amd.dist import sharded_preprocess
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        comm = Comm(device=dev)
+        cfg = json.load(open(sys.argv[3]))
+        results = []
+        for cs in cfg["cases"]:
+            fq = open(cs["fastq"], "rb").read()
+            k = cs["k"]
+            recs = fq.decode().split("@r")[1:]
+            mine = ("@r" + "@r".join(recs[rank::world])).encode() if recs[rank::world] else b""
+            bases, seg, nb, nr = pack_fastq(mine, k, cs["min_qual"])
+            d_bases = torch.from_numpy(bases.view(np.int32)).to(dev)
+            d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+            torch.cuda.synchronize()
+            h = AssemblyHelper.new(k, False, cs["min_count"], cs["min_qual"], 0, False, bool(cs.get("do_fit", False)),
+                                   bool(cs.get("no_bubble_collapse", False)), bool(cs.get("no_dead_end_removal", False)))
+            try:
+                sharded_preprocess(h, d_bases, d_seg, len(seg) - 1, nb, nr, comm, n_partitions=cs.get("P") or None)
+                h.assemble()
+                res = {"pre": h.get_preprocessing_info(), "asm": h.get_assembly()}
+            except ShkError as e:
+                res = {"error": str(e)}
+            results.append(res)
+            h.free()
+        with open(f"{out_path}.{rank}", "w") as f:
+            json.dump(results, f)
     elif mode == "rccl":
         from sparrowhawk_amd import AssemblyHelper, pack_fastq, ShkError
         from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
