@@ -123,6 +123,10 @@ ncclResult_t run_group(Comm *c, hipStream_t st, std::vector<Op> &ops) {
             if (o.bytes && hipMemcpy(o.recv, c->data + (size_t)o.peer * OUTBOX_BYTES + e->off, o.bytes, hipMemcpyHostToDevice) != hipSuccess) { rc = ncclUnhandledCudaError; break; }
         }
     }
+    // hipMemcpy from PAGEABLE host memory (the shared-memory outboxes) may return once the bytes are staged, before the DMA to
+    // the device has finished, and the library's stream is a non-blocking one — nothing orders its next kernel behind that DMA.
+    // A real collective is stream-ordered; this stand-in waits for the device here so that it is too.
+    if (hipDeviceSynchronize() != hipSuccess && rc == ncclSuccess) rc = ncclUnhandledCudaError;
     barrier(c);                                                              // (outboxes may be overwritten from here on)
     return rc;
 }
