@@ -1218,7 +1218,10 @@ public:
         // (no fills for adj_ and alive_: k_graph_local writes the adjacency byte of every row before k_graph_remote ORs
         // into it, k_row_starts sets the alive flags)
         HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
-        if (n) {
+        // (sharded assembly: a rank that holds NO solid k-mer still owns partitions and is asked about neighbour candidates by
+        // the others — its (empty) mini tables must exist: found by the 250-case campaign on 4 ranks, where such a rank answered
+        // from tables nobody had built and took a memory fault)
+        if (n || sh_active_) {
             Graph<W> g = graph_view();
             EvTimer t(stream_);
             hipLaunchKernelGGL(k_gp_count<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_, g.gt,
@@ -1230,7 +1233,7 @@ public:
                                gp_rows.p);
             HIPCHK(hipGetLastError());
             const uint64_t regroup_env = env_u64("SHK_REGROUP_ROWS", 2);        // 0 never, 1 always, 2 when the rows are scattered
-            if (regroup_env == 1 || (regroup_env == 2 && rows_scattered_)) {
+            if (n && (regroup_env == 1 || (regroup_env == 2 && rows_scattered_))) {
                 // The rows are not grouped by minimiser partition (they came out of the bucket path in key-hash order): move them
                 // into the order of the row lists once.  Every later pass finds a partition's rows side by side again — the key
                 // reads of k_graph_local coalesce, the LDS tiles of the collapse hold neighbours — and the lists become the identity.
@@ -1946,11 +1949,16 @@ public:
             HIPCHK(hipMemcpyAsync(hM2, d_M.p, 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(&h_fl, ctl_.p + 13, 8, hipMemcpyDeviceToHost, stream_));      // (flags of k_hl_apply / k_ls_answer, read with the counts)
             HIPCHK(stream_wait(stream_));
+            // (these flags are LOCAL: the verdict must be every rank's — a rank that left alone would leave the others in the
+            // next collective and itself one collective ahead for the rest of the process)
+            int rc_fl = 0;
             if ((uint32_t)h_fl) {
                 err = (uint32_t)h_fl == 1 ? "sharded assembly: a record reached a rank that does not own its k-mer (ownership rules disagree)"
                                          : "sharded assembly: the two sides of a link across ranks disagree";
-                return -6;
+                rc_fl = -6;
             }
+            if (world > 1) { if (int rc = agree(rc_fl, "the stitching of the chains")) return rc; }
+            else if (rc_fl) return rc_fl;
             n_u = hM2[1];
             uheads.resize(n_u);
             if (n_u) HIPCHK(hipMemcpy(uheads.data(), d_uheads.p, (size_t)n_u * sizeof(UHead), hipMemcpyDeviceToHost));

@@ -496,6 +496,13 @@ def test_sharded_graph_several_ranks(world):
     g, fq = make_dataset(40000, 30, read_len=400, err=0.003, seed=8460 + world, circular=True)       # six- and eight-word keys (k up to 255)
     cases.append((fq, dict(k=161, min_count=2, min_qual=0)))
     cases.append((fq, dict(k=255, min_count=1, min_qual=0)))
+    # a genome of k + 5 bases: six solid k-mers under one or two minimisers, so some rank owns NO solid k-mer and still has
+    # to answer neighbour queries (empty graph tables), join every exchange and agree on the stitching (found by the
+    # 250-case campaign at 4 ranks)
+    tiny = synth.random_genome(46, 8470 + world)
+    codes, quals = synth.sample_reads(tiny, 12, 46, 8471 + world, err=0.0, circular=False)
+    cases.append((synth.to_fastq(codes, quals), dict(k=41, min_count=2, min_qual=0)))
+    i_tiny = len(cases) - 1
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     try:
         with tempfile.TemporaryDirectory() as d:
@@ -511,6 +518,8 @@ def test_sharded_graph_several_ranks(world):
             assert "error" not in res[r][i], (i, r, res[r][i])
             assert res[r][i]["pre"] == pre, (i, r)
             assert res[r][i]["asm"] == asm, (i, r, pr)
+        if i == i_tiny and world >= 3:
+            assert min(res[r][i]["n_solid_local"] for r in range(world)) == 0      # a rank without a single solid k-mer
         if i >= 30:
             assert sum(res[r][i]["n_solid_local"] for r in range(world)) == json.loads(pre)["nkmers"]      # nobody holds the whole set
 
