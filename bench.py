@@ -387,6 +387,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- N > 1: one untimed trial step decides the path EVERY rank measures.  The library's collectives report a failure on
+    # every rank (api.cpp: agree), so all ranks see the exception; the flag is summed anyway, so that a rank-local failure moves
+    # everybody too.  Order: RCCL inside the library -> the same shk_shard_* pieces with torch.distributed's collectives -> one
+    # isolate per rank (no data-path collective).  Every step down is LOUD (stderr) and recorded in the JSON line ("fallbacks").
+    fallbacks = []
+    inject = os.environ.get("BENCH_TEST_FAIL_PATHS", "").split(",")     # (tests/test_dist.py: the steps down, rehearsed)
+    while sharded and world > 1:
+        trial_error = None
+        try:
+            if args.collectives in inject:
+                raise RuntimeError("injected failure (BENCH_TEST_FAIL_PATHS)")
+            one_step()
+        except Exception as e:
+            trial_error = repr(e)
+        flag = torch.tensor([1 if trial_error else 0], device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag)
+        if int(flag.item()) == 0:
+            break
+        path = "lib" if args.collectives == "lib" else "torch"
+        fallbacks.append({"path": "sharded, collectives=" + path, "error": trial_error or "another rank failed"})
+        print(f"[bench rank {rank}] the sharded step failed with collectives={path}: {trial_error or 'on another rank'}",
+              file=sys.stderr, flush=True)
+        torch.cuda.synchronize()
+        if args.collectives == "lib":
+            comm.free()
+            comm = Comm(device=dev)
+            args.collectives = "torch"
+        else:
+            sharded = False                              # every rank assembles an isolate of its own
+            d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
+                torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -542,8 +573,10 @@ def main():
                                      else "graph phases sharded too (collective shk_assemble: neighbour queries, half links, stitched chains, "
                                           "unitig-level correction, per-rank emission)") if args.collectives == "lib"
                                     else "one pooled sample, sharded, collectives by torch.distributed (" + args.backend + ")" +
-                                         ("" if not lib_error else " — SECOND PATH: the library's RCCL communicator failed: " + str(lib_error)))
-                                   if sharded else "one isolate per rank (batch of isolates), no data-path collective"),
+                                         ("" if not lib_error else " — SECOND PATH: the library's RCCL communicator failed: " + str(lib_error)) +
+                                         ("" if not fallbacks else " — SECOND PATH: " + fallbacks[0]["error"]))
+                                   if sharded else "one isolate per rank (batch of isolates), no data-path collective" +
+                                   ("" if not fallbacks else " — FALLBACK: the sharded path failed on this node, see fallbacks")),
                    "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -560,6 +593,8 @@ def main():
                      "note": "integer/hash path bound by instruction issue and LDS round trips, not by HBM: see DESIGN.md section 4"},
         "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
     }
+    if fallbacks:
+        line["fallbacks"] = fallbacks                     # the paths that failed before the one measured (see config.parallelism)
     if iso_leg is not None:
         line["value_isolates_mode"] = n_bases * world / iso_leg / 1e9
         line["ms_per_step_isolates_mode"] = iso_leg * 1e3

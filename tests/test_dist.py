@@ -365,6 +365,40 @@ def test_a_record_exchange_that_loses_data_is_reported(world, dedupe):
         assert "error" in x and "lost or duplicated data" in x["error"], (r, x)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("truncate", [0, 4096, -1])
+def test_bench_launches_its_own_ranks_and_steps_down_loudly(truncate):
+    """`python bench.py --gpus 2` without a launcher: it starts its own two ranks (here both on the one GPU,
+    gloo for torch's group, the library's exchange through tests/mock_rccl), prints ONE JSON line and exits 0.  With a
+    transport that loses data the library reports it on every rank; the bench then measures the same shk_shard_* pieces with
+    torch.distributed's collectives and SAYS so in the line (`fallbacks`, `config.parallelism`) — never a silent switch; when
+    that path fails too (injected), every rank assembles an isolate of its own and the line says that."""
+    env = dict(os.environ, SHK_RCCL_LIBRARY=mock_rccl_library(), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MOCK_RCCL_TRUNCATE_BYTES", None)
+    if truncate > 0:
+        env["MOCK_RCCL_TRUNCATE_BYTES"] = str(truncate)
+    if truncate < 0:                                        # both sharded paths fail: one isolate per rank, said in the line
+        env["BENCH_TEST_FAIL_PATHS"] = "lib,torch"
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-gpu", "--backend", "gloo", "--genome", "300000",
+                         "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                        env=env, timeout=400)
+    assert pr.returncode == 0, pr.stdout[-1500:] + pr.stderr[-3000:]
+    lines = [x for x in pr.stdout.splitlines() if x.strip()]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["config"]["ncontigs"] >= 1
+    if truncate < 0:
+        assert [f["path"] for f in line["fallbacks"]] == ["sharded, collectives=lib", "sharded, collectives=torch"]
+        assert "one isolate per rank" in line["config"]["parallelism"] and "FALLBACK" in line["config"]["parallelism"]
+        assert line["config"]["ncontigs"] == 1
+    elif truncate:
+        assert line["fallbacks"][0]["path"] == "sharded, collectives=lib" and "lost or duplicated data" in line["fallbacks"][0]["error"]
+        assert "torch.distributed" in line["config"]["parallelism"] and "SECOND PATH" in line["config"]["parallelism"]
+        assert "the sharded step failed with collectives=lib" in pr.stderr
+    else:
+        assert "fallbacks" not in line and "inside the library" in line["config"]["parallelism"]
+
+
 def test_a_missing_rccl_library_is_an_error_not_a_crash():
     """ADVICE r2: dlerror() clears its message when read — reading it twice handed std::string a null pointer and the
     process died instead of returning SHK_E_DEVICE.  Runs in a child (the library resolves RCCL once per process)."""
