@@ -537,6 +537,14 @@ def test_sharded_graph_several_ranks(world):
     codes, quals = synth.sample_reads(tiny, 12, 46, 8471 + world, err=0.0, circular=False)
     cases.append((synth.to_fastq(codes, quals), dict(k=41, min_count=2, min_qual=0)))
     i_tiny = len(cases) - 1
+    # degenerate inputs on several ranks (test_empty_and_degenerate_inputs has them on one GPU): nothing solid anywhere, a
+    # single k-mer, a homopolymer (one node with a self-loop), one read shorter than k — with fewer records than ranks, so
+    # that some ranks are handed no read at all
+    cases.append((synth.to_fastq(codes, quals), dict(k=41, min_count=50, min_qual=0)))
+    one = "ACGTTGCATGCCGATAGCTAGCTAGGATCCA"
+    cases.append(((f"@r0\n{one}\n+\n{'I' * 31}\n" * 3).encode(), dict(k=31, min_count=1, min_qual=0)))
+    cases.append(((f"@r0\n{'A' * 60}\n+\n{'I' * 60}\n" * 2).encode(), dict(k=31, min_count=0, min_qual=0)))
+    cases.append((b"@r0\nACGTACGT\n+\nIIIIIIII\n", dict(k=31, min_count=0, min_qual=0)))
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     try:
         with tempfile.TemporaryDirectory() as d:
