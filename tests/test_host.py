@@ -42,6 +42,27 @@ def test_new_rejects_bad_parameters(lib):
     assert lib.shk_new_error() == -1
 
 
+def test_without_a_hip_device_the_product_refuses(lib):
+    """No CPU fallback anywhere on the product path: on a box without a HIP device shk_new fails with SHK_E_DEVICE and says
+    why, the Python mirror raises, and bench.py / smoke() end with an error instead of measuring or checking something else."""
+    import subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a HIP device")
+    assert not lib.shk_new(31, 0, 5, 20, 0, 0, 0, 0, 0)
+    assert lib.shk_new_error() == -5                                          # SHK_E_DEVICE (include/shk.h)
+    assert b"no HIP device" in lib.shk_new_error_message() and b"no CPU fallback" in lib.shk_new_error_message()
+    from sparrowhawk_amd import AssemblyHelper, ShkError
+    with pytest.raises(ShkError):
+        AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], stdout=subprocess.PIPE,
+                        stderr=subprocess.PIPE, text=True, timeout=300)
+    assert pr.returncode != 0 and pr.stdout.strip() == "" and "needs a HIP device" in pr.stderr
+    pr = subprocess.run([sys.executable, os.path.join(ROOT, "__graft_entry__.py"), "smoke"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                        text=True, timeout=300)
+    assert pr.returncode != 0
+
+
 def unpack(bases, seg, i):
     s, e = int(seg[i]), int(seg[i + 1])
     return "".join("ACGT"[(int(bases[p >> 4]) >> (2 * (p & 15))) & 3] for p in range(s, e))
