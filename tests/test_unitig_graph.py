@@ -108,7 +108,8 @@ def library_contigs(L, pg, k, tips, bubbles, drop_mirror_of_short_rings=False):
 @pytest.mark.parametrize("block", range(8))
 def test_unitig_level_correction_equals_the_oracle(block):
     L = _lib.load()
-    rng = np.random.default_rng(7000 + block)                # the inputs of test_graph_stages_against_a_brute_force_python_graph
+    # (the inputs of test_graph_stages_against_a_brute_force_python_graph; SHK_UG_FUZZ_SEED: a longer campaign with other seeds)
+    rng = np.random.default_rng(int(os.environ.get("SHK_UG_FUZZ_SEED", 7000)) + block)
     n_removed = 0
     for case in range(block * 40, block * 40 + 40):
         fq, k, min_count, flags = _random_graph_case(rng, case)
