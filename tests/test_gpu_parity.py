@@ -494,6 +494,43 @@ def test_device_fastq_parser_equals_host_parser():
         assert h.n_distinct == 0
 
 
+def test_damaged_fastq_texts_are_taken_or_refused_as_the_oracle_does():
+    """400 small FASTQ texts, most of them damaged (tests/util.py: damaged_fastq_texts — CRLF on some lines, blank lines,
+    a missing '@' / '+', qualities of another length, records cut anywhere, IUPAC codes, bytes >= 0x80, ...), through
+    shk_preprocess with the device parser first (default) and with the host parser alone: both must refuse exactly the
+    texts the oracle refuses (SHK_E_PARSE) and count the oracle's k-mers from the others."""
+    from util import damaged_fastq_texts
+    n_ok = n_bad = 0
+    for case, (data, min_qual, what) in enumerate(damaged_fastq_texts(78, 400)):
+        try:
+            o = run_oracle([data], k=15, min_count=0, min_qual=min_qual)
+            want = o.distinct()
+        except ValueError:
+            want = None
+        for host_parser in (False, True):
+            def run():
+                h = AssemblyHelper.new(15, False, 0, min_qual, 0, False, False, False, False)
+                try:
+                    h.preprocess(data)
+                    if h.n_distinct == 0:
+                        return (np.zeros((0, 1), dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+                    kk, cc, _ = sorted_table(*h.distinct())
+                    return kk, cc
+                except ShkError as e:
+                    assert e.code == -3, (case, what, data, e.code)
+                    return None
+                finally:
+                    h.free()
+            got = _with_env({"SHK_HOST_PARSER": "1"} if host_parser else {}, run)
+            who = "host parser" if host_parser else "device parser first"
+            assert (got is None) == (want is None), (case, what, data, who, "product " + ("refuses" if got is None else "takes"))
+            if got is not None:
+                assert len(got[1]) == len(want[1]) and np.array_equal(got[0].reshape(-1), want[0].reshape(-1)) and np.array_equal(got[1], want[1]), (case, what, data, who)
+        n_ok += want is not None
+        n_bad += want is None
+    assert n_ok > 100 and n_bad > 60, (n_ok, n_bad)
+
+
 def test_several_batches_per_handle():
     """Inputs are handed to the device in batches (chunked mode: every chunk_size reads; any mode: when a
     batch would exceed its 32-bit base offsets; streaming: per pushed chunk).  Every batch keeps its own

@@ -108,39 +108,10 @@ def test_host_packer_and_oracle_reader_agree_on_damaged_fastq():
     quality bytes below '!', tabs and spaces, bytes >= 0x80, a last line without its newline — go through the
     product's host reader (shk_pack_fastq) and through the oracle's: both must take or refuse the same texts
     (SHK_E_PARSE), and what they take must give the same canonical k-mer counts."""
-    from util import run_oracle
-    rng = np.random.default_rng(77)
+    from util import damaged_fastq_texts, run_oracle
     k = 15
     n_ok = n_bad = 0
-    for case in range(600):
-        recs = []
-        for i in range(int(rng.integers(0, 6))):
-            L_ = int(rng.choice([0, 1, 14, 15, 16, 40, 90]))
-            alphabet = "ACGT" if rng.random() < 0.6 else str(rng.choice(["ACGTN", "ACGTacgtn", "ACGTRYKM.-*"]))
-            seq = "".join(rng.choice(list(alphabet), L_)) if L_ else ""
-            qual = "".join(chr(int(c)) for c in rng.integers(33, 75, L_))
-            recs.append([f"@r{i} extra", seq, "+" if rng.random() < 0.7 else f"+r{i} extra", qual])
-        what = str(rng.choice(["none", "none", "crlf", "crlf_some", "no_last_newline", "blank_end", "blank_middle", "no_plus", "no_at",
-                               "qual_short", "qual_long", "cut", "low_qual_byte", "tabs", "high_bytes", "fasta", "only_newlines"]))
-        if recs and what == "no_plus": recs[int(rng.integers(len(recs)))][2] = "ACGT"
-        if recs and what == "no_at": r_ = recs[int(rng.integers(len(recs)))]; r_[0] = r_[0][1:]
-        if recs and what == "qual_short": r_ = recs[int(rng.integers(len(recs)))]; r_[3] = r_[3][:-1] if r_[3] else "I"
-        if recs and what == "qual_long": recs[int(rng.integers(len(recs)))][3] += "I"
-        if recs and what == "low_qual_byte": r_ = recs[int(rng.integers(len(recs)))]; r_[3] = (" " + r_[3][1:]) if r_[3] else r_[3]
-        if recs and what == "tabs": r_ = recs[int(rng.integers(len(recs)))]; r_[1] = r_[1].replace("A", "\t", 1); 
-        if recs and what == "fasta": recs[0][0] = ">" + recs[0][0][1:]
-        lines = [x for r_ in recs for x in r_]
-        nl = "\r\n" if what == "crlf" else "\n"
-        text = "".join(x + (("\r\n" if rng.random() < 0.5 else "\n") if what == "crlf_some" else nl) for x in lines)
-        if what == "no_last_newline" and text: text = text.rstrip("\r\n")
-        if what == "blank_end": text += "\n" * int(rng.integers(1, 4))
-        if what == "blank_middle" and len(recs) >= 2: text = text.replace(nl + "@r1", nl + nl + "@r1", 1)
-        if what == "only_newlines": text = "\n" * int(rng.integers(0, 5))
-        data = text.encode()
-        if what == "cut" and data: data = data[:int(rng.integers(0, len(data)))]
-        if what == "high_bytes" and data:
-            b_ = bytearray(data); b_[int(rng.integers(len(b_)))] = int(rng.integers(128, 256)); data = bytes(b_)
-        min_qual = int(rng.choice([0, 10, 20]))
+    for case, (data, min_qual, what) in enumerate(damaged_fastq_texts(77, 600)):
         try:
             o = run_oracle([data], k=k, min_count=0, min_qual=min_qual)
             want = {tuple(int(x) for x in key): int(c) for key, c in zip(*o.distinct())}

@@ -184,3 +184,39 @@ def compare_all(helper, oracle, check_graph=True):
     assert out["outdot"] == ref["outdot"], "DOT differs"
     assert helper.get_assembly() == oracle.assembly_json()
     return out
+
+
+def damaged_fastq_texts(seed, n):
+    """n small FASTQ texts, most of them damaged in one way (SPEC S1 / S2): clean, CRLF on all or some lines, blank lines at the
+    end or in the middle, a missing '@' / '+', qualities of another length, records cut anywhere, lower case, IUPAC codes,
+    quality bytes below '!', tabs, bytes >= 0x80, a last line without its newline.  Yields (text, min_qual, what)."""
+    rng = np.random.default_rng(seed)
+    for case in range(n):
+        recs = []
+        for i in range(int(rng.integers(0, 6))):
+            L_ = int(rng.choice([0, 1, 14, 15, 16, 40, 90]))
+            alphabet = "ACGT" if rng.random() < 0.6 else str(rng.choice(["ACGTN", "ACGTacgtn", "ACGTRYKM.-*"]))
+            seq = "".join(rng.choice(list(alphabet), L_)) if L_ else ""
+            qual = "".join(chr(int(c)) for c in rng.integers(33, 75, L_))
+            recs.append([f"@r{i} extra", seq, "+" if rng.random() < 0.7 else f"+r{i} extra", qual])
+        what = str(rng.choice(["none", "none", "crlf", "crlf_some", "no_last_newline", "blank_end", "blank_middle", "no_plus", "no_at",
+                               "qual_short", "qual_long", "cut", "low_qual_byte", "tabs", "high_bytes", "fasta", "only_newlines"]))
+        if recs and what == "no_plus": recs[int(rng.integers(len(recs)))][2] = "ACGT"
+        if recs and what == "no_at": r_ = recs[int(rng.integers(len(recs)))]; r_[0] = r_[0][1:]
+        if recs and what == "qual_short": r_ = recs[int(rng.integers(len(recs)))]; r_[3] = r_[3][:-1] if r_[3] else "I"
+        if recs and what == "qual_long": recs[int(rng.integers(len(recs)))][3] += "I"
+        if recs and what == "low_qual_byte": r_ = recs[int(rng.integers(len(recs)))]; r_[3] = (" " + r_[3][1:]) if r_[3] else r_[3]
+        if recs and what == "tabs": r_ = recs[int(rng.integers(len(recs)))]; r_[1] = r_[1].replace("A", "\t", 1); 
+        if recs and what == "fasta": recs[0][0] = ">" + recs[0][0][1:]
+        lines = [x for r_ in recs for x in r_]
+        nl = "\r\n" if what == "crlf" else "\n"
+        text = "".join(x + (("\r\n" if rng.random() < 0.5 else "\n") if what == "crlf_some" else nl) for x in lines)
+        if what == "no_last_newline" and text: text = text.rstrip("\r\n")
+        if what == "blank_end": text += "\n" * int(rng.integers(1, 4))
+        if what == "blank_middle" and len(recs) >= 2: text = text.replace(nl + "@r1", nl + nl + "@r1", 1)
+        if what == "only_newlines": text = "\n" * int(rng.integers(0, 5))
+        data = text.encode()
+        if what == "cut" and data: data = data[:int(rng.integers(0, len(data)))]
+        if what == "high_bytes" and data:
+            b_ = bytearray(data); b_[int(rng.integers(len(b_)))] = int(rng.integers(128, 256)); data = bytes(b_)
+        yield data, int(rng.choice([0, 10, 20])), what
