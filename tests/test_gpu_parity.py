@@ -498,9 +498,11 @@ def test_damaged_fastq_texts_are_taken_or_refused_as_the_oracle_does():
     """400 small FASTQ texts, most of them damaged (tests/util.py: damaged_fastq_texts — CRLF on some lines, blank lines,
     a missing '@' / '+', qualities of another length, records cut anywhere, IUPAC codes, bytes >= 0x80, ...), through
     shk_preprocess with the device parser first (default) and with the host parser alone: both must refuse exactly the
-    texts the oracle refuses (SHK_E_PARSE) and count the oracle's k-mers from the others."""
+    texts the oracle refuses (SHK_E_PARSE) and count the oracle's k-mers from the others; a third of them also as the
+    second file of a pair behind a clean first file, either file gzip-wrapped or plain."""
     from util import damaged_fastq_texts
-    n_ok = n_bad = 0
+    n_ok = n_bad = n_pairs = 0
+    clean = None                                            # the last text that was taken and held k-mers
     for case, (data, min_qual, what) in enumerate(damaged_fastq_texts(78, 400)):
         try:
             o = run_oracle([data], k=15, min_count=0, min_qual=min_qual)
@@ -528,7 +530,28 @@ def test_damaged_fastq_texts_are_taken_or_refused_as_the_oracle_does():
                 assert len(got[1]) == len(want[1]) and np.array_equal(got[0].reshape(-1), want[0].reshape(-1)) and np.array_equal(got[1], want[1]), (case, what, data, who)
         n_ok += want is not None
         n_bad += want is None
-    assert n_ok > 100 and n_bad > 60, (n_ok, n_bad)
+        # as the SECOND file of a pair behind a clean first one (pooled: S1), and gzip-wrapped: the same verdict
+        if case % 3 == 0 and clean is not None:
+            try:
+                want2 = run_oracle([clean[0], data], k=15, min_count=0, min_qual=clean[1]).distinct()
+            except ValueError:
+                want2 = None
+            h = AssemblyHelper.new(15, False, 0, clean[1], 0, False, False, False, False)
+            try:
+                h.preprocess(gzip.compress(clean[0]) if case % 2 else clean[0], gzip.compress(data) if case % 4 < 2 else data)
+                got2 = sorted_table(*h.distinct())[:2] if h.n_distinct else (np.zeros((0, 1), dtype=np.uint64), np.zeros(0, dtype=np.uint32))
+            except ShkError as e:
+                assert e.code == -3, (case, what, data, e.code)
+                got2 = None
+            finally:
+                h.free()
+            assert (got2 is None) == (want2 is None), (case, what, data, "as second file", "product " + ("refuses" if got2 is None else "takes"))
+            if got2 is not None:
+                assert np.array_equal(got2[0].reshape(-1), want2[0].reshape(-1)) and np.array_equal(got2[1], want2[1]), (case, what, data, "as second file")
+            n_pairs += 1
+        if want is not None and len(want[1]) > 0:
+            clean = (data, min_qual)
+    assert n_ok > 100 and n_bad > 60 and n_pairs > 80, (n_ok, n_bad, n_pairs)
 
 
 def test_several_batches_per_handle():
