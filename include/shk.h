@@ -186,8 +186,15 @@ uint32_t shk_used_min_count(shk_handle *h);
 /* after shk_assemble: per solid node (same row order as shk_get_solid) */
 int shk_get_adjacency(shk_handle *h, uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
                       uint64_t cap);
-/* timing of the last preprocess/assemble, milliseconds, by stage name; returns a JSON object */
+/* timing of the last preprocess/assemble, milliseconds, by stage name; returns a JSON object.  Two entries are not times:
+ * "peak_device_bytes" = the most device memory the handle held at once, "device_bytes_now" = what it holds at the call
+ * (the reference reports the peak wasm memory with every assembly: Assembler.ts:69-71,137). */
 const char *shk_get_timings(shk_handle *h);
+/* the same figure alone: high-water mark of the device bytes charged to this handle (its pool blocks, the packed reads
+ * uploaded for it, the exchange buffers of the shard layer) */
+uint64_t shk_peak_device_bytes(shk_handle *h);
+/* host-only (tests): the counter behind it — applies signed byte deltas in order, reports high-water mark and remainder */
+void shk_host_mem_counter(const int64_t *deltas, size_t n, uint64_t *peak, uint64_t *current);
 
 /* ---- host-only self tests of the device/host shared k-mer arithmetic (no GPU needed) */
 int shk_host_canonical(const char *seq, uint32_t k, uint64_t *out_words /*W*/, int *orient);

@@ -62,6 +62,8 @@ SIGNATURES = {
     "shk_used_min_count": (_u32, [_vp]),
     "shk_get_adjacency": (_int, [_vp, _vp, _vp, _vp, _u64]),
     "shk_get_timings": (_cp, [_vp]),
+    "shk_peak_device_bytes": (_u64, [_vp]),
+    "shk_host_mem_counter": (None, [_vp, _sz, C.POINTER(_u64), C.POINTER(_u64)]),
     "shk_host_canonical": (_int, [_cp, _u32, _vp, C.POINTER(_int)]),
     "shk_host_nthash": (_u64, [_cp, _u32]),
     "shk_host_fit": (_int, [_vp, C.POINTER(_u32)]),

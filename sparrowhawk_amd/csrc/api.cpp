@@ -7,7 +7,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <new>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -58,6 +60,7 @@ struct shk_handle {
     uint64_t batches_started = 0;      // batches handed to the pipeline (a failure after the first one poisons the handle)
     ShardComm *shard_comm = nullptr;   // sharded assembly: the communicator shk_shard_preprocess ran on (shk_assemble is collective over it)
     AssemblyText text;
+    std::shared_ptr<void> mem = mem_acct_new();   // device bytes this handle holds / held at most (pipeline.h: mem_acct_*)
 
     const char *mode() const { return do_bloom ? "bloom" : (chunk_size > 0 ? "chunked" : "bulk"); }
     void post(const std::string &s) { if (cb) cb(s.c_str(), cb_user); }
@@ -80,11 +83,23 @@ struct DevGuard {
     DevGuard(const DevGuard &) = delete;
     DevGuard &operator=(const DevGuard &) = delete;
 };
+// the calling thread allocates (and frees) device blocks on behalf of this handle while the guard lives
+struct MemGuard {
+    std::shared_ptr<void> prev;
+    explicit MemGuard(const std::shared_ptr<void> &a) : prev(mem_acct_set(a)) {}
+    ~MemGuard() { (void)mem_acct_set(prev); }
+    MemGuard(const MemGuard &) = delete;
+    MemGuard &operator=(const MemGuard &) = delete;
+};
 enum class Poison { Never, AfterFirstBatch, Always };
 template <typename F> static int guarded(shk_handle *h, Poison poison, F &&body) {
     if (!h) return SHK_E_PARAM;
     if (h->st == St::Failed) return fail(h, SHK_E_STATE, "the handle failed earlier (" + h->first_err + "): free it and start again");
     DevGuard g(h->pipe ? h->pipe->device() : current_device());
+    MemGuard mg(h->mem);
+    // device buffers that go out of scope inside the call (early returns included) are parked until the handle's stream
+    // has drained, then go back to the pool: nothing in flight can be handed to another handle (pipeline.h)
+    DeferScope park(h->pipe);
     int rc;
     try { rc = body(); }
     catch (const std::bad_alloc &) { rc = fail(h, SHK_E_OOM, "out of host memory"); }
@@ -99,6 +114,12 @@ template <typename F> static int guarded(shk_handle *h, Poison poison, F &&body)
 }
 
 extern "C" {
+
+// the communicators that exist: a handle keeps the one its sharded preprocess ran on, and shk_assemble must find out that it
+// has been freed meanwhile (SHK_E_STATE, not a use after free)
+static std::mutex g_live_mu;
+static std::set<ShardComm *> &live_comms() { static auto *s = new std::set<ShardComm *>(); return *s; }
+static bool comm_is_live(ShardComm *c) { std::lock_guard<std::mutex> lk(g_live_mu); return live_comms().count(c) != 0; }
 
 void shk_release_cached_memory(void) { device_pool_trim(); big_trim(); }
 int shk_measure_stream_read(size_t bytes, int iters, double *gbs) {
@@ -128,7 +149,10 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
     h->chunk_size = chunk_size; h->do_bloom = do_bloom != 0; h->do_fit = do_fit != 0;
     h->no_bubble = no_bubble_collapse != 0; h->no_deadend = no_dead_end_removal != 0;
     std::string err;
-    h->pipe = make_pipeline((int)k, err);
+    {
+        MemGuard mg(h->mem);
+        h->pipe = make_pipeline((int)k, err);
+    }
     if (!h->pipe) { g_new_err = SHK_E_DEVICE; g_new_msg = err; delete h; return nullptr; }
     h->pipe->set_bloom(h->do_bloom);
     return h;
@@ -347,6 +371,7 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
             const Piece nx = pieces[i + 1];
             const uint8_t *tn = nx.file ? t2 : t1;
             uploader = std::thread([&, nx, tn]() {
+                MemGuard mg(h->mem);                       // (the text block this thread allocates belongs to the handle)
                 try { up_rc = gpu_upload_text(tn + nx.off, nx.end - nx.off, device, nxt, up_err); }
                 catch (...) { up_rc = -4; up_err = "out of host memory (uploader)"; }
             });
@@ -682,12 +707,13 @@ static int assemble_impl(shk_handle *h) {
     if (h->pipe->sharded_graph()) {
         // the graph is spread over the ranks of the communicator shk_shard_preprocess ran on: collective (csrc/shard_graph.h).
         // The three phases run interleaved across ranks; the states are posted in the reference's order.
-        if (!h->shard_comm) return fail(h, SHK_E_STATE, "assemble: the communicator of the sharded preprocess is gone");
+        if (!h->shard_comm || !comm_is_live(h->shard_comm)) return fail(h, SHK_E_STATE, "assemble: the communicator of the sharded preprocess is gone (shk_comm_free before shk_assemble)");
         h->post("assembly:create_graph");
         std::vector<RawContig> contigs;
         if (h->pipe->n_solid_global() >= (1u << 20)) writer_prewarm(3000);
         int rc = h->pipe->shard_assemble(h->shard_comm, !h->no_deadend, !h->no_bubble, contigs, err);
-        if (rc) { if (rc == -5) comm_mark_broken(h->shard_comm); return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err); }
+        // (a failure the other ranks cannot know of has aborted the communicator already: Pipeline::shard_assemble)
+        if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
         h->post("assembly:correct_graph");
         h->post("assembly:collapse_graph");
         h->pipe->times().add("assemble_device_total_host_clock", now_ms() - t0);
@@ -799,10 +825,18 @@ const char *shk_get_timings(shk_handle *h) {
         char buf[64]; snprintf(buf, sizeof buf, "%.6f", kv.second);
         j += "\"" + kv.first + "\":" + buf;
     }
+    {   // not a time: the most device memory this handle held at once, in bytes (Assembler.ts:69-71,137 reports peak memory)
+        char buf[96]; snprintf(buf, sizeof buf, "%s\"peak_device_bytes\":%llu,\"device_bytes_now\":%llu", first ? "" : ",",
+                               (unsigned long long)mem_acct_peak(h->mem), (unsigned long long)mem_acct_current(h->mem));
+        j += buf;
+    }
     j += "}";
     h->timings_json.swap(j);
     return h->timings_json.c_str();
 }
+
+uint64_t shk_peak_device_bytes(shk_handle *h) { return h ? mem_acct_peak(h->mem) : 0; }
+void shk_host_mem_counter(const int64_t *deltas, size_t n, uint64_t *peak, uint64_t *current) { mem_acct_replay(deltas, n, peak, current); }
 
 // ---- collectives inside the library (shard_comm.hip: RCCL) ---------------------------------------------
 struct shk_comm { ShardComm *c = nullptr; };
@@ -904,7 +938,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     struct Block { void *p = nullptr; size_t bytes = 0; ~Block() { if (p) device_pool_release(p, bytes); } } send, recv, send_w, recv_w, gk[8], gc;
     // (declared after the blocks, so it runs before they go back to the pool: on every way out — errors included —
     // the stream is drained first; the pool has no stream-ordering bookkeeping)
-    struct DrainOnExit { void *st; ~DrainOnExit() { std::string e; (void)device_stream_sync(st, e); } } drain{st};
+    struct DrainOnExit { ShardComm *c; void *st; ~DrainOnExit() { std::string e; (void)comm_stream_wait(c, st, e); } } drain{c, st};
     {
         int rc_pack = SHK_OK;
         if (int rc = plan_exchange(all.data(), world, P, rank, plan, err)) rc_pack = cfail(rc);
@@ -948,7 +982,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
             for (uint32_t r = 0; r < world; r++) { so[r] = so[r] / rec_bytes * 4; sb[r] = plan.send_counts[r] * 4; ro[r] = ro[r] / rec_bytes * 4; rb[r] = plan.recv_counts[r] * 4; }
             if (int rc = comm_alltoallv(c, send_w.p, so.data(), sb.data(), recv_w.p, ro.data(), rb.data(), st, err, 4)) return cfail(rc);
         }
-        if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
+        if (int rc = comm_stream_wait(c, st, err)) { comm_mark_broken(c); return cfail(rc); }
         h->pipe->times().add("shard_exchange_host_clock", now_ms() - tx);
         h->pipe->times().add("shard_exchange_sent_MB", (double)(n_send * (rec_bytes + (weighted ? 4 : 0))) / 1e6);
     }
@@ -1040,7 +1074,7 @@ static int shard_preprocess_impl(shk_handle *h, shk_comm *cm, const void *d_base
     for (uint32_t j = 0; j < W; j++)
         if (int rc = comm_allgatherv(c, keys[j], gk[j].p, off8.data(), len8.data(), st, err)) return cfail(rc);
     if (int rc = comm_allgatherv(c, cnt, gc.p, off4.data(), len4.data(), st, err)) return cfail(rc);
-    if (int rc = device_stream_sync(st, err)) { comm_mark_broken(c); return cfail(rc); }
+    if (int rc = comm_stream_wait(c, st, err)) { comm_mark_broken(c); return cfail(rc); }
     const void *kp[8] = {gk[0].p, gk[1].p, gk[2].p, gk[3].p, gk[4].p, gk[5].p, gk[6].p, gk[7].p};
     if (int rc = shard_set_solid_impl(h, kp, gc.p, n_total, red[SHK_HISTO_BINS])) return rc;
     h->pipe->times().add("shard_preprocess_host_clock", now_ms() - t0);
@@ -1059,6 +1093,7 @@ shk_comm *shk_comm_init(const uint8_t id[SHK_UNIQUE_ID_BYTES], int rank, int wor
         shk_comm *w = new (std::nothrow) shk_comm();
         if (!w) { comm_destroy(c); g_comm_err = "out of host memory"; return nullptr; }
         w->c = c;
+        { std::lock_guard<std::mutex> lk(g_live_mu); live_comms().insert(c); }
         return w;
     } catch (...) { g_comm_err = "unexpected exception"; return nullptr; }
 }
@@ -1068,12 +1103,18 @@ int shk_comm_world(const shk_comm *c) { return c ? comm_world(c->c) : 0; }
 void shk_comm_free(shk_comm *c) {
     if (!c) return;
     DevGuard g(comm_device(c->c));
+    { std::lock_guard<std::mutex> lk(g_live_mu); live_comms().erase(c->c); }
     comm_destroy(c->c);
     delete c;
 }
 int shk_shard_preprocess(shk_handle *h, shk_comm *c, const void *d_bases, const void *d_seg_off, uint64_t n_seg,
                          uint64_t n_bases, uint64_t n_reads, uint32_t n_partitions) {
-    return guarded(h, Poison::AfterFirstBatch, [&] { return shard_preprocess_impl(h, c, d_bases, d_seg_off, n_seg, n_bases, n_reads, n_partitions); });
+    return guarded(h, Poison::AfterFirstBatch, [&] {
+        const int rc = shard_preprocess_impl(h, c, d_bases, d_seg_off, n_seg, n_bases, n_reads, n_partitions);
+        // a collective that failed on this rank alone: abort now, so that the peers' waits end (shard_comm.h: comm_stream_wait)
+        if (rc != SHK_OK && c && c->c && comm_broken(c->c)) comm_abort_now(c->c);
+        return rc;
+    });
 }
 int shk_plan_exchange(const uint64_t *part_records_all, uint32_t world, uint32_t n_partitions, uint32_t rank,
                       uint64_t *base, uint64_t *send_counts, uint64_t *recv_counts, uint64_t *run_off, uint32_t *run_cnt) {

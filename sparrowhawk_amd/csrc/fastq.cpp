@@ -2,7 +2,8 @@
 #include "fastq.h"
 #include "inflate_mt.h"
 
-#include <malloc.h>
+#include <sys/mman.h>
+#include <unordered_map>
 #include <stdlib.h>
 #include <string.h>
 #include <mutex>
@@ -18,8 +19,16 @@ namespace {
 struct BigPool {
     std::mutex mu;
     std::vector<std::pair<size_t, void *>> kept;          // (bytes, block)
+    std::unordered_map<void *, size_t> size_of;           // every big block alive (handed out or kept) -> its real size
     size_t kept_bytes = 0;
-    static constexpr size_t MIN_BIG = (size_t)4 << 20, KEEP_MAX = (size_t)12 << 30;
+    static constexpr size_t MIN_BIG = (size_t)4 << 20;
+    // what may stay cached per process: SHK_HOST_POOL_MAX bytes (default 4 GiB — the text of one .fastq.gz isolate with its
+    // marker buffers; a node runs one process per GPU, so eight of these)
+    size_t keep_max = [] {
+        const char *e = getenv("SHK_HOST_POOL_MAX");
+        if (e && *e) return (size_t)strtoull(e, nullptr, 10);
+        return (size_t)4 << 30;
+    }();
 };
 BigPool &big_pool() { static BigPool *p = new BigPool(); return *p; }     // never destroyed (process teardown order)
 inline size_t big_round(size_t bytes) { return (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1); }
@@ -27,8 +36,8 @@ inline size_t big_round(size_t bytes) { return (bytes + (((size_t)2 << 20) - 1))
 void *big_alloc(size_t bytes) {
     if (bytes < BigPool::MIN_BIG) return malloc(bytes ? bytes : 1);
     const size_t want = big_round(bytes);
+    BigPool &bp = big_pool();
     {
-        BigPool &bp = big_pool();
         std::lock_guard<std::mutex> lk(bp.mu);
         size_t best = (size_t)-1;
         for (size_t i = 0; i < bp.kept.size(); i++)
@@ -36,34 +45,37 @@ void *big_alloc(size_t bytes) {
         if (best != (size_t)-1) {
             void *p = bp.kept[best].second;
             bp.kept_bytes -= bp.kept[best].first;
-            // the block keeps its real size in a header-less way: callers free with THEIR size, so remember the real one
+            // (the block keeps its real size in size_of: callers free with THEIR size)
             bp.kept[best] = bp.kept.back(); bp.kept.pop_back();
             return p;
         }
     }
     void *p = aligned_alloc((size_t)2 << 20, want);
-    if (p) (void)madvise(p, want, MADV_HUGEPAGE);
+    if (!p) return nullptr;
+    (void)madvise(p, want, MADV_HUGEPAGE);
+    try { std::lock_guard<std::mutex> lk(bp.mu); bp.size_of[p] = want; }
+    catch (...) { free(p); return nullptr; }
     return p;
 }
 void big_free(void *p, size_t bytes) {
     if (!p) return;
     if (bytes < BigPool::MIN_BIG) { free(p); return; }
-    // (a recycled block may be larger than `bytes`: malloc_usable_size tells what it really holds)
-    const size_t real = malloc_usable_size(p) & ~(((size_t)2 << 20) - 1);
     BigPool &bp = big_pool();
     {
         std::lock_guard<std::mutex> lk(bp.mu);
-        if (real >= BigPool::MIN_BIG && bp.kept_bytes + real <= BigPool::KEEP_MAX && bp.kept.size() < 512) {
-            bp.kept.emplace_back(real, p); bp.kept_bytes += real;
-            return;
+        auto it = bp.size_of.find(p);
+        const size_t real = it != bp.size_of.end() ? it->second : 0;       // (recorded at allocation: a recycled block may be larger than `bytes`)
+        if (real >= BigPool::MIN_BIG && bp.kept_bytes + real <= bp.keep_max && bp.kept.size() < 512) {
+            try { bp.kept.emplace_back(real, p); bp.kept_bytes += real; return; } catch (...) {}
         }
+        if (it != bp.size_of.end()) bp.size_of.erase(it);
     }
     free(p);
 }
 void big_trim() {
     BigPool &bp = big_pool();
     std::lock_guard<std::mutex> lk(bp.mu);
-    for (auto &kv : bp.kept) free(kv.second);
+    for (auto &kv : bp.kept) { bp.size_of.erase(kv.second); free(kv.second); }
     bp.kept.clear(); bp.kept_bytes = 0;
 }
 

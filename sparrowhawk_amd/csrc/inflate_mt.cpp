@@ -233,16 +233,37 @@ bool find_block_start(const uint8_t *in, size_t n, uint64_t from, uint64_t limit
 
 std::atomic<uint64_t> g_members{0};
 
-template <typename F> void run_threads(unsigned T, F &&fn) {
+// fn(t) for t in [0, T) on T threads.  No exception leaves a worker (std::terminate) or this function with threads still
+// joinable: whatever is thrown — std::bad_alloc from a marker buffer on a host short of memory, a gzip bomb — is caught,
+// every thread is joined, and false comes back: the caller gives the member to zlib.
+template <typename F> bool run_threads(unsigned T, F &&fn) {
+    std::atomic<bool> failed{false};
+    auto safe = [&fn, &failed](unsigned t) { try { fn(t); } catch (...) { failed.store(true); } };
     std::vector<std::thread> ts;
-    for (unsigned t = 1; t < T; t++) ts.emplace_back([&fn, t] { fn(t); });
-    fn(0u);
+    try {
+        ts.reserve(T);
+        for (unsigned t = 1; t < T; t++) ts.emplace_back(safe, t);
+    } catch (...) {                                           // (a thread could not be started: its share stays undone)
+        failed.store(true);
+    }
+    safe(0u);
     for (auto &t : ts) t.join();
+    return !failed.load();
 }
 
 }  // namespace
 
+static int inflate_member_parallel_body(const uint8_t *in, size_t n, ByteVec &out, size_t out_at, size_t &consumed, unsigned threads);
+// 0 = the member is in `out`; 1 = not taken (the caller gives it to zlib: every unexpected turn ends here, out of host
+// memory included — no exception leaves this function)
 int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t out_at, size_t &consumed, unsigned threads) {
+    try { return inflate_member_parallel_body(in, n, out, out_at, consumed, threads); }
+    catch (...) {
+        try { if (out.size() > out_at) out.resize(out_at); } catch (...) {}
+        return 1;
+    }
+}
+static int inflate_member_parallel_body(const uint8_t *in, size_t n, ByteVec &out, size_t out_at, size_t &consumed, unsigned threads) {
     // ---- gzip member header (RFC 1952)
     if (n < 18 || in[0] != 0x1F || in[1] != 0x8B || in[2] != 8) return 1;
     const unsigned flg = in[3];
@@ -263,12 +284,12 @@ int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t ou
     // ---- 1. block starts
     std::vector<uint64_t> start(C, 0);
     std::vector<uint8_t> ok(C, 1);
-    run_threads(C, [&](unsigned c) {
+    if (!run_threads(C, [&](unsigned c) {
         if (c == 0) return;
         const uint64_t from = (uint64_t)(dn / C) * c * 8, limit = std::min<uint64_t>((uint64_t)(dn / C) * (c + 1) * 8, (uint64_t)dn * 8);
         uint64_t f = 0;
         if (find_block_start(def, dn, from, limit, f)) start[c] = f; else ok[c] = 0;
-    });
+    })) return 1;
     // (a chunk without a start is merged into its predecessor)
     std::vector<uint64_t> st; st.push_back(0);
     for (unsigned c = 1; c < C; c++) if (ok[c] && start[c] > st.back()) st.push_back(start[c]);
@@ -279,13 +300,13 @@ int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t ou
     std::vector<SymVec> sym(C);
     std::vector<Stop> how(C, Stop::Corrupt);
     std::vector<uint64_t> endpos(C, 0);
-    run_threads(C, [&](unsigned c) {
+    if (!run_threads(C, [&](unsigned c) {
         Bits b{def, dn};
         b.seek(st[c]);
         const uint64_t stop_at = c + 1 < C ? st[c + 1] : ~0ull;
         sym[c].reserve((size_t)((c + 1 < C ? st[c + 1] : (uint64_t)dn * 8) - st[c]) / 8 * 6 + 65536);   // (FASTQ text deflates 3-5x; a vector that runs out grows)
         how[c] = inflate_blocks(b, sym[c], c == 0, stop_at, false, &endpos[c]);
-    });
+    })) return 1;
     for (unsigned c = 0; c < C; c++) if (how[c] != (c + 1 < C ? Stop::AtStop : Stop::Final)) return 1;
     const double t2 = now();
     // ---- trailer
@@ -315,7 +336,7 @@ int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t ou
     const double t4 = now();
     std::vector<uint32_t> crc(C, 0);
     std::atomic<int> bad{0};
-    run_threads(C, [&](unsigned c) {
+    if (!run_threads(C, [&](unsigned c) {
         uint8_t *o = out.data() + out_at + off[c];
         const SymVec &s = sym[c];
         const uint8_t *w = c ? win[c].data() : nullptr;
@@ -327,7 +348,7 @@ int inflate_member_parallel(const uint8_t *in, size_t n, ByteVec &out, size_t ou
         for (size_t a = 0; a < s.size(); a += (size_t)1 << 30) cr = (uint32_t)crc32(cr, o + a, (uInt)std::min<size_t>(s.size() - a, (size_t)1 << 30));
         crc[c] = cr;
         SymVec().swap(sym[c]);
-    });
+    })) { out.resize(out_at); return 1; }
     if (bad.load()) { out.resize(out_at); return 1; }
     uint32_t total_crc = crc[0];
     for (unsigned c = 1; c < C; c++) total_crc = (uint32_t)crc32_combine(total_crc, crc[c], (z_off_t)(off[c + 1] - off[c]));

@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 #include <map>
+#include <memory>
 
 namespace shk {
 
@@ -92,8 +93,23 @@ public:
     virtual uint64_t n_solid_global() const = 0;
     virtual int shard_assemble(ShardComm *comm, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) = 0;
     virtual StageTimes &times() = 0;
+    // waits until nothing is in flight on the pipeline's streams (through the shard layer's watchdog while a collective call
+    // of several ranks runs); never fails — an error stays on the stream for the next call to find
+    virtual void drain() = 0;
     virtual void *stream() = 0;
     virtual int device() const = 0;                  // the HIP device this pipeline's stream and buffers live on
+};
+
+// Device buffers that go out of scope on the calling thread while this object lives are kept until it dies; then the
+// pipeline's stream is drained and they go back to the pool (see DevBuf in pipeline.hip).  One per entry point of the C ABI.
+class DeferScope {
+public:
+    explicit DeferScope(IPipeline *pipe);
+    ~DeferScope();
+    DeferScope(const DeferScope &) = delete;
+    DeferScope &operator=(const DeferScope &) = delete;
+private:
+    IPipeline *pipe_; void *list_; void *prev_;
 };
 
 // returns nullptr (and err) if no device / bad k
@@ -115,6 +131,15 @@ void *device_pool_alloc(size_t &bytes);
 // best rate (GB/s) of `iters` pure streaming reads of a `bytes` buffer on the current device
 int stream_read_gbs(size_t bytes, int iters, double *gbs, std::string &err);
 void device_pool_release(void *p, size_t bytes);
+// peak device memory per handle (Assembler.ts:69-71,137 reports peak wasm memory with every assembly): an accounting context
+// is made per handle, carried by the thread that serves it (mem_acct_set returns the previous one), and every block the pool
+// hands out meanwhile is charged to it until it goes back
+std::shared_ptr<void> mem_acct_new();
+std::shared_ptr<void> mem_acct_set(std::shared_ptr<void> a);
+uint64_t mem_acct_peak(const std::shared_ptr<void> &a);
+uint64_t mem_acct_current(const std::shared_ptr<void> &a);
+// the counter alone, on the host (tests): applies signed byte deltas, returns the high-water mark and what is left
+void mem_acct_replay(const int64_t *deltas, size_t n, uint64_t *peak, uint64_t *current);
 int device_stream_sync(void *stream, std::string &err);      // waits for a hipStream_t
 int device_copy_h2d_async(void *dst, const void *src, size_t bytes, void *stream, std::string &err);
 int device_download(void *host, const void *dptr, size_t bytes, std::string &err);      // blocking device -> host copy

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <map>
 #include <memory>
@@ -40,6 +41,14 @@ namespace shk {
             err = std::string(#call) + ": " + hipGetErrorString(_e);                      \
             return -5;                                                                    \
         }                                                                                 \
+    } while (0)
+// host wait on the pipeline's stream (inside Pipeline<W> methods with `err` in scope): during a collective call of more
+// than one rank the wait is the shard layer's watchdog (shard_comm.h: comm_stream_wait) — a peer that left or died cannot
+// hold this rank for ever
+#define WAIT_STREAM()                                                                     \
+    do {                                                                                  \
+        if (wd_comm_) { if (int _rc = comm_stream_wait(wd_comm_, stream_, err)) return _rc; } \
+        else HIPCHK(stream_wait(stream_));                                                \
     } while (0)
 
 static constexpr uint32_t NIL = 0xFFFFFFFFu;
@@ -110,10 +119,35 @@ namespace shk {
 // hipMalloc/hipFree of its multi-GB buffers cost more than the kernels (measured ~10 ms/step).
 // Blocks are returned here on release and reused by the next handle; shk_release_cached_memory()
 // gives them back to the driver.
+// Peak device memory of a handle (the reference reports peak wasm memory with every assembly: Assembler.ts:69-71,137).
+// Every block the pool hands out is charged to the accounting context the calling thread carries (set by the C ABI's entry
+// points for the handle they serve) and released from the context it was charged to, whichever thread gives it back.
+struct MemAcct {
+    std::atomic<uint64_t> cur{0}, peak{0};
+    void add(uint64_t b) { const uint64_t c = cur.fetch_add(b) + b; uint64_t p = peak.load(); while (c > p && !peak.compare_exchange_weak(p, c)) {} }
+    void sub(uint64_t b) { cur.fetch_sub(b); }
+};
+static thread_local std::shared_ptr<MemAcct> tls_mem_acct;
+std::shared_ptr<void> mem_acct_new() { return std::static_pointer_cast<void>(std::make_shared<MemAcct>()); }
+std::shared_ptr<void> mem_acct_set(std::shared_ptr<void> a) {
+    std::shared_ptr<void> prev = std::static_pointer_cast<void>(tls_mem_acct);
+    tls_mem_acct = std::static_pointer_cast<MemAcct>(a);
+    return prev;
+}
+uint64_t mem_acct_peak(const std::shared_ptr<void> &a) { return a ? std::static_pointer_cast<MemAcct>(a)->peak.load() : 0; }
+uint64_t mem_acct_current(const std::shared_ptr<void> &a) { return a ? std::static_pointer_cast<MemAcct>(a)->cur.load() : 0; }
+void mem_acct_replay(const int64_t *deltas, size_t n, uint64_t *peak, uint64_t *current) {
+    MemAcct a;
+    for (size_t i = 0; i < n; i++) { if (deltas[i] >= 0) a.add((uint64_t)deltas[i]); else a.sub((uint64_t)(-deltas[i])); }
+    if (peak) *peak = a.peak.load();
+    if (current) *current = a.cur.load();
+}
+
 struct DevPool {
     std::mutex mu;
     std::multimap<std::pair<int, size_t>, void *> free_blocks;     // (device, bytes) -> block
-    std::map<void *, int> owner_dev;                               // every block handed out -> the device it lives on
+    struct Out { int dev; std::shared_ptr<MemAcct> acct; };
+    std::map<void *, Out> owner_dev;                               // every block handed out -> the device it lives on, who pays for it
     bool enabled = true;
     DevPool() { const char *v = getenv("SHK_NO_POOL"); enabled = !(v && *v == '1'); }
     static int cur_dev() { int d = 0; (void)hipGetDevice(&d); return d; }
@@ -122,11 +156,14 @@ struct DevPool {
         // big scratch buffers vary a little from handle to handle: round them up so the cached block fits again
         if (bytes > ((size_t)256 << 20)) bytes = (bytes + ((size_t)256 << 20) - 1) & ~(((size_t)256 << 20) - 1);
         const int dev = cur_dev();
+        const std::shared_ptr<MemAcct> &acct = tls_mem_acct;
         if (enabled) {
             std::lock_guard<std::mutex> lk(mu);
             auto it = free_blocks.lower_bound(std::make_pair(dev, bytes));
             if (it != free_blocks.end() && it->first.first == dev && it->first.second <= bytes + bytes / 2 + (1u << 20)) {
-                void *p = it->second; bytes = it->first.second; free_blocks.erase(it); owner_dev[p] = dev; e = hipSuccess; return p;
+                void *p = it->second; bytes = it->first.second; free_blocks.erase(it); owner_dev[p] = Out{dev, acct}; e = hipSuccess;
+                if (acct) acct->add(bytes);
+                return p;
             }
         }
         void *p = nullptr;
@@ -135,18 +172,18 @@ struct DevPool {
             trim();
             e = hipMalloc(&p, bytes);
         }
-        if (e == hipSuccess && enabled) { std::lock_guard<std::mutex> lk(mu); owner_dev[p] = dev; }
+        if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); owner_dev[p] = Out{dev, acct}; if (acct) acct->add(bytes); }
         return e == hipSuccess ? p : nullptr;
     }
     // a block goes back under the device it was allocated on, whatever device the calling thread has current
     // (an FFI consumer may free a handle from another thread: the HIP current device is per thread)
     void put(void *p, size_t bytes) {
         if (!p) return;
-        if (!enabled) { (void)hipFree(p); return; }
         std::lock_guard<std::mutex> lk(mu);
         auto it = owner_dev.find(p);
-        const int dev = it != owner_dev.end() ? it->second : cur_dev();
-        if (it != owner_dev.end()) owner_dev.erase(it);
+        const int dev = it != owner_dev.end() ? it->second.dev : cur_dev();
+        if (it != owner_dev.end()) { if (it->second.acct) it->second.acct->sub(bytes); owner_dev.erase(it); }
+        if (!enabled) { (void)hipFree(p); return; }
         free_blocks.emplace(std::make_pair(dev, bytes), p);
     }
     void trim() {
@@ -160,12 +197,23 @@ void device_pool_trim() { dev_pool().trim(); }
 void *device_pool_alloc(size_t &bytes) { hipError_t e; return dev_pool().get(bytes, e); }
 void device_pool_release(void *p, size_t bytes) { dev_pool().put(p, bytes); }
 
+// A DevBuf that goes out of scope while an entry point of the C ABI runs is parked until that entry point has drained the
+// handle's stream (DeferScope, pipeline.h): an early `return rc` may destroy buffers that kernels, collectives or copies
+// still in flight use, and the pool hands a freed block to whichever handle asks next (two handles in flight: batch.py).
+// Explicit release() calls — made where the code knows the stream is idle — go to the pool at once.
+static thread_local std::vector<std::pair<void *, size_t>> *tls_defer = nullptr;
 template <typename T> struct DevBuf {
     T *p = nullptr; size_t n = 0; size_t bytes = 0;
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
-    ~DevBuf() { release(); }
+    ~DevBuf() {
+        if (p && tls_defer) {
+            try { tls_defer->push_back(std::make_pair((void *)p, bytes)); p = nullptr; n = 0; bytes = 0; return; }
+            catch (...) {}                                 // (no room for the note: give the block back now)
+        }
+        release();
+    }
     void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(bytes, o.bytes); }
     void release() { if (p) { dev_pool().put(p, bytes); p = nullptr; n = 0; bytes = 0; } }
     int alloc(size_t count, std::string &err) {
@@ -199,6 +247,23 @@ struct PinnedBuf {
         bytes = b; return 0;
     }
 };
+
+DeferScope::DeferScope(IPipeline *pipe) : pipe_(pipe) {
+    auto *v = new (std::nothrow) std::vector<std::pair<void *, size_t>>();
+    if (v) { try { v->reserve(256); } catch (...) {} }
+    list_ = v; prev_ = tls_defer; tls_defer = v;
+}
+DeferScope::~DeferScope() {
+    auto *v = (std::vector<std::pair<void *, size_t>> *)list_;
+    tls_defer = (std::vector<std::pair<void *, size_t>> *)prev_;
+    if (!v) return;
+    if (!v->empty()) {
+        if (pipe_) pipe_->drain();                        // nothing in flight reads or writes the parked blocks any more
+        else (void)hipDeviceSynchronize();
+        for (auto &b : *v) dev_pool().put(b.first, b.second);
+    }
+    delete v;
+}
 
 // streams of freed handles are reused too (create + destroy cost ~0.2 ms per handle); every use of a
 // handle's stream ends in a synchronize, so a pooled stream is idle
@@ -300,6 +365,7 @@ template <int W> class Pipeline : public IPipeline {
 public:
     explicit Pipeline(int k) : k_(k) {}
     ~Pipeline() override {
+        drain();                                            // (the member buffers go back to the pool idle)
         EvTimer::resolve(pending_timers_, times_);
         if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
         if (stream_) stream_pool_put(stream_dev_, stream_);
@@ -313,6 +379,13 @@ public:
         return 0;
     }
     StageTimes &times() override { EvTimer::resolve(pending_timers_, times_); return times_; }
+    void drain() override {
+        if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+        if (!stream_) return;
+        std::string e;
+        if (wd_comm_) (void)comm_stream_wait(wd_comm_, stream_, e);
+        else (void)hipStreamSynchronize(stream_);
+    }
     void *stream() override { return (void *)stream_; }
     int device() const override { return stream_dev_; }
     uint64_t total_instances() const override { return total_instances_; }
@@ -361,7 +434,7 @@ public:
             double ms = t.stop();
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             if ((uint32_t)h[1] == 0) {
                 times_.add("count_kernel", ms);
                 total_instances_ += h[0];
@@ -494,7 +567,7 @@ public:
                 t.mark();
                 unsigned long long h[2];
                 HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
-                HIPCHK(stream_wait(stream_));
+                WAIT_STREAM();
                 times_.add("h2d_pieces_x1", (double)C);
                 const uint32_t *fl = (const uint32_t *)&h[0];
                 if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
@@ -512,7 +585,7 @@ public:
             t.mark();
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));          // (one host round trip: flags and the timer together)
+            WAIT_STREAM();          // (one host round trip: flags and the timer together)
             const double ms = t.elapsed();
             const uint32_t *fl = (const uint32_t *)&h[0];
             if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
@@ -556,7 +629,7 @@ public:
         HIPCHK(hipGetLastError());
         std::vector<unsigned long long> h(pp_.P);
         HIPCHK(hipMemcpyAsync(h.data(), tot.p, (size_t)pp_.P * 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         std::unique_ptr<BatchRecs> b(new BatchRecs());
         b->part_off.assign(pp_.P + 1, 0);
         for (uint32_t p = 0; p < pp_.P; p++) b->part_off[p + 1] = b->part_off[p] + h[p];
@@ -566,7 +639,7 @@ public:
         hipLaunchKernelGGL((k_pack_partition<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, recs_.p, fill_.p, pp_, base.p, b->dense.p);
         HIPCHK(hipGetLastError());
         times_.add("batch_pack_kernel", t.stop());
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         batches_.push_back(std::move(b));
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
         if (batches_.size() >= env_u64("SHK_MERGE_BATCHES_AT", 192)) return merge_batches(err);
@@ -595,7 +668,7 @@ public:
         hipLaunchKernelGGL((k_merge_runs<RW>), dim3(pp_.P), dim3(256), 0, stream_, run_view_, base.p, m->dense.p);
         HIPCHK(hipGetLastError());
         times_.add("batch_merge_kernel", t.stop());
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         batches_.clear();
         batches_.push_back(std::move(m));
         run_off_.release(); run_cnt_.release(); have_parts_ = false;
@@ -625,7 +698,7 @@ public:
         if (int rc = run_cnt_.alloc(n_runs, err)) return rc;
         HIPCHK(hipMemcpyAsync(run_off_.p, addr16.data(), n_runs * 8, hipMemcpyHostToDevice, stream_));
         HIPCHK(hipMemcpyAsync(run_cnt_.p, cnt.data(), n_runs * 4, hipMemcpyHostToDevice, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         run_view_.run_addr16 = run_off_.p; run_view_.run_cnt = run_cnt_.p;
         run_view_.S = nb; run_view_.k = k_; n_count_parts_ = pp_.P; run_view_.dbg = 0;
         have_parts_ = true;
@@ -726,7 +799,7 @@ public:
             unsigned long long h[4];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));   // (final unless partitions overflowed)
-            HIPCHK(stream_wait(stream_));          // one host round trip: counters, histogram and the timer
+            WAIT_STREAM();          // one host round trip: counters, histogram and the timer
             ms_out = split ? t_split.elapsed() : t.elapsed();      // (dedupe + count)
             const uint32_t n_ovf = (uint32_t)h[3];
             // rows written by the bucket path are ordered by key hash, not grouped by minimiser partition (build_graph regroups)
@@ -795,7 +868,7 @@ public:
                     if (bloom) HIPCHK(hipMemcpyAsync(newc.data(), d_new.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipMemcpyAsync(mxf.data(), d_maxfill.p, (size_t)ni * 4, hipMemcpyDeviceToHost, stream_));
                     HIPCHK(hipMemcpyAsync(&n_list, ctl_.p + 4, sizeof n_list, hipMemcpyDeviceToHost, stream_));
-                    HIPCHK(stream_wait(stream_));
+                    WAIT_STREAM();
                     std::vector<OvfItem> again;
                     uint32_t n_good = 0;
                     for (uint32_t i = 0; i < ni; i++) {
@@ -818,7 +891,7 @@ public:
                                            ctl_.p + 0, ctl_.p + 1, (uint32_t *)(ctl_.p + 2), env_dbg("SHK_DEBUG_B"),
                                            bloom ? 1u : 0u, ctl_.p + 9);
                         HIPCHK(hipGetLastError());
-                        HIPCHK(stream_wait(stream_));      // d_items / d_kmers are reused by the next pass
+                        WAIT_STREAM();      // d_items / d_kmers are reused by the next pass
                     }
                     n_good_total += n_good;
                     items.swap(again);
@@ -837,7 +910,7 @@ public:
                 times_.add("count_residue_rerun_x1", (double)bad.size());
                 HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
-                HIPCHK(stream_wait(stream_));
+                WAIT_STREAM();
                 times_.add("count_bucket_splits_x1", (double)(h[2] >> 32));
                 if (bloom) {
                     // k-mers the filter took as new: each is one distinct k-mer (less the false positives) and one
@@ -910,7 +983,7 @@ public:
             times_.add("histogram_kernel", t.stop());
         }
         HIPCHK(hipMemcpyAsync(histo, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         n_distinct_ = 0;
         for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
         return 0;
@@ -935,7 +1008,7 @@ public:
         HIPCHK(hipGetLastError());
         unsigned long long got = 0;
         HIPCHK(hipMemcpyAsync(&got, ctl_.p, 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         if (got != expect) { err = "compaction count mismatch"; return -6; }
         return 0;
     }
@@ -966,7 +1039,7 @@ public:
             HIPCHK(hipGetLastError());
             unsigned long long got = 0;
             HIPCHK(hipMemcpyAsync(&got, ctl_.p, 8, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             if (got != expect) { err = "row compaction count mismatch"; return -6; }
             for (int j = 0; j < W; j++) ekeys_[j].release();
             ecnt_.release();
@@ -1029,7 +1102,7 @@ public:
         HIPCHK(hipGetLastError());
         std::vector<unsigned long long> h(pp_.P);
         HIPCHK(hipMemcpyAsync(h.data(), tot.p, (size_t)pp_.P * 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         for (uint32_t p = 0; p < pp_.P; p++) part_records[p] = h[p];
         return 0;
     }
@@ -1046,7 +1119,7 @@ public:
                            (uint64_t *)d_send);
         HIPCHK(hipGetLastError());
         times_.add("shard_pack_kernel", t.stop());
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         // the local slices are no longer needed once packed
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
         return 0;
@@ -1075,7 +1148,7 @@ public:
         t.mark();
         std::vector<uint32_t> h(pp_.P);
         HIPCHK(hipMemcpyAsync(h.data(), dd_n_.p, (size_t)pp_.P * 4, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         times_.add("shard_dedupe_kernel", t.elapsed());
         unsigned long long n_dd = 0;
         for (uint32_t p = 0; p < pp_.P; p++) { part_records[p] = h[p]; n_dd += h[p]; }
@@ -1096,7 +1169,7 @@ public:
                            (uint64_t *)d_send, (uint32_t *)d_send_w);
         HIPCHK(hipGetLastError());
         times_.add("shard_pack_kernel", t.stop());
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         shard_drop_dedup();
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
         return 0;
@@ -1158,7 +1231,7 @@ public:
         }
         if (int rc = nc.alloc(n, err)) return rc;
         if (n) HIPCHK(hipMemcpyAsync(nc.p, cnt, n * 4, hipMemcpyDeviceToDevice, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         for (int j = 0; j < W; j++) skeys_[j].swap(nk[j]);
         scnt_.swap(nc);
         n_solid_ = n; total_instances_ = total_instances; n_distinct_ = 0;
@@ -1245,7 +1318,7 @@ public:
                 hipLaunchKernelGGL(k_regroup_rows<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, scnt_.p, gp_of.p, gp_rows.p, (uint32_t)n,
                                    out_keys, nc.p, ngp.p);
                 HIPCHK(hipGetLastError());
-                HIPCHK(stream_wait(stream_));                          // (the old arrays go back to the pool below)
+                WAIT_STREAM();                          // (the old arrays go back to the pool below)
                 for (int j = 0; j < W; j++) skeys_[j].swap(nk[j]);
                 scnt_.swap(nc); gp_of.swap(ngp);
                 g = graph_view();
@@ -1282,7 +1355,7 @@ public:
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
             unsigned long long h[3];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             if ((uint32_t)h[1] || h[2] > gt_slots_) { err = "graph table overflow"; return -6; }
         }
         graph_ready_ = true;
@@ -1292,7 +1365,7 @@ public:
     int read_ctl(unsigned int &v, int slot, std::string &err) {
         unsigned long long h = 0;
         HIPCHK(hipMemcpyAsync(&h, ctl_.p + slot, 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         v = (unsigned int)h;
         return 0;
     }
@@ -1358,7 +1431,7 @@ public:
             }
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p + 5, sizeof h, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             const unsigned int n1 = (unsigned int)h[0], n2 = (unsigned int)h[1];
             tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
             if (n1 + n2 == 0) break;
@@ -1489,7 +1562,7 @@ public:
         heads.assign(HEADS_SPEC, HeadRec());
         HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
         HIPCHK(hipMemcpyAsync(heads.data(), cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
@@ -1531,7 +1604,7 @@ public:
             HIPCHK(hipMemcpyAsync(&last[1], off.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(&last[2], fl.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(&last[3], idx.p + (nh - 1), 8, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             const uint64_t out_bytes2 = last[0] + last[1], n_emit = last[2] + last[3];
             if (n_emit >= 0x7FFFFFF0ull) { err = "device writer: too many contigs"; return -1; }
             if (int rc = d_off2.alloc(nh, err)) return rc;
@@ -1574,7 +1647,7 @@ public:
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
             HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             out.reserve(emitted.size());
             for (uint32_t i : emitted) {
                 RawContig rc; rc.kc = heads[i].kc;
@@ -1633,7 +1706,7 @@ public:
         HIPCHK(hipGetLastError());
         unsigned int h_cnt[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(h_cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         if (h_cnt[2]) { err = "device writer: the graph and the chains disagree about a link (" + std::to_string(h_cnt[2]) + ")"; return -6; }
         if (h_cnt[0] > link_cap) { err = "device writer: more links than 8 per contig"; return -6; }
         uint32_t nl = h_cnt[0];
@@ -1647,7 +1720,7 @@ public:
             if (tmp.n < bytes) if (int rc = tmp.alloc(bytes + 256, err)) return rc;
             HIPCHK(hipcub::DeviceSelect::Unique(tmp.p, bytes, links2.p, links.p, d_cnt.p + 1, (int)nl, stream_));
             HIPCHK(hipMemcpyAsync(h_cnt, d_cnt.p, 16, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             nl = h_cnt[1];
         }
         // ---- sizes and offsets of the records
@@ -1675,7 +1748,7 @@ public:
                 HIPCHK(hipMemcpyAsync(&last[2 * q], so[q][0]->p + (cnt - 1), 8, hipMemcpyDeviceToHost, stream_));
                 HIPCHK(hipMemcpyAsync(&last[2 * q + 1], so[q][1]->p + (cnt - 1), 8, hipMemcpyDeviceToHost, stream_));
             }
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
         }
         u64 sect[7];
         for (int q = 0; q < 7; q++) sect[q] = last[2 * q] + last[2 * q + 1];
@@ -1700,7 +1773,7 @@ public:
         times_.add("device_writer_kernels", tw.stop());
         const double t0 = now_ms_();
         HIPCHK(hipMemcpyAsync(hjson_.p, d_js.p, total + 1, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         times_.add("device_writer_d2h_host_clock", now_ms_() - t0);
         times_.add("device_writer_json_MB", (double)total / 1e6);
         times_.add("device_writer_links_x1e-3", nl * 1e-3);
@@ -1741,28 +1814,43 @@ public:
                        uint64_t extra = 0, std::vector<uint64_t> *extra_all = nullptr) {
         const uint32_t world = sh_world_;
         const uint32_t row = world + 1;
-        if (int rc = rt_row_.alloc(ROUTE_MAX_WORLD + 1, err)) return rc;
-        if (int rc = rt_all_.alloc((size_t)row * world + 1, err)) return rc;
-        if (int rc = rt_cur_.alloc(ROUTE_MAX_WORLD, err)) return rc;
+        constexpr uint64_t LOCAL_FAIL = 1ull << 63;       // in the word that rides along: "this rank could not stage its records"
+        // Everything this rank can allocate before the sizes are known is allocated first (the send buffer from its upper
+        // bound): a failure here still travels with the size exchange and every rank leaves together.
+        int rc_local = 0;
+        if ((rc_local = rt_row_.alloc(ROUTE_MAX_WORLD + 1, err))) return rc_local;     // (a few hundred bytes, also needed to say so)
+        if ((rc_local = rt_all_.alloc((size_t)row * world + 1, err))) return rc_local;
+        if (!rc_local) rc_local = rt_cur_.alloc(ROUTE_MAX_WORLD, err);
+        if (!rc_local) rc_local = r.sidx.alloc(n_items, err);
+        if (!rc_local) rc_local = r.send.alloc((size_t)n_items * PW + 1, err);
+        if (rc_local) { n_items = 0; extra |= LOCAL_FAIL; }
         HIPCHK(hipMemsetAsync(rt_row_.p, 0, (ROUTE_MAX_WORLD + 1) * 8, stream_));
         if (n_items) {
             hipLaunchKernelGGL(k_route_count, dim3(grid_for(n_items)), dim3(256), 0, stream_, dest, n_items, rt_row_.p);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipMemcpyAsync(rt_row_.p + world, &extra, 8, hipMemcpyHostToDevice, stream_));
+        rt_extra_host_ = extra;                               // (a member: the asynchronous copy reads it after this line)
+        HIPCHK(hipMemcpyAsync(rt_row_.p + world, &rt_extra_host_, 8, hipMemcpyHostToDevice, stream_));
         if (int rc = comm_allgather(c, rt_row_.p, rt_all_.p, (size_t)row * 8, stream_, err)) return rc;
         std::vector<uint64_t> all((size_t)row * world);
         HIPCHK(hipMemcpyAsync(all.data(), rt_all_.p, all.size() * 8, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
+        times_.add("shard_host_waits_x1", 1.0);
+        bool peer_failed = false;
+        for (uint32_t s = 0; s < world; s++) if (all[(size_t)s * row + world] & LOCAL_FAIL) peer_failed = true;
+        if (peer_failed) {                                    // every rank sees the same row: all leave here
+            sh_agreed_ = true;
+            if (rc_local) return rc_local;
+            err = "sharded assembly: another rank ran out of device memory while staging an exchange"; return -5;
+        }
         r.send_cnt.assign(world, 0); r.recv_cnt.assign(world, 0); r.n_send = 0; r.n_recv = 0;
         std::vector<unsigned long long> &cur = rt_cur_host_;           // (a member: the asynchronous copy below may read it after this call has returned)
         cur.assign(ROUTE_MAX_WORLD, 0);
         for (uint32_t d = 0; d < world; d++) { r.send_cnt[d] = all[(size_t)sh_rank_ * row + d]; cur[d] = r.n_send; r.n_send += r.send_cnt[d]; }
         for (uint32_t s = 0; s < world; s++) { r.recv_cnt[s] = all[(size_t)s * row + sh_rank_]; r.n_recv += r.recv_cnt[s]; }
-        if (extra_all) { extra_all->assign(world, 0); for (uint32_t s = 0; s < world; s++) (*extra_all)[s] = all[(size_t)s * row + world]; }
-        if (int rc = r.send.alloc(r.n_send * PW + 1, err)) return rc;
+        if (extra_all) { extra_all->assign(world, 0); for (uint32_t s = 0; s < world; s++) (*extra_all)[s] = all[(size_t)s * row + world] & ~LOCAL_FAIL; }
+        // (the receive buffer can only be sized now: a failure here is this rank's alone — shard_assemble aborts the communicator)
         if (int rc = r.recv.alloc(r.n_recv * PW + 1, err)) return rc;
-        if (int rc = r.sidx.alloc(n_items, err)) return rc;
         if (n_items) {
             HIPCHK(hipMemcpyAsync(rt_cur_.p, cur.data(), ROUTE_MAX_WORLD * 8, hipMemcpyHostToDevice, stream_));
             hipLaunchKernelGGL((k_route_pack<PW>), dim3((n_items + ROUTE_CH - 1) / ROUTE_CH), dim3(256), 0, stream_, dest, pay, n_items,
@@ -1787,7 +1875,20 @@ public:
         return comm_alltoallv(c, ans, so.data(), sb.data(), back.p, ro.data(), rb.data(), stream_, err);
     }
 
+    // Collective.  Every way out leaves the ranks in step: a local failure travels with the next size exchange or agreement
+    // round and all ranks return an error together (sh_agreed_); a failure nobody else can know of (device memory that runs
+    // out after the sizes were agreed, a HIP error, a collective that fails) aborts the communicator at once, so that the
+    // peers' watchdogs (comm_stream_wait) end their waits instead of blocking for ever, and shk_comm_free does not block.
     int shard_assemble(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) override {
+        sh_agreed_ = false;
+        wd_comm_ = (c && comm_world(c) > 1) ? c : nullptr;
+        const int rc = shard_assemble_impl(c, tips, bubbles, out, err);
+        if (rc && wd_comm_ && !sh_agreed_) comm_abort_now(c);
+        drain();                                           // (through the watchdog: the stream may hold collectives of a call that failed)
+        wd_comm_ = nullptr;
+        return rc;
+    }
+    int shard_assemble_impl(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) {
         // SHK_STAGE_LOG=1: after every step the stream is drained and the step's name goes to stderr (which step a fault belongs to)
         const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;
         auto stage = [&](const char *what) {
@@ -1806,6 +1907,7 @@ public:
             uint64_t f = local_rc ? 1u : 0u;
             std::string e2;
             if (int rc = comm_allreduce_host_u64(c, &f, 1, stream_, e2)) { if (local_rc) return local_rc; err = e2; return rc; }
+            if (f) sh_agreed_ = true;                        // (every rank has seen the flag and leaves)
             if (local_rc) return local_rc;
             if (f) { err = std::string("sharded assembly: another rank failed during ") + stage; return -5; }
             return 0;
@@ -1828,8 +1930,8 @@ public:
             std::vector<uint64_t> flags;
             const int rc_x = rc_local ? rc_local : 0;
             if (int rc = route_exchange<W + 1>(c, xq_dest_.p, xq_pay_.p, rc_x ? 0u : xq_n_, rq, err, rc_x ? 1u : 0u, &flags)) { if (rc_x) return rc_x; return rc; }
-            if (rc_x) return rc_x;
-            for (uint64_t f : flags) if (f) { err = "sharded assembly: another rank failed during the local graph build"; return -5; }
+            if (rc_x) { sh_agreed_ = true; return rc_x; }
+            for (uint64_t f : flags) if (f) { sh_agreed_ = true; err = "sharded assembly: another rank failed during the local graph build"; return -5; }
             if (int rc = xans.alloc(rq.n_recv + 1, err)) return rc;
             if (rq.n_recv) {
                 hipLaunchKernelGGL(k_xq_answer<W>, dim3(grid_for(rq.n_recv)), dim3(256), 0, stream_, g.keys, g.gt, rq.recv.p, rq.n_recv, gbase, xans.p);
@@ -1880,12 +1982,12 @@ public:
             uint64_t mine[2] = {rc_chain ? 0u : n_lch, rc_chain ? 1u : 0u};
             std::vector<uint64_t> all2((size_t)world * 2);
             if (int rc = comm_allgather_host_u64(c, mine, 2, all2.data(), stream_, err)) { if (rc_chain) return rc_chain; return rc; }
-            if (rc_chain) return rc_chain;
-            for (uint32_t r = 0; r < world; r++) { if (all2[2 * r + 1]) { err = "sharded assembly: another rank failed during the local contraction"; return -5; } lcnt[r] = all2[2 * r]; }
+            if (rc_chain) { sh_agreed_ = true; return rc_chain; }
+            for (uint32_t r = 0; r < world; r++) { if (all2[2 * r + 1]) { sh_agreed_ = true; err = "sharded assembly: another rank failed during the local contraction"; return -5; } lcnt[r] = all2[2 * r]; }
             for (uint32_t r = 0; r < world; r++) lbase[r + 1] = lbase[r] + lcnt[r];
         }
         const uint64_t M = lbase[world];
-        if (M >= 0xFFFFFFF0ull) { err = "sharded assembly: more than 2^32 local chains"; return -1; }
+        if (M >= 0xFFFFFFF0ull) { sh_agreed_ = true; err = "sharded assembly: more than 2^32 local chains"; return -1; }      // (the same sum on every rank)
         DevBuf<SegRec> lsegs, gsegs;
         DevBuf<unsigned long long> d_gbases;
         if (int rc = lsegs.alloc(n_lch + 1, err)) return rc;
@@ -1948,7 +2050,7 @@ public:
             unsigned long long h_fl = 0;
             HIPCHK(hipMemcpyAsync(hM2, d_M.p, 8, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(&h_fl, ctl_.p + 13, 8, hipMemcpyDeviceToHost, stream_));      // (flags of k_hl_apply / k_ls_answer, read with the counts)
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
             // (these flags are LOCAL: the verdict must be every rank's — a rank that left alone would leave the others in the
             // next collective and itself one collective ahead for the rest of the process)
             int rc_fl = 0;
@@ -1977,7 +2079,8 @@ public:
         {
             std::vector<uint32_t> slot_at((size_t)M + 1, 0xFFFFFFFFu);
             for (uint32_t i = 0; i < n_u; i++) {
-                if (uheads[i].root >= M || slot_at[uheads[i].root] != 0xFFFFFFFFu) { err = "sharded assembly: two unitigs with one first chain"; return -6; }
+                // (the gathered records and their ranking are the same on every rank: so is this verdict)
+                if (uheads[i].root >= M || slot_at[uheads[i].root] != 0xFFFFFFFFu) { sh_agreed_ = true; err = "sharded assembly: two unitigs with one first chain"; return -6; }
                 slot_at[uheads[i].root] = i;
             }
             uint32_t at = 0;
@@ -2011,7 +2114,7 @@ public:
             }
             if (int rc = comm_allreduce_u64(c, d_ends.p, ends_words, stream_, err)) return rc;     // (every word is written by exactly one rank)
             HIPCHK(hipMemcpyAsync(h_ends.data(), d_ends.p, ends_words * 8, hipMemcpyDeviceToHost, stream_));
-            HIPCHK(stream_wait(stream_));
+            WAIT_STREAM();
         }
         lap("ends");
         std::vector<UnitigRec> recs(n_u);
@@ -2029,7 +2132,7 @@ public:
         // (the same code on the same records: it fails on every rank or on none — an agreement round is only paid where the
         // graph is large enough for one host to run out of memory alone)
         if (n_u >= (1u << 20)) { if (int rc = agree(rc_ug ? -6 : 0, "the unitig graph")) return rc; }
-        else if (rc_ug) return -6;
+        else if (rc_ug) { sh_agreed_ = true; return -6; }
         tips_removed_ = res.tips_removed; bubbles_removed_ = res.bubbles_removed; rounds_ = res.rounds;
         // rings: the smallest k-mer of their records — a pass over the nodes of the rings, on every rank, merged on the host
         if (!res.need_min.empty()) {
@@ -2051,7 +2154,7 @@ public:
                 hipLaunchKernelGGL(k_sring_min1<W>, dim3(grid_for(2ull * n)), dim3(256), 0, stream_, g, cs.ol.p, ring_of.p, pmin.p);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(h_pmin.data(), pmin.p, (size_t)n_rings * 8, hipMemcpyDeviceToHost, stream_));
-                HIPCHK(stream_wait(stream_));
+                WAIT_STREAM();
             }
             if (int rc = comm_allgather_host_u64(c, h_pmin.data(), n_rings, all_pmin.data(), stream_, err)) return rc;
             for (uint32_t i = 0; i < n_rings; i++) for (uint32_t r = 0; r < world; r++) h_pmin[i] = std::min(h_pmin[i], all_pmin[(size_t)r * n_rings + i]);
@@ -2062,7 +2165,7 @@ public:
                 hipLaunchKernelGGL(k_sring_report<W>, dim3(grid_for(n_rings)), dim3(256), 0, stream_, g, cs.ol.p, fin.p, (uint32_t)lbase[rank], vmin.p, n_rings, rep.p);
                 HIPCHK(hipGetLastError());
                 HIPCHK(hipMemcpyAsync(h_rep.data(), rep.p, h_rep.size() * 8, hipMemcpyDeviceToHost, stream_));
-                HIPCHK(stream_wait(stream_));
+                WAIT_STREAM();
             }
             if (int rc = comm_allgather_host_u64(c, h_rep.data(), h_rep.size(), all_rep.data(), stream_, err)) return rc;
             std::vector<UnitigMinKey> mk(n_u);
@@ -2084,7 +2187,7 @@ public:
                 mk[res.need_min[i]] = best;
             }
             int rc_rr = unitig_resolve_rings(k_, recs, mk, res, err);
-            if (rc_rr) return -6;                       // (deterministic on identical input: every rank takes the same way out)
+            if (rc_rr) { sh_agreed_ = true; return -6; }      // (deterministic on identical input: every rank takes the same way out)
         }
         lap("rings");
         // layout: contig text offsets, and for every unitig record where its nodes go
@@ -2132,7 +2235,7 @@ public:
             HIPCHK(hipMemcpyAsync(hout_.p, d_text.p, text_bytes, hipMemcpyDeviceToHost, stream_));
         }
         stage("6 emission kernels");
-        HIPCHK(stream_wait(stream_));
+        WAIT_STREAM();
         times_.add("shard_graph_emit", te.stop());
         out.reserve(res.contigs.size());
         for (size_t i = 0; i < res.contigs.size(); i++) {
@@ -2159,6 +2262,8 @@ private:
     int k_;
     hipStream_t stream_ = nullptr; int stream_dev_ = 0;
     hipStream_t copy_stream_ = nullptr;              // uploads that overlap pass 1 (count_batch_host)
+    ShardComm *wd_comm_ = nullptr;                   // set while a collective call of several ranks runs: host waits go through its watchdog
+    bool sh_agreed_ = false;                         // shard_assemble: the error it is about to return is known to every rank
     StageTimes times_;
     std::vector<EvTimer::Pending> pending_timers_;
     int n_cus_ = 256;
@@ -2207,6 +2312,7 @@ private:
     DevBuf<uint32_t> xq_dest_; DevBuf<uint64_t> xq_pay_; DevBuf<unsigned long long> xq_meta_;
     DevBuf<unsigned long long> rt_row_, rt_all_, rt_cur_;   // the router's small buffers (kept: no wait for their sake)
     std::vector<unsigned long long> rt_cur_host_;
+    uint64_t rt_extra_host_ = 0;
 };
 
 int current_device() { int d = 0; (void)hipGetDevice(&d); return d; }

@@ -27,6 +27,16 @@ int comm_device(const ShardComm *c);
 // instead of destroying it, so peers blocked in a collective fail fast
 void comm_mark_broken(ShardComm *c);
 std::string comm_async_error(ShardComm *c);           // ncclCommGetAsyncError as text; "" when there is none
+// A rank that leaves a collective call ALONE (a local failure nobody else knows of: out of device memory after the sizes
+// were agreed, a HIP error) aborts the communicator at once: its own queued collectives are cancelled, shk_comm_free will not
+// block, and peers see the failure through RCCL's asynchronous error or, at the latest, through the watchdog below.
+void comm_abort_now(ShardComm *c);
+bool comm_broken(const ShardComm *c);
+// Host wait of the shard layer: polls `stream`, looks at RCCL's asynchronous error every few milliseconds, and gives up
+// after SHK_COMM_TIMEOUT_S seconds (default 300; 0 = wait for ever) — a peer that died or left cannot hold this rank in a
+// collective for ever.  On error / timeout the communicator is aborted (the stream's collectives are cancelled, so the
+// buffers they use may be freed) and -5 is returned.  With c == nullptr or a one-rank communicator: a plain wait.
+int comm_stream_wait(ShardComm *c, void *stream, std::string &err);
 
 // All operate on device memory and are enqueued on `stream` (a hipStream_t); none of them waits for the stream.
 // sum of n uint64 over the ranks, in place

@@ -7,7 +7,9 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
@@ -161,6 +163,54 @@ void comm_destroy(ShardComm *c) {
     delete c;
 }
 void comm_mark_broken(ShardComm *c) { if (c) c->broken = true; }
+bool comm_broken(const ShardComm *c) { return c && c->broken; }
+void comm_abort_now(ShardComm *c) {
+    if (!c) return;
+    c->broken = true;
+    Rccl &R = rccl();
+    if (c->comm && R.ok && R.CommAbort) { (void)R.CommAbort(c->comm); c->comm = nullptr; }      // (comm_destroy then has nothing left to tear down)
+}
+static double comm_timeout_s() {
+    static const double v = [] {
+        const char *e = getenv("SHK_COMM_TIMEOUT_S");
+        if (!e || !*e) return 300.0;
+        const double x = strtod(e, nullptr);
+        return x < 0 ? 300.0 : x;
+    }();
+    return v;
+}
+int comm_stream_wait(ShardComm *c, void *stream, std::string &err) {
+    hipStream_t st = (hipStream_t)stream;
+    if (!c || c->world <= 1) {
+        // (nothing can keep a one-rank collective waiting: poll for a few milliseconds — the waits are short — then block)
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t e;
+        while ((e = hipStreamQuery(st)) == hipErrorNotReady)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) { e = hipStreamSynchronize(st); break; }
+        if (e != hipSuccess) { err = std::string("stream: ") + hipGetErrorString(e); return -5; }
+        return 0;
+    }
+    if (!c->comm) { err = "the communicator was aborted"; return -5; }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto last_check = t0;
+    const double limit = comm_timeout_s();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) { err = std::string("stream: ") + hipGetErrorString(e); comm_abort_now(c); return -5; }
+        const auto now = std::chrono::steady_clock::now();
+        if (now - last_check > std::chrono::milliseconds(5)) {
+            last_check = now;
+            const std::string ae = comm_async_error(c);
+            if (!ae.empty()) { err = ae; comm_abort_now(c); (void)hipStreamSynchronize(st); return -5; }
+            if (limit > 0 && std::chrono::duration<double>(now - t0).count() > limit) {
+                err = "a collective did not complete within SHK_COMM_TIMEOUT_S (a peer left the call or died): communicator aborted";
+                comm_abort_now(c); (void)hipStreamSynchronize(st); return -5;
+            }
+            std::this_thread::yield();
+        }
+    }
+}
 // an error RCCL found asynchronously (a peer that died, a link that failed): "" when there is none or the
 // library cannot tell
 std::string comm_async_error(ShardComm *c) {
@@ -178,6 +228,7 @@ int comm_device(const ShardComm *c) { return c ? c->device : 0; }
 int comm_allreduce_u64(ShardComm *c, void *d_buf, size_t n, void *stream, std::string &err) {
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!c->comm) { err = "comm: the communicator was aborted"; return -5; }
     if (!n) return 0;
     // (pieces of <= 256 MiB per call, as everywhere in this file: see comm_alltoallv)
     const size_t PIECE_N = (size_t)piece_bytes() / 8;
@@ -191,6 +242,7 @@ int comm_allreduce_u64(ShardComm *c, void *d_buf, size_t n, void *stream, std::s
 int comm_allgather(ShardComm *c, const void *d_send, void *d_recv, size_t bytes, void *stream, std::string &err) {
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!c->comm) { err = "comm: the communicator was aborted"; return -5; }
     if (!bytes) return 0;
     if (bytes % 8) { err = "comm_allgather: bytes must be a multiple of 8"; return -1; }
     const size_t PIECE = (size_t)piece_bytes();
@@ -214,6 +266,7 @@ int comm_alltoallv(ShardComm *c, const void *d_send, const uint64_t *send_off, c
                    void *d_recv, const uint64_t *recv_off, const uint64_t *recv_bytes, void *stream, std::string &err, uint32_t elem) {
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!c->comm) { err = "comm: the communicator was aborted"; return -5; }
     if (elem != 8 && elem != 4) { err = "comm_alltoallv: elements of 4 or 8 bytes"; return -1; }
     for (int p = 0; p < c->world; p++)
         if ((send_off[p] | send_bytes[p] | recv_off[p] | recv_bytes[p]) % elem) { err = "comm_alltoallv: offsets and sizes must be multiples of the element size"; return -1; }
@@ -248,6 +301,7 @@ int comm_allgatherv(ShardComm *c, const void *d_send, void *d_recv, const uint64
                     void *stream, std::string &err) {
     Rccl &R = rccl();
     if (!c || !R.ok) { err = "comm: not initialised"; return -1; }
+    if (!c->comm) { err = "comm: the communicator was aborted"; return -5; }
     for (int s = 0; s < c->world; s++)
         if ((off[s] | bytes[s]) % 4) { err = "comm_allgatherv: offsets and sizes must be multiples of 4"; return -1; }
     RCCLCHK(R.GroupStart());
@@ -280,10 +334,10 @@ int comm_allreduce_host_u64(ShardComm *c, uint64_t *host_inout, size_t n, void *
     hipStream_t st = (hipStream_t)stream;
     if (hipMemcpyAsync(buf, host_inout, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
     if (int rc = comm_allreduce_u64(c, buf, n, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
-    if (hipMemcpyAsync(host_inout, buf, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        err = std::string("all-reduce: ") + hipGetErrorString(hipGetLastError()); c->broken = true; return -5;
+    if (hipMemcpyAsync(host_inout, buf, n * 8, hipMemcpyDeviceToHost, st) != hipSuccess) {
+        err = std::string("all-reduce: ") + hipGetErrorString(hipGetLastError()); c->broken = true; (void)hipStreamSynchronize(st); return -5;
     }
-    return 0;
+    return comm_stream_wait(c, stream, err);
 }
 
 int comm_allgather_host_u64(ShardComm *c, const uint64_t *host_in, size_t n, uint64_t *host_out, void *stream, std::string &err) {
@@ -298,10 +352,10 @@ int comm_allgather_host_u64(ShardComm *c, const uint64_t *host_in, size_t n, uin
     hipStream_t st = (hipStream_t)stream;
     if (hipMemcpyAsync(in, host_in, n * 8, hipMemcpyHostToDevice, st) != hipSuccess) { err = "hipMemcpyAsync failed"; return -5; }
     if (int rc = comm_allgather(c, in, out, n * 8, stream, err)) { (void)hipStreamSynchronize(st); return rc; }
-    if (hipMemcpyAsync(host_out, out, n * 8 * world, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-        err = std::string("all-gather: ") + hipGetErrorString(hipGetLastError()); c->broken = true; return -5;
+    if (hipMemcpyAsync(host_out, out, n * 8 * world, hipMemcpyDeviceToHost, st) != hipSuccess) {
+        err = std::string("all-gather: ") + hipGetErrorString(hipGetLastError()); c->broken = true; (void)hipStreamSynchronize(st); return -5;
     }
-    return 0;
+    return comm_stream_wait(c, stream, err);
 }
 
 // ---- host-side plan -------------------------------------------------------------------------------

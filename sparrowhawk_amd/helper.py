@@ -148,6 +148,11 @@ class AssemblyHelper:
     def timings(self):
         return json.loads(self._L.shk_get_timings(self._h).decode())
 
+    @property
+    def peak_device_bytes(self):
+        """most device memory this handle held at once (the reference reports peak wasm memory: Assembler.ts:69-71,137)"""
+        return int(self._L.shk_peak_device_bytes(self._h))
+
 
 def pack_fastq(data, k, min_qual):
     """Host packer (SPEC S1-S2): returns (bases u32[], seg_off u32[], n_bases, n_reads)."""

@@ -388,3 +388,25 @@ def test_multithreaded_gzip_reader_gives_zlibs_bytes(lib, level, kind, monkeypat
     out2, n2 = C.c_void_p(), C.c_size_t()
     rc = lib.shk_host_gunzip(z[:len(z) // 2], len(z) // 2, C.byref(out2), C.byref(n2), None, None)
     assert rc != 0
+
+
+def test_peak_device_memory_counter(lib):
+    """shk_get_timings' "peak_device_bytes" (the reference reports peak memory with every assembly: Assembler.ts:69-71,137):
+    the counter behind it — blocks charged and released in any order, the high-water mark never falls, the remainder is exact."""
+    import ctypes as C
+    import random
+    rng = random.Random(7)
+    for _ in range(50):
+        live, deltas, cur, peak = [], [], 0, 0
+        for _ in range(rng.randrange(1, 400)):
+            if live and rng.random() < 0.45:
+                b = live.pop(rng.randrange(len(live)))
+                deltas.append(-b); cur -= b
+            else:
+                b = rng.choice([4096, 1 << 20, 3 << 28, 12345 * 4096])
+                live.append(b); deltas.append(b); cur += b
+                peak = max(peak, cur)
+        arr = (C.c_int64 * len(deltas))(*deltas)
+        p, c = C.c_uint64(0), C.c_uint64(0)
+        lib.shk_host_mem_counter(arr, len(deltas), C.byref(p), C.byref(c))
+        assert (p.value, c.value) == (peak, cur)
