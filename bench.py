@@ -150,6 +150,7 @@ def run_legs(torch, dev, args, raw_get_assembly):
                 state["ncontigs"] = json.loads(ctypes.string_at(ptr))["ncontigs"]
                 state["n_solid"], state["n_distinct"] = h.n_solid, h.n_distinct
             t = h.timings()
+            state["peak_device_bytes"] = int(t.get("peak_device_bytes", 0))
             h.free()
             return t
         dt, ts = timed(step, args.leg_steps)
@@ -158,7 +159,8 @@ def run_legs(torch, dev, args, raw_get_assembly):
         alg = dr.n_bases * 0.25 + dr.n_seg * 4 + state["n_distinct"] * (8 * W + 4)
         dom, k_ms = ("k_partition", p_ms) if p_ms > c_ms else ("count (k_count_partitions + k_ovf_scatter + k_count_buckets)", c_ms)
         legs[name] = {
-            "workload": note, "value": input_bases / dt / 1e9, "unit": "Gbases/s", "ms_per_step": dt * 1e3, "steps": args.leg_steps,
+            "workload": note, "value": input_bases / dt / 1e9, "unit": "Gbases/s", "clock": "device-resident", "ms_per_step": dt * 1e3, "steps": args.leg_steps,
+            "peak_device_bytes": state.get("peak_device_bytes"),
             "k": k, "segments": int(dr.n_seg), "bases_on_device": int(dr.n_bases), "n_distinct_kmers": state["n_distinct"],
             "n_solid_kmers": state["n_solid"], "ncontigs": state["ncontigs"],
             "roofline": {"bound": "hbm", "kernel": dom, "kernel_ms": k_ms, "count_step_ms": c_ms + p_ms,
@@ -220,14 +222,14 @@ def run_legs(torch, dev, args, raw_get_assembly):
     legs["fastq_gz"] = {
         "workload": base + f"k={args.k}, error-free, as a single-member .fastq.gz of {len(gz) / 1e9:.2f} GB ({len(fq) / 1e9:.2f} GB of text) in host "
                     "memory -> shk_preprocess (multi-threaded inflate: csrc/inflate_mt.cpp, then as fastq_text) -> contigs; PCIe-inclusive",
-        "value": input_bases / dtz / 1e9, "unit": "Gbases/s", "ms_per_step": dtz * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
+        "value": input_bases / dtz / 1e9, "unit": "Gbases/s", "clock": "host text (PCIe-inclusive)", "ms_per_step": dtz * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
         "gunzip_GB_per_s_of_text": len(fq) / 1e9 / (sum(t.get("gunzip_host_clock", 0.0) for t in tsz) / len(tsz) * 1e-3),
         "stage_ms": {kk: sum(t.get(kk, 0.0) for t in tsz) / len(tsz) for kk in sorted(tsz[-1]) if not kk.endswith("_x1")},
     }
     legs["fastq_text"] = {
         "workload": base + f"k={args.k}, error-free, as {len(fq) / 1e9:.2f} GB of FASTQ text in host (pageable) memory -> shk_preprocess "
                     "(device parser, upload in pieces under the parse) -> shk_assemble -> contigs on the host; PCIe-inclusive",
-        "value": input_bases / dt / 1e9, "unit": "Gbases/s", "ms_per_step": dt * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
+        "value": input_bases / dt / 1e9, "unit": "Gbases/s", "clock": "host text (PCIe-inclusive)", "ms_per_step": dt * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
         "stage_ms": {kk: sum(t.get(kk, 0.0) for t in ts) / len(ts) for kk in sorted(ts[-1]) if not kk.endswith("_x1")},
     }
     return legs
@@ -392,6 +394,7 @@ def main():
     # everybody too.  Order: RCCL inside the library -> the same shk_shard_* pieces with torch.distributed's collectives -> one
     # isolate per rank (no data-path collective).  Every step down is LOUD (stderr) and recorded in the JSON line ("fallbacks").
     fallbacks = []
+    stepped_down_to_replicas = False
     inject = os.environ.get("BENCH_TEST_FAIL_PATHS", "").split(",")     # (tests/test_dist.py: the steps down, rehearsed)
     while sharded and world > 1:
         trial_error = None
@@ -416,6 +419,7 @@ def main():
             args.collectives = "torch"
         else:
             sharded = False                              # every rank assembles an isolate of its own
+            stepped_down_to_replicas = True
             d_bases, d_seg, n_reads, n_bases, genome = make_reads_on_device(
                 torch, dev, args.genome, args.coverage, args.read_len, 0xEC02 + rank)
     for _ in range(args.warmup):
@@ -512,6 +516,63 @@ def main():
             host_step()
         torch.cuda.synchronize()
         host_leg = (time.perf_counter() - th) / args.steps
+    # ---- the SURVEY 8(d) clock with two handles in flight: both fed from host pinned memory, so the upload of isolate i+1
+    # rides under the kernels of isolate i (a batch of isolates on one GPU)
+    host_inflight_leg = None
+    if host_leg is not None and not args.no_inflight_leg:
+        import threading
+        todo_lock2, todo2 = threading.Lock(), [0]
+
+        def hfl_worker(n_total):
+            while True:
+                with todo_lock2:
+                    if todo2[0] >= n_total:
+                        return
+                    todo2[0] += 1
+                host_step()
+        for n_total in (max(2, args.warmup), args.steps):
+            todo2[0] = 0
+            torch.cuda.synchronize()
+            tf = time.perf_counter()
+            ths = [threading.Thread(target=hfl_worker, args=(n_total,)) for _ in range(2)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            torch.cuda.synchronize()
+            host_inflight_leg = (time.perf_counter() - tf) / n_total
+    # ---- the shard layer with a one-rank communicator (N = 1): what the exchange machinery and the collective shk_assemble
+    # cost when nothing has to leave the GPU — driver-timed beside the plain path
+    sharded_one_rank = None
+    if world == 1 and not sharded and args.err == 0 and not args.no_legs:
+        try:
+            from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
+            comm1 = LibComm(0, 1)
+            st1 = {}
+
+            def sh_step():
+                h = AssemblyHelper.new(args.k, False, args.min_count, 20, 0, False, False, False, False)
+                sharded_preprocess_rccl(h, d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads, comm1)
+                h.assemble()
+                assert raw_get_assembly(h._h)
+                st1["t"] = h.timings()
+                h.free()
+            for _ in range(max(1, args.warmup)):
+                sh_step()
+            torch.cuda.synchronize()
+            ts1 = time.perf_counter()
+            for _ in range(args.leg_steps):
+                sh_step()
+            torch.cuda.synchronize()
+            dts = (time.perf_counter() - ts1) / args.leg_steps
+            sharded_one_rank = {"value": n_bases / dts / 1e9, "unit": "Gbases/s", "clock": "device-resident", "ms_per_step": dts * 1e3,
+                                "steps": args.leg_steps, "host_waits_per_assemble": st1["t"].get("shard_host_waits_x1"),
+                                "workload": "the headline isolate through shk_shard_preprocess + the collective shk_assemble on a one-rank RCCL "
+                                            "communicator (records deduplicated, packed, exchanged with itself; graph phases on the sharded path)",
+                                "stage_ms": {kk: vv for kk, vv in sorted(st1["t"].items()) if kk.startswith("shard_")}}
+            comm1.free()
+        except Exception as e:
+            sharded_one_rank = {"error": repr(e)}
     if world > 1:
         tt = torch.tensor([dt], device=dev if args.backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -559,8 +620,10 @@ def main():
             stream_gbs = g.value
     line = {
         "metric": "Gbases/s assembled, k=31 150bp reads",
-        "value": value, "unit": "Gbases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": value, "unit": "Gbases/s", "clock": "device-resident", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        # ("replicas": the sharded paths failed on this node and every rank assembled an isolate of its own — see `fallbacks`)
+        "scaling": "replicas" if stepped_down_to_replicas else "weak",
         "vs_baseline": None, "dtype": "u64", "data": "synthetic",
         "config": {"workload": (f"one pooled sample of {args.genome * world} bp, " if sharded else "") +
                                f"{args.genome} bp isolate per GPU, {args.coverage}x {args.read_len} bp reads "
@@ -577,7 +640,10 @@ def main():
                                          ("" if not fallbacks else " — SECOND PATH: " + fallbacks[0]["error"]))
                                    if sharded else "one isolate per rank (batch of isolates), no data-path collective" +
                                    ("" if not fallbacks else " — FALLBACK: the sharded path failed on this node, see fallbacks")),
-                   "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid},
+                   "ncontigs": ncontigs, "n_distinct_kmers": n_distinct, "n_solid_kmers": n_solid,
+                   "peak_device_bytes": int(max(t.get("peak_device_bytes", 0) for t in all_t)),
+                   "clock": "`value` starts with the packed reads resident in HBM (the bench contract); the SURVEY 8(d) clock — packed reads "
+                            "in host pinned memory -> contig strings on the host — is `host_pinned.value` / `value_host_pinned`"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      # what SURVEY.md 8(d) asks to report beside the algorithmic fraction: the kernel's MEASURED fabric
@@ -591,7 +657,7 @@ def main():
                      "count_step_ms": c_ms + p_ms,
                      "count_step_frac": (alg_bytes / ((c_ms + p_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS) if c_ms + p_ms > 0 else 0.0,
                      "note": "integer/hash path bound by instruction issue and LDS round trips, not by HBM: see DESIGN.md section 4"},
-        "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1])},
+        "stage_ms": {k: sum(t.get(k, 0.0) for t in all_t) / len(all_t) for k in sorted(all_t[-1]) if k not in ("peak_device_bytes", "device_bytes_now")},
     }
     if fallbacks:
         line["fallbacks"] = fallbacks                     # the paths that failed before the one measured (see config.parallelism)
@@ -607,7 +673,17 @@ def main():
         line["ms_per_step_two_in_flight"] = inflight_leg * 1e3
         line["two_in_flight_note"] = ("the same steps with two handles in flight (two host threads, two streams): the kernels of one "
                                       "handle fill the host gaps of the other — a batch of isolates on one GPU (sparrowhawk_amd/batch.py)")
+    if inflight_leg is not None:
+        line["two_in_flight"] = {"value": n_bases / inflight_leg / 1e9, "unit": "Gbases/s", "clock": "device-resident", "ms_per_step": inflight_leg * 1e3}
+    if sharded_one_rank is not None:
+        line["sharded_one_rank"] = sharded_one_rank
     if host_leg is not None:
+        line["host_pinned"] = {"value": n_bases / host_leg / 1e9, "unit": "Gbases/s", "clock": "host-pinned", "ms_per_step": host_leg * 1e3,
+                               "note": "SURVEY.md 8(d): packed reads in host pinned memory -> contig strings on the host, one handle at a time"}
+        if host_inflight_leg is not None:
+            line["host_pinned_two_in_flight"] = {"value": n_bases / host_inflight_leg / 1e9, "unit": "Gbases/s", "clock": "host-pinned",
+                                                 "ms_per_step": host_inflight_leg * 1e3,
+                                                 "note": "the same clock with two handles in flight: the upload of isolate i+1 under the kernels of isolate i"}
         line["value_host_pinned"] = n_bases / host_leg / 1e9
         line["ms_per_step_host_pinned"] = host_leg * 1e3
         line["host_pinned_note"] = ("packed reads in host pinned memory -> contigs on host (SURVEY.md 8d clock): %.0f MB uploaded in "

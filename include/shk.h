@@ -204,6 +204,10 @@ int shk_host_fit(const uint64_t *histo500, uint32_t *used_min_count); /* 1 ok, 0
  * unitigs handed in as text, any strand, any order: seqs = the spellings back to back, offsets[n+1] their
  * bounds, kc[n] their k-mer count sums.  Returns a malloc'd NUL-terminated JSON (shk_host_free) or NULL. */
 char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k);
+/* the same on text that arrives while the writer works, piece_bytes at a time every delay_us microseconds (the device path
+ * downloads the contigs in pieces and the writer copies what is there: csrc/pipeline.h TextArrival) — same JSON */
+char *shk_host_assembly_json_arriving(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k,
+                                      uint64_t piece_bytes, uint32_t delay_us);
 void shk_host_free(void *p);
 /* host-only: the gzip reader of shk_preprocess alone (fastx_wasm.rs:53-70: gz sniff, multi-member) — BGZF blocks in
  * parallel, a large plain member by the multi-threaded two-pass inflater (csrc/inflate_mt.cpp), the rest by zlib.  *out is

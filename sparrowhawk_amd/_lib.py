@@ -68,6 +68,7 @@ SIGNATURES = {
     "shk_host_nthash": (_u64, [_cp, _u32]),
     "shk_host_fit": (_int, [_vp, C.POINTER(_u32)]),
     "shk_host_assembly_json": (_vp, [_cp, _vp, _vp, _u64, _u32]),
+    "shk_host_assembly_json_arriving": (_vp, [_cp, _vp, _vp, _u64, _u32, _u64, _u32]),
     "shk_host_free": (None, [_vp]),
     "shk_host_gunzip": (_int, [_cp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u64), C.POINTER(C.c_double)]),
     "shk_host_unitig_assemble": (_vp, [_u32, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int]),

@@ -3,6 +3,7 @@
 // machine, the progress strings (AssemblyPage.vue:458-609) and the JSON getters.
 #include "../../include/shk.h"
 
+#include <atomic>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
@@ -210,8 +211,12 @@ static int finish_counting(shk_handle *h) {
 
 static int run_counting(shk_handle *h, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg,
                         uint64_t n_bases) {
-    if (int rc = count_one_batch(h, d_bases, d_seg_off, n_seg, n_bases)) return rc;
-    return finish_counting(h);
+    // (one batch, and the caller's reads stay in place until this function returns: the two counting passes run back to back)
+    h->pipe->single_batch_resident(true);
+    int rc = count_one_batch(h, d_bases, d_seg_off, n_seg, n_bases);
+    if (!rc) rc = finish_counting(h);
+    h->pipe->single_batch_resident(false);
+    return rc;
 }
 
 // bases per batch of the host-parsed paths (a batch is limited to 2^32 packed bases by its 32-bit offsets)
@@ -605,9 +610,11 @@ static int preprocess_packed_host_impl(shk_handle *h, const uint32_t *bases, con
     h->post_mode(("loop:" + std::to_string(n_reads) + ":100").c_str());
     // upload and pass 1 overlap piece by piece (Pipeline::count_batch_host), then histogram / fit / filter as usual
     h->batches_started++;
+    h->pipe->single_batch_resident(true);
     int rc = h->pipe->count_batch_host((uint32_t *)db.p, (uint32_t *)ds.p, bases, seg_off, n_seg, n_bases, err);
     if (rc) rc = fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err);
     else rc = finish_counting(h);
+    h->pipe->single_batch_resident(false);
     { std::string e2; (void)device_stream_sync(st, e2); }      // the blocks go back to the pool idle, also after a failure
     h->pipe->times().add("h2d_packed_reads_MB", (double)(want_b + want_s) / 1e6);
     h->pipe->times().add("preprocess_from_host_total_host_clock", now_ms() - t0);
@@ -737,7 +744,8 @@ static int assemble_impl(shk_handle *h) {
     if (h->pipe->n_solid() >= (1u << 20)) writer_prewarm(3000);     // megabases of output in about a millisecond
     std::vector<RawContig> contigs;
     const char *dev_json = nullptr; size_t dev_json_len = 0; uint64_t dev_nc = 0;
-    rc = h->pipe->collapse(contigs, err, &dev_json, &dev_json_len, &dev_nc);
+    TextArrival *arrival = nullptr;                    // megabases of contigs: their text is still crossing PCIe when the writer starts
+    rc = h->pipe->collapse(contigs, err, &dev_json, &dev_json_len, &dev_nc, &arrival);
     if (rc) return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err);
     h->pipe->times().add("assemble_device_total_host_clock", now_ms() - t0);
     h->post("assembly:saving");
@@ -749,9 +757,12 @@ static int assemble_impl(shk_handle *h) {
         return SHK_OK;
     }
     const double t1 = now_ms();
-    build_assembly_text(contigs, h->k, h->text);
+    struct ArrivalDone { TextArrival *a; ~ArrivalDone() { if (a) { std::string e; (void)a->finish(e); } } } arrival_done{arrival};   // (also when the writer throws)
+    build_assembly_text(contigs, h->k, h->text, arrival);
+    if (arrival) { arrival_done.a = nullptr; if (int rc2 = arrival->finish(err)) return fail(h, rc2 == -4 ? SHK_E_OOM : SHK_E_DEVICE, err); }
     h->asm_json.swap(h->text.json);
     h->pipe->times().add("outputs_host_clock", now_ms() - t1);
+    if (arrival) h->pipe->times().add("outputs_with_arrival_x1", 1.0);
     for (auto &kv : h->text.stage_ms) h->pipe->times().add(kv.first, kv.second);
     h->st = St::Assembled;
     h->post("assembly:end");
@@ -1202,6 +1213,50 @@ char *shk_host_assembly_json(const char *seqs, const uint64_t *offsets, const ui
         AssemblyText text;
         build_assembly_text(contigs, k, text);
         char *out = (char *)malloc(text.json.size());        // (the JSON carries its terminator)
+        if (!out) return nullptr;
+        memcpy(out, text.json.data(), text.json.size());
+        return out;
+    } catch (...) { return nullptr; }
+}
+// the same writer on text that ARRIVES while it works (the device path hands it text that is still crossing PCIe): a thread
+// releases the bytes piece by piece into a buffer that starts out as garbage, the contigs carry their ends as the device
+// path's do — the JSON must be the one shk_host_assembly_json gives (tests; no GPU)
+char *shk_host_assembly_json_arriving(const char *seqs, const uint64_t *offsets, const uint64_t *kc, uint64_t n_contigs, uint32_t k,
+                                      uint64_t piece_bytes, uint32_t delay_us) {
+    try {
+        if ((!seqs && n_contigs) || !offsets || (!kc && n_contigs) || !piece_bytes) return nullptr;
+        const size_t total = (size_t)offsets[n_contigs];
+        struct Fake : TextArrival {
+            std::vector<char> buf; std::atomic<size_t> ready{0};
+            const char *base() const override { return buf.data(); }
+            size_t total() const override { return buf.size(); }
+            void wait_range(size_t, size_t end) override { if (end > buf.size()) end = buf.size(); while (ready.load(std::memory_order_acquire) < end) std::this_thread::yield(); }
+            int finish(std::string &) override { wait_all(); return 0; }
+        } fake;
+        fake.buf.assign(total, '#');                       // (what has not arrived is not sequence)
+        const uint32_t E = std::max<uint32_t>(k, 32);
+        std::vector<char> ends((size_t)n_contigs * 2 * E, 0);
+        std::vector<RawContig> contigs((size_t)n_contigs);
+        for (uint64_t i = 0; i < n_contigs; i++) {
+            if (offsets[i + 1] < offsets[i] + k) return nullptr;
+            const size_t len = (size_t)(offsets[i + 1] - offsets[i]), m = std::min<size_t>(E, len);
+            contigs[i].ext = fake.buf.data() + offsets[i]; contigs[i].ext_n = len; contigs[i].kc = kc[i];
+            memcpy(&ends[(size_t)i * 2 * E], seqs + offsets[i], m);
+            memcpy(&ends[(size_t)i * 2 * E + E], seqs + offsets[i] + len - m, m);
+            contigs[i].head = &ends[(size_t)i * 2 * E]; contigs[i].tail = contigs[i].head + E; contigs[i].ends_n = (uint32_t)m;
+        }
+        std::thread feeder([&] {
+            for (size_t o = 0; o < total; o += (size_t)piece_bytes) {
+                if (delay_us) std::this_thread::sleep_for(std::chrono::microseconds(delay_us));
+                const size_t m = std::min<size_t>((size_t)piece_bytes, total - o);
+                memcpy(fake.buf.data() + o, seqs + o, m);
+                fake.ready.store(o + m, std::memory_order_release);
+            }
+        });
+        struct Join { std::thread &t; ~Join() { if (t.joinable()) t.join(); } } join{feeder};
+        AssemblyText text;
+        build_assembly_text(contigs, k, text, total ? &fake : nullptr);
+        char *out = (char *)malloc(text.json.size());
         if (!out) return nullptr;
         memcpy(out, text.json.data(), text.json.size());
         return out;

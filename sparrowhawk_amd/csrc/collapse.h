@@ -80,7 +80,11 @@ template <int W>
 __global__ __launch_bounds__(256) void k_succ_split(Graph<W> g, const uint8_t *__restrict__ alive,
                                                     uint2 *__restrict__ winfo, uint32_t *__restrict__ spl,
                                                     uint2 *__restrict__ ol, unsigned int *__restrict__ n_spl,
-                                                    uint32_t split_mask, unsigned long long *__restrict__ n_alive /* += alive oriented nodes */) {
+                                                    uint32_t split_mask, unsigned long long *__restrict__ n_alive /* += alive oriented nodes */,
+                                                    const unsigned long long *__restrict__ skip = nullptr /* two counters: return at once unless both are 0 */) {
+    // (launched behind a correction round whose outcome the host does not know yet: if that round removed nodes the graph
+    // is not final and this launch is repeated later — pipeline.hip: rank_chains)
+    if (skip && (skip[0] | skip[1])) return;
     __shared__ uint32_t wtot[SS_ITEMS * 4];
     __shared__ uint32_t woff[SS_ITEMS * 4];
     __shared__ uint32_t blk_base, blk_alive;
@@ -188,7 +192,9 @@ template <int W>
 __global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, const uint32_t *__restrict__ row_starts, uint32_t tile_rows,
                                                            const uint8_t *__restrict__ alive,
                                                            const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
-                                                           FragRec *__restrict__ frag, uint32_t split_mask) {
+                                                           FragRec *__restrict__ frag, uint32_t split_mask,
+                                                           const unsigned long long *__restrict__ skip = nullptr /* as k_succ_split */) {
+    if (skip && (skip[0] | skip[1])) return;
     __shared__ uint16_t l_succ[LF_TILE];       // local index of the successor; LF_STOP: the fragment ends here; LF_DONE: a walker has passed
     __shared__ uint32_t l_cnt[LF_TILE];        // count; once passed: (local head << 13) | position in the fragment
     __shared__ uint16_t l_heads[LF_TILE];

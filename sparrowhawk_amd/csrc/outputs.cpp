@@ -79,9 +79,13 @@ struct PtrSink {
     size_t big = (size_t)-1;
     std::vector<std::pair<char *, std::pair<const char *, size_t>>> *deferred = nullptr;
     std::mutex *mu = nullptr;
+    TextArrival *arr = nullptr;        // the sequences may still be arriving from the device: wait for the bytes about to be copied
     void seq(const char *q, size_t m) {
         if (m >= big && deferred) { std::lock_guard<std::mutex> lk(*mu); deferred->push_back({p, {q, m}}); }
-        else memcpy(p, q, m);
+        else {
+            if (arr && q >= arr->base() && q < arr->base() + arr->total()) { const size_t o = (size_t)(q - arr->base()); arr->wait_range(o, o + m); }
+            memcpy(p, q, m);
+        }
         p += m;
     }
     void nl() { *p++ = '\\'; *p++ = 'n'; }
@@ -218,7 +222,14 @@ template <typename F> void par_ranges(size_t n, size_t min_per_piece, F &&fn, Wo
 
 void writer_prewarm(long microseconds) { WorkPool::get().prewarm(microseconds); }
 
-void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out) {
+void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out, TextArrival *arrival) {
+    // Text that is still arriving (pipeline.h: TextArrival): everything in front of the copies reads the contigs' ENDS only
+    // (RawContig::head / tail: the first / last max(k, 32) bases); whatever needs more — a strand or order decision that is
+    // still open after those bases, a reverse complement — waits for the whole text first (rare: ties).
+    auto all_here = [&] { if (arrival) { arrival->wait_all(); arrival = nullptr; for (auto &c : contigs) { c.head = c.tail = nullptr; c.ends_n = 0; } } };
+    auto first_bases = [](const RawContig &c) { return c.head ? c.head : c.data(); };                       // >= min(size, max(k, 32)) of them
+    auto last_k = [k](const RawContig &c) { return c.tail ? c.tail + (c.ends_n - k) : c.data() + c.size() - k; };
+    if (arrival) for (auto &c : contigs) if (!c.head || c.ends_n < std::min<uint64_t>(c.size(), std::max<uint32_t>(k, 32))) { all_here(); break; }
     const char *pm = getenv("SHK_WRITER_PAR_MIN");          // (tests force the parallel paths on small outputs)
     const size_t par_min = (pm && *pm) ? (size_t)strtoull(pm, nullptr, 10) : ((size_t)1 << 20);
     const bool many = contigs.size() >= (par_min >= ((size_t)1 << 20) ? (size_t)20000 : (size_t)2);
@@ -230,13 +241,30 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     double t_last = clock_ms();
     auto lap = [&](const char *name) { const double t = clock_ms(); out.stage_ms.emplace_back(name, t - t_last); t_last = t; };
     // SPEC S10: each unitig is emitted as min(seq, revcomp(seq))
+    if (arrival) {
+        // from the ends alone: position i of revcomp(s) is comp(s[n-1-i]) — decided within the first ends_n positions, or open
+        bool open = false;
+        for (auto &c : contigs) {
+            const size_t n = c.size(), m = c.ends_n;
+            int verdict = 0;                              // -1 revcomp smaller, +1 not, 0 open
+            for (size_t i = 0; i < m && !verdict; i++) {
+                const char a = comp(c.tail[m - 1 - i]), b = c.head[i];
+                if (a != b) verdict = a < b ? -1 : 1;
+            }
+            if (verdict == 0 && m >= n) verdict = 1;      // (the whole contig was compared: it is its own reverse complement)
+            if (verdict <= 0) { open = true; break; }      // a reverse complement has to be built, or the ends do not decide
+        }
+        if (open) all_here();
+    }
     auto canon = [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
             RawContig &c = contigs[i];
             if (revcomp_is_smaller(c.data(), c.size())) { c.own = revcomp(c.data(), c.size()); c.ext = nullptr; c.ext_n = 0; }
         }
     };
-    if (many) par_ranges(contigs.size(), grain, canon, &wp); else canon(0, contigs.size());
+    if (arrival) {}                                        // (every contig is the smaller strand already: decided above)
+    else
+    { if (many) par_ranges(contigs.size(), grain, canon, &wp); else canon(0, contigs.size()); }
     lap("outputs_canonical_strand");
     // SPEC S11: order by (length desc, sequence asc).  An index is sorted, not the records; with many contigs the
     // ranges are sorted in parallel and merged pairwise.
@@ -248,7 +276,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     auto make_keys = [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
             const RawContig &c = contigs[i];
-            const char *p = c.data(); const size_t n = c.size(), m = std::min<size_t>(n, 32);
+            const char *p = first_bases(c); const size_t n = c.size(), m = std::min<size_t>(n, 32);
             uint64_t pf = 0;
             for (size_t j = 0; j < m; j++) { const char ch = p[j]; pf = (pf << 2) | (uint64_t)(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3); }
             pf <<= 2 * (32 - m);
@@ -261,6 +289,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         if (x.prefix != y.prefix) return x.prefix < y.prefix;
         const RawContig &a = contigs[x.idx], &b = contigs[y.idx];
         if (a.size() != b.size()) return a.size() > b.size();           // (lengths beyond 2^32 - 1)
+        if (arrival) arrival->wait_all();                               // (a tie on length and 32 bases: the texts decide)
         const int c = memcmp(a.data(), b.data(), a.size());
         return c != 0 ? c < 0 : x.idx < y.idx;                          // (equal spellings cannot occur; keeps the order total)
     };
@@ -342,7 +371,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     auto dec_o = [](uint64_t v) { return (uint32_t)((v >> 40) & 1); };
     auto key_of_enc = [&](uint64_t v) -> Key {
         const RawContig &c = contigs[dec_c(v)];
-        return dec_o(v) ? pack_rc(c.data() + c.size() - k) : pack(c.data());
+        return dec_o(v) ? pack_rc(last_k(c)) : pack(first_bases(c));
     };
     auto fp_of = [](size_t h) -> uint64_t { uint64_t f = (uint64_t)(h >> 41); return f == 0x7FFFFF ? 0x7FFFFE : f; };   // (all ones is "empty")
     auto put2 = [&](const Key &x, uint64_t contig, uint64_t o) {
@@ -372,8 +401,8 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     };
     auto fill = [&](size_t a, size_t b) {
         for (size_t i = a; i < b; i++) {
-            put2(pack(contigs[i].data()), i, 0);
-            put2(pack_rc(contigs[i].data() + contigs[i].size() - k), i, 1);           // first k-mer of the '-' orientation
+            put2(pack(first_bases(contigs[i])), i, 0);
+            put2(pack_rc(last_k(contigs[i])), i, 1);           // first k-mer of the '-' orientation
         }
     };
     if (many) par_ranges(nc, grain, fill, &wp); else fill(0, nc);
@@ -382,7 +411,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     auto find_links = [&](size_t a, size_t b, std::vector<Link> &dst) {
         for (size_t i = a; i < b; i++) for (uint32_t o = 0; o < 2; o++) {
             // last k-mer of the orientation: of '+' the contig's last k-mer, of '-' the reverse complement of its first
-            Key cand = o ? pack_rc(contigs[i].data()) : pack(contigs[i].data() + contigs[i].size() - k);
+            Key cand = o ? pack_rc(first_bases(contigs[i])) : pack(last_k(contigs[i]));
             shl2(cand, 0); mask_k(cand);                    // drop the first base, append A
             for (uint64_t bb = 0; bb < 4; bb++) {
                 cand.w[0] = (cand.w[0] & ~3ull) | bb;
@@ -516,7 +545,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     for (size_t p = 0; p < parts.size(); p++) memcpy(base + part_off[p], parts[p].lit.data(), parts[p].lit.size());
     auto write_range = [&](size_t r) {
         PtrSink w{base + ranges[r].off};
-        w.big = seq_bytes >= par_min ? big : (size_t)-1; w.deferred = &deferred; w.mu = &deferred_mu;
+        w.big = seq_bytes >= par_min ? big : (size_t)-1; w.deferred = &deferred; w.mu = &deferred_mu; w.arr = arrival;
         for (size_t i = ranges[r].a; i < ranges[r].b; i++) emit_rec(w, parts[ranges[r].part].kind, i);
     };
     if (ranges.size() > 1 && (many || seq_bytes >= par_min)) wp.run(ranges.size(), write_range);
@@ -526,8 +555,19 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
         for (auto &d : deferred)
             for (size_t o = 0; o < d.second.second; o += piece)
                 copies.push_back(Copy{d.second.first + o, d.first + o, std::min(piece, d.second.second - o)});
+        if (arrival) {
+            // the pieces in the order of their arrival: the three copies of a piece (FASTA, GFA1, GFA2) follow one another
+            std::sort(copies.begin(), copies.end(), [](const Copy &a, const Copy &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
+            TextArrival *arr = arrival;
+            wp.run(copies.size(), [&copies, arr](size_t i) {
+                const Copy &c = copies[i];
+                if (c.src >= arr->base() && c.src < arr->base() + arr->total()) { const size_t o = (size_t)(c.src - arr->base()); arr->wait_range(o, o + c.n); }
+                memcpy(c.dst, c.src, c.n);
+            });
+        } else
         wp.run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
     }
+    if (arrival) arrival->wait_all();
     WorkPool::get().prewarm(0);                         // the writer is done: the workers go back to sleep
     if (&wp != &WorkPool::get()) wp.prewarm(0);
     lap("outputs_write");

@@ -18,7 +18,9 @@ struct AssemblyText {
     std::vector<std::pair<std::string, double>> stage_ms;     // where the writer's time went (host clock)
 };
 
-void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out);
+// arrival (optional): the contigs' text (RawContig::ext) is still arriving from the device; the contigs then carry their
+// first / last bases (head / tail), and the writer copies every range of text as soon as it is there
+void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyText &out, TextArrival *arrival = nullptr);
 // the writer's worker threads will be needed within about this long: they wake up now (shk_assemble calls this when
 // the graph phases of a megabase assembly start, so that the copies of the contigs do not wait for sleeping threads)
 void writer_prewarm(long microseconds);

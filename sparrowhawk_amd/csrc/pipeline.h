@@ -11,12 +11,27 @@ namespace shk {
 
 struct ShardComm;             // shard_comm.h
 
+// The text of the contigs may still be on its way from the device when the writer starts (pipeline.hip: collapse): it
+// arrives in slabs, roughly front to back, and the writer copies a range as soon as its slabs are there — the download of a
+// 5 Mbp contig and its three copies into the JSON (FASTA, GFA1, GFA2) run side by side.
+class TextArrival {
+public:
+    virtual ~TextArrival() {}
+    virtual const char *base() const = 0;             // first byte of the arriving text (pinned host memory)
+    virtual size_t total() const = 0;
+    virtual void wait_range(size_t begin, size_t end) = 0;     // returns when [begin, end) has arrived (any thread)
+    void wait_all() { wait_range(0, total()); }
+    virtual int finish(std::string &err) = 0;         // waits for all of it; non-zero if the download failed
+};
+
 struct RawContig {            // one unitig as spelled by the device, arbitrary strand
     // The sequence either lives in the pipeline's pinned download buffer (ext: valid until the next
     // collapse() or the pipeline's destruction — a 5 Mbp contig is not copied again) or in `own`.
     const char *ext = nullptr; size_t ext_n = 0;
     std::string own;
     uint64_t kc = 0;          // sum of k-mer counts over its nodes
+    // with a TextArrival: copies of the first and the last min(size, ends_n) bases, there before the text itself
+    const char *head = nullptr, *tail = nullptr; uint32_t ends_n = 0;
     const char *data() const { return ext ? ext : own.data(); }
     size_t size() const { return ext ? ext_n : own.size(); }
 };
@@ -46,6 +61,9 @@ public:
     // do_bloom (docs/src/assembly.md:18): partitions that go through the k-mer-level repartition pass a Bloom
     // pre-filter first, so their singletons are never stored; counts may then be one too high, never too low
     virtual void set_bloom(bool on) = 0;
+    // the next count_batch / count_batch_host hands over the ONLY batch of this handle and its packed reads stay where they are
+    // until histogram() has returned: pass 2 may then be launched behind pass 1 without a host round trip in between
+    virtual void single_batch_resident(bool on) = 0;
     // spectrum histogram (SPEC S5).  Rows with count <= emit_threshold will never be asked for
     // by filter(): the counting pass may drop them as soon as they are histogrammed.
     virtual int histogram(uint64_t histo[500], uint32_t emit_threshold, std::string &err) = 0;
@@ -62,8 +80,10 @@ public:
     // json (optional): a FRAGMENTED assembly (>= SHK_DEVICE_WRITER_MIN contigs, default 20 000) is turned into the
     // get_assembly() JSON on the device (writer_gpu.h: order, links, FASTA / DOT / GFA1 / GFA2 text) and `out` stays empty;
     // *json then points at the NUL-terminated text in pinned host memory owned by the pipeline, *n_contigs says how many
+    // arrival (optional): when the caller can start on text that is still arriving, *arrival is set (owned by the pipeline,
+    // valid until the next collapse) and the contigs carry their first / last bases; otherwise the text is complete on return
     virtual int collapse(std::vector<RawContig> &out, std::string &err, const char **json = nullptr, size_t *json_len = nullptr,
-                         uint64_t *n_contigs = nullptr) = 0;
+                         uint64_t *n_contigs = nullptr, TextArrival **arrival = nullptr) = 0;
     virtual int get_adjacency(uint8_t *adj_initial, uint8_t *adj_final, uint8_t *alive,
                               uint64_t cap, std::string &err) = 0;
     // shard layer (one process per GPU): partition -> pack -> [all-to-all] -> count -> rows ->

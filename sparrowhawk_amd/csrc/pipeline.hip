@@ -47,11 +47,16 @@ namespace shk {
 // hold this rank for ever
 #define WAIT_STREAM()                                                                     \
     do {                                                                                  \
+        n_host_waits_++;                                                                  \
         if (wd_comm_) { if (int _rc = comm_stream_wait(wd_comm_, stream_, err)) return _rc; } \
         else HIPCHK(stream_wait(stream_));                                                \
     } while (0)
 
 static constexpr uint32_t NIL = 0xFFFFFFFFu;
+// device-side counters and flags of a pipeline (ctl_): 0-2 count / graph build, 3-6 correction rounds, 5-10 collapse, 8-9
+// pass 1, 11-12 / 14 pass 2, 13 shard layer, 16-17 what the FIRST correction round removed (tips, bubbles: read back with
+// the collapse's first counters — the round costs no host round trip of its own)
+static constexpr int CTL_WORDS = 32;
 static constexpr uint64_t EMPTY64 = ~0ull;
 static constexpr int MAX_PROBE = 4096;
 static constexpr int SPLIT_LOG_DEFAULT = 6;    // one sampled splitter every ~64 oriented nodes (the walk hops over LDS-built fragments: 5 -> 6 measured best)
@@ -358,6 +363,74 @@ static inline uint32_t env_dbg(const char *name) {
 #endif
 }
 
+// ---- the contig text goes to the host by a KERNEL that writes pinned host memory slab by slab and raises a flag per slab
+// there (TextArrival, pipeline.h).  hipMemcpyAsync in pieces cost a blit kernel and ~11 us of gap per piece on the GPU box
+// (10 pieces: 0.2 ms for 5 MB that cross PCIe in 0.09) and an event query per look; here the host polls plain memory.
+static constexpr uint32_t ARRIVAL_SLAB = 64u << 10;
+__global__ __launch_bounds__(256) void k_text_to_host(const char *__restrict__ src, char *__restrict__ dst_host, unsigned long long bytes,
+                                                      uint32_t n_slabs, uint32_t *__restrict__ flags_host) {
+    for (uint32_t s = blockIdx.x; s < n_slabs; s += gridDim.x) {                      // (roughly front to back)
+        const unsigned long long o = (unsigned long long)s * ARRIVAL_SLAB;
+        const uint32_t m = (uint32_t)(bytes - o < ARRIVAL_SLAB ? bytes - o : ARRIVAL_SLAB);
+        const uint4 *a = reinterpret_cast<const uint4 *>(src + o);
+        uint4 *d = reinterpret_cast<uint4 *>(dst_host + o);
+        const uint32_t nv = m >> 4;
+#pragma unroll 4
+        for (uint32_t i = threadIdx.x; i < nv; i += 256) d[i] = a[i];
+        if (threadIdx.x < (m & 15u)) dst_host[o + (nv << 4) + threadIdx.x] = src[o + (nv << 4) + threadIdx.x];
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&flags_host[s], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// first / last E bytes of every emitted contig, side by side, written straight to pinned host memory with a flag behind them
+// (the writer's order, links and strand checks need nothing else of a contig before its text has arrived):
+// ends[c][0][E] = text[off .. off + m), ends[c][1][E] = text[off + len - m .. off + len), m = min(E, len).  ONE workgroup.
+__global__ __launch_bounds__(1024) void k_ends_to_host(const char *__restrict__ text, const unsigned long long *__restrict__ src /* {off, len} per contig */,
+                                                       uint32_t nc, uint32_t E, char *__restrict__ ends_host, uint32_t *__restrict__ flag_host) {
+    const unsigned long long total = (unsigned long long)nc * 2ull * E;
+    for (unsigned long long t = threadIdx.x; t < total; t += blockDim.x) {
+        const uint32_t c = (uint32_t)(t / (2ull * E)), r = (uint32_t)(t % (2ull * E)), side = r / E, j = r % E;
+        const unsigned long long off = src[2 * c], len = src[2 * c + 1];
+        const unsigned long long m = len < E ? len : (unsigned long long)E;
+        char ch = 0;
+        if (j < m) ch = side ? text[off + len - m + j] : text[off + j];
+        ends_host[t] = ch;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+class SlabArrival : public TextArrival {
+public:
+    void set(char *dst, size_t bytes, volatile uint32_t *flags, uint32_t n_slabs, hipStream_t st) { base_ = dst; total_ = bytes; flags_ = flags; n_slabs_ = n_slabs; st_ = st; failed_.store(false); }
+    const char *base() const override { return base_; }
+    size_t total() const override { return total_; }
+    static bool spin_until(volatile uint32_t *f, std::atomic<bool> &failed) {
+        if (__atomic_load_n(f, __ATOMIC_ACQUIRE)) return true;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t it = 0;; it++) {
+            if (__atomic_load_n(f, __ATOMIC_ACQUIRE)) return true;
+            if (failed.load(std::memory_order_relaxed)) return false;
+            if ((it & 0xFFFu) == 0xFFFu && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) { failed.store(true); return false; }   // (a kernel that died: nobody waits for ever)
+            __builtin_ia32_pause();
+        }
+    }
+    void wait_range(size_t begin, size_t end) override {
+        if (end > total_) end = total_;
+        if (begin >= end) return;
+        for (size_t s = begin / ARRIVAL_SLAB; s <= (end - 1) / ARRIVAL_SLAB; s++) if (!spin_until(flags_ + s, failed_)) return;
+    }
+    int finish(std::string &err) override {
+        const hipError_t e = hipStreamSynchronize(st_);                    // (the kernel itself: its source buffer may go afterwards)
+        if (e != hipSuccess || failed_.load()) { err = std::string("download of the contigs failed") + (e != hipSuccess ? std::string(": ") + hipGetErrorString(e) : std::string()); return -5; }
+        return 0;
+    }
+    std::atomic<bool> failed_{false};
+private:
+    char *base_ = nullptr; size_t total_ = 0; volatile uint32_t *flags_ = nullptr; uint32_t n_slabs_ = 0; hipStream_t st_ = nullptr;
+};
+
 // minimiser length of the counting partitions and of the graph partitions
 static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
 
@@ -375,7 +448,8 @@ public:
         { int cus = 0; (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, stream_dev_); n_cus_ = cus > 0 ? cus : 256; }
         stream_ = stream_pool_get(stream_dev_);
         if (!stream_) HIPCHK(hipStreamCreate(&stream_));
-        HIPCHK(ctl_.alloc(16, err) ? hipErrorOutOfMemory : hipSuccess);
+        HIPCHK(ctl_.alloc(CTL_WORDS, err) ? hipErrorOutOfMemory : hipSuccess);
+        if (mbox_.alloc(MBOX_BYTES, err)) return -4;
         return 0;
     }
     StageTimes &times() override { EvTimer::resolve(pending_timers_, times_); return times_; }
@@ -425,7 +499,7 @@ public:
         }
         pending_.push_back({d_bases, d_seg_off, n_seg});
         for (;;) {
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
             EvTimer t(stream_);
             hipLaunchKernelGGL(k_count_segments<W>, dim3(grid_for(n_seg)), dim3(256), 0, stream_, d_bases,
                                d_seg_off, (uint32_t)n_seg, k_, table_view(), (uint32_t *)(ctl_.p + 1),
@@ -525,6 +599,7 @@ public:
         // records per slice: mean run length is ~(WBLK+1)/2 k-mers (shorter if max_n caps it); 2x slack
         const uint64_t per_rec = pp_.max_n >= 16 ? 4 : 2;
         uint64_t cap = inst_ub / (per_rec * P * pp_.G) + 32 + env_u64("SHK_SLICE_PAD", 0);
+        if (cap_override_) { cap = cap_override_; cap_override_ = 0; }      // (pass 1 repeated with the room the first run asked for)
         for (int attempt = 0; attempt < 2; attempt++) {
             // The 256 producer workgroups append to slices [p][0..G) at the same time; when consecutive slices lie
             // (almost) a multiple of 2 KB apart their writes keep meeting in the same memory channels
@@ -538,7 +613,7 @@ public:
             if (int rc = recs_.alloc(n_slices * cap * RW, err)) return rc;
             if (int rc = fill_.alloc(n_slices, err)) return rc;
             HIPCHK(hipMemsetAsync(fill_.p, 0, n_slices * 4, stream_));
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
             EvTimer t(stream_);
             if (h_bases && attempt == 0) {
                 // ---- upload and pass 1, piece by piece
@@ -564,11 +639,17 @@ public:
                     else launch_partition<8>(d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
                 }
                 HIPCHK(hipGetLastError());
+                times_.add("h2d_pieces_x1", (double)C);
+                if (defer_p1_ && batches_.empty()) {            // (as below: pass 2 follows without a host round trip)
+                    HIPCHK(hipMemcpyAsync(mbox64() + MB_P1, ctl_.p + 8, 16, hipMemcpyDeviceToHost, stream_));
+                    t.stop_later("partition_with_upload", pending_timers_);
+                    p1_ = P1Pending{true, d_bases, d_seg_off, n_seg, n_bases, cap};
+                    return finish_partition(n_slices, err);
+                }
                 t.mark();
                 unsigned long long h[2];
                 HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
                 WAIT_STREAM();
-                times_.add("h2d_pieces_x1", (double)C);
                 const uint32_t *fl = (const uint32_t *)&h[0];
                 if (fl[1]) { err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
                 if ((uint32_t)h[1] <= cap) {
@@ -582,6 +663,16 @@ public:
             }
             launch_partition_all(wblk, d_bases, d_seg_off, n_seg);
             HIPCHK(hipGetLastError());
+            if (defer_p1_ && attempt == 0 && batches_.empty() && piece_list_.empty()) {
+                // ONE batch whose reads outlive histogram() (the packed entry points): pass 2 is launched behind pass 1 without a
+                // host round trip; the flags land in pinned memory and are looked at after pass 2's own read-back.  A slice
+                // that overflowed stored nothing beyond its room (wave_flush) and its run is clamped (k_make_runs): pass 2 then
+                // ran on a part of the records and both passes are repeated with the exact room (histogram()).
+                HIPCHK(hipMemcpyAsync(mbox64() + MB_P1, ctl_.p + 8, 16, hipMemcpyDeviceToHost, stream_));
+                t.stop_later("partition_kernel", pending_timers_);
+                p1_ = P1Pending{true, d_bases, d_seg_off, n_seg, n_bases, cap};
+                return finish_partition(n_slices, err);
+            }
             t.mark();
             unsigned long long h[2];
             HIPCHK(hipMemcpyAsync(h, ctl_.p + 8, sizeof h, hipMemcpyDeviceToHost, stream_));
@@ -705,6 +796,7 @@ public:
         return 0;
     }
     void set_bloom(bool on) override { bloom_ = on; }
+    void single_batch_resident(bool on) override { defer_p1_ = on && !global_mode_; }
     void expect_more_batches() override { if (!forced_P_ && batches_.empty() && !have_parts_) forced_P_ = (uint32_t)PART_MAX_P; }
 
     // pass 2 into (keys, cnt) with the given emit threshold; sizes the output by retrying.
@@ -743,7 +835,7 @@ public:
             for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
             if (int rc = cnt.alloc(cap, err)) return rc;
             HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
@@ -963,8 +1055,28 @@ public:
                     }
                 }
                 split_ready_ = true;
-                if (int rc = run_count_partitions(run_view_, n_count_parts_, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
-                                                  inst_ub_rows, ms, err)) { split_ready_ = false; return rc; }
+                int rc_p2 = run_count_partitions(run_view_, n_count_parts_, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
+                                                 inst_ub_rows, ms, err);
+                if (p1_.on) {
+                    // pass 1's flags arrived with pass 2's read-back (count_batch_impl): look at them now
+                    if (rc_p2) { std::string e2; (void)e2; (void)hipStreamSynchronize(stream_); }
+                    p1_.on = false;
+                    const unsigned long long *h = mbox64() + MB_P1;
+                    const uint32_t *fl = (const uint32_t *)&h[0];
+                    if (fl[1]) { split_ready_ = false; err = "a read segment exceeds 32768 bases (split it on the host)"; return -1; }
+                    if ((uint32_t)h[1] > p1_.cap) {
+                        // a slice overflowed: both passes again, pass 1 with the exact room (the reads are still on the device)
+                        times_.add("partition_retry", 1.0);
+                        cap_override_ = (uint64_t)(uint32_t)h[1] + 8;
+                        have_parts_ = false; split_ready_ = false;
+                        const bool d = defer_p1_; defer_p1_ = false;
+                        const int rc1 = count_batch_impl(p1_.d_bases, p1_.d_seg_off, nullptr, nullptr, p1_.n_seg, p1_.n_bases, err);
+                        defer_p1_ = d;
+                        if (rc1) return rc1;
+                        return histogram(histo, emit_threshold, err);
+                    }
+                }
+                if (rc_p2) { split_ready_ = false; return rc_p2; }
                 split_ready_ = false;
                 times_.add("count_kernel", ms);
                 total_instances_ = inst;
@@ -1001,7 +1113,7 @@ public:
         for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(expect, err)) return rc;
         if (int rc = cnt.alloc(expect, err)) return rc;
         if (!tslots_ || !expect) return 0;
-        HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
         KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
         hipLaunchKernelGGL(k_compact<W>, dim3(grid_for(tslots_)), dim3(256), 0, stream_, table_view(), tslots_,
                            threshold, ok, cnt.p, ctl_.p + 0);
@@ -1031,7 +1143,7 @@ public:
             if (threshold < emit_threshold_) { err = "filter threshold below the emit threshold"; return -6; }
             for (int j = 0; j < W; j++) if (int rc = skeys_[j].alloc(expect, err)) return rc;
             if (int rc = scnt_.alloc(expect, err)) return rc;
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
             KeyArr<W> ik, ok;
             for (int j = 0; j < W; j++) { ik.w[j] = ekeys_[j].p; ok.w[j] = skeys_[j].p; }
             hipLaunchKernelGGL(k_compact_rows<W>, dim3(grid_for(n_emitted_)), dim3(256), 0, stream_, ik, ecnt_.p,
@@ -1290,7 +1402,7 @@ public:
         HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));   // (the mini tables are initialised by their builders)
         // (no fills for adj_ and alive_: k_graph_local writes the adjacency byte of every row before k_graph_remote ORs
         // into it, k_row_starts sets the alive flags)
-        HIPCHK(hipMemsetAsync(ctl_.p, 0, 16 * sizeof(unsigned long long), stream_));
+        HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
         // (sharded assembly: a rank that holds NO solid k-mer still owns partitions and is asked about neighbour candidates by
         // the others — its (empty) mini tables must exist: found by the 250-case campaign on 4 ranks, where such a rank answered
         // from tables nobody had built and took a memory fault)
@@ -1353,15 +1465,29 @@ public:
                 }
             }
             HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
-            unsigned long long h[3];
-            HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
-            WAIT_STREAM();
-            if ((uint32_t)h[1] || h[2] > gt_slots_) { err = "graph table overflow"; return -6; }
+            // (the overflow flags of the tables are read with the next counters that come back anyway — the correction's or the
+            // collapse's: check_graph_flags(); the sharded assembly reads them here)
+            graph_check_pending_ = true;
+            if (sh_active_) {
+                HIPCHK(hipMemcpyAsync(mbox64() + MB_CTL, ctl_.p, 3 * 8, hipMemcpyDeviceToHost, stream_));
+                WAIT_STREAM();
+                if (int rc = check_graph_flags(err)) return rc;
+            }
+            // (the big scratch of this phase goes back to the pool now, not when the entry point ends: see DeferScope)
+            if (!sh_active_ || sh_world_ <= 1) { /* the stream is busy: parked until the call ends, or reused below */ }
         }
         graph_ready_ = true;
         return 0;
     }
 
+    // mbox64()[MB_CTL ..] holds a fresh copy of ctl_[0..2]: the graph tables' overflow flags (build_graph)
+    int check_graph_flags(std::string &err) {
+        if (!graph_check_pending_) return 0;
+        graph_check_pending_ = false;
+        const unsigned long long *h = mbox64() + MB_CTL;
+        if ((uint32_t)h[1] || h[2] > gt_slots_) { err = "graph table overflow"; return -6; }
+        return 0;
+    }
     int read_ctl(unsigned int &v, int slot, std::string &err) {
         unsigned long long h = 0;
         HIPCHK(hipMemcpyAsync(&h, ctl_.p + slot, 8, hipMemcpyDeviceToHost, stream_));
@@ -1381,62 +1507,83 @@ public:
         return 0;
     }
 
+    // SPEC S9.  The FIRST round is launched without waiting for its outcome: what it removed (ctl_[16], ctl_[17]) comes back
+    // with the first counters of the collapse, whose first two kernels return at once when the round did remove something
+    // (rank_chains) — an error-free isolate, where the round finds nothing, pays no host round trip for the correction.
+    // Further rounds (reads with errors) run from finish_correction(), one read-back per round as before.
     int correct(bool tips, bool bubbles, std::string &err) override {
         if (!graph_ready_) { err = "graph not built"; return -2; }
         const uint32_t n = (uint32_t)n_solid_;
         tips_removed_ = bubbles_removed_ = 0; rounds_ = 0;
+        corr_pending_ = false; corr_tips_ = tips; corr_bubbles_ = bubbles;
         if (n == 0 || (!tips && !bubbles)) return 0;
-        Graph<W> g = graph_view();
-        DevBuf<uint32_t> cand, tip_head, removed;
-        DevBuf<uint8_t> mark, kill;
-        DevBuf<TipRec> tiprec;
-        if (int rc = cand.alloc(2ull * n, err)) return rc;
-        if (int rc = removed.alloc(n, err)) return rc;
-        if (int rc = mark.alloc(n, err)) return rc;
-        if (!tips) HIPCHK(hipMemsetAsync(mark.p, 0, n, stream_));       // (with tips: k_tip_candidates clears it in the first round)
+        if (int rc = corr_.cand.alloc(2ull * n, err)) return rc;
+        if (int rc = corr_.removed.alloc(n, err)) return rc;
+        if (int rc = corr_.mark.alloc(n, err)) return rc;
+        if (!tips) HIPCHK(hipMemsetAsync(corr_.mark.p, 0, n, stream_));       // (with tips: k_tip_candidates clears it in the first round)
         if (tips) {
             // every candidate may turn out to be a tip: sized for all oriented nodes, so that no count has to
             // come back to the host inside a round (the counters live in ctl_: 3 candidates, 4 tips, 5/6 removed)
-            if (int rc = tip_head.alloc(2ull * n, err)) return rc;
-            if (int rc = tiprec.alloc(2ull * n, err)) return rc;
-            if (int rc = kill.alloc(2ull * n, err)) return rc;
+            if (int rc = corr_.tip_head.alloc(2ull * n, err)) return rc;
+            if (int rc = corr_.tiprec.alloc(2ull * n, err)) return rc;
+            if (int rc = corr_.kill.alloc(2ull * n, err)) return rc;
             // (tip_head := NIL by k_tip_candidates in the first round)
         }
         EvTimer t(stream_);
+        if (int rc = correction_round(0, err)) return rc;
+        t.stop_later("correct_total", pending_timers_);
+        corr_pending_ = true;
+        return 0;
+    }
+    struct CorrScratch { DevBuf<uint32_t> cand, tip_head, removed; DevBuf<uint8_t> mark, kill; DevBuf<TipRec> tiprec;
+                         void release() { cand.release(); tip_head.release(); removed.release(); mark.release(); kill.release(); tiprec.release(); } };
+    // one round of S9 on the stream; removal counts go to ctl_[16], ctl_[17] (round 0) or ctl_[5], ctl_[6]
+    int correction_round(int round, std::string &err) {
+        const uint32_t n = (uint32_t)n_solid_;
+        Graph<W> g = graph_view();
         const dim3 G(1024), B(256);
-        for (int round = 0; round < 32; round++) {
-            HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
-            if (tips) {
-                hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
-                                   cand.p, (unsigned int *)(ctl_.p + 3), round == 0 ? (uint2 *)tip_head.p : (uint2 *)nullptr,
-                                   round == 0 ? mark.p : (uint8_t *)nullptr);
-                hipLaunchKernelGGL(k_tip_walk<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3),
-                                   tiprec.p, (unsigned int *)(ctl_.p + 4), tip_head.p);
-                hipLaunchKernelGGL(k_tip_decide<W>, G, B, 0, stream_, g, tiprec.p, (const unsigned int *)(ctl_.p + 4),
-                                   tip_head.p, kill.p);
-                hipLaunchKernelGGL(k_tip_remove<W>, G, B, 0, stream_, g, tiprec.p, (const unsigned int *)(ctl_.p + 4),
-                                   kill.p, tip_head.p, mark.p);
-                hipLaunchKernelGGL(k_tip_reset_heads, G, B, 0, stream_, tiprec.p, (const unsigned int *)(ctl_.p + 4),
-                                   tip_head.p);
-                HIPCHK(hipGetLastError());
-                if (int rc = apply_marks(g, mark, removed, 5, err)) return rc;
-            }
-            if (bubbles) {
-                HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
-                hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
-                                   cand.p, (unsigned int *)(ctl_.p + 3));
-                hipLaunchKernelGGL(k_bubble<W>, G, B, 0, stream_, g, cand.p, (const unsigned int *)(ctl_.p + 3), mark.p);
-                HIPCHK(hipGetLastError());
-                if (int rc = apply_marks(g, mark, removed, 6, err)) return rc;
-            }
-            unsigned long long h[2];
-            HIPCHK(hipMemcpyAsync(h, ctl_.p + 5, sizeof h, hipMemcpyDeviceToHost, stream_));
-            WAIT_STREAM();
-            const unsigned int n1 = (unsigned int)h[0], n2 = (unsigned int)h[1];
-            tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
-            if (n1 + n2 == 0) break;
+        const bool tips = corr_tips_, bubbles = corr_bubbles_;
+        const int s_tip = round == 0 ? 16 : 5, s_bub = round == 0 ? 17 : 6;
+        HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
+        if (tips) {
+            hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
+                               corr_.cand.p, (unsigned int *)(ctl_.p + 3), round == 0 ? (uint2 *)corr_.tip_head.p : (uint2 *)nullptr,
+                               round == 0 ? corr_.mark.p : (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_tip_walk<W>, G, B, 0, stream_, g, corr_.cand.p, (const unsigned int *)(ctl_.p + 3),
+                               corr_.tiprec.p, (unsigned int *)(ctl_.p + 4), corr_.tip_head.p);
+            hipLaunchKernelGGL(k_tip_decide<W>, G, B, 0, stream_, g, corr_.tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                               corr_.tip_head.p, corr_.kill.p);
+            hipLaunchKernelGGL(k_tip_remove<W>, G, B, 0, stream_, g, corr_.tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                               corr_.kill.p, corr_.tip_head.p, corr_.mark.p);
+            hipLaunchKernelGGL(k_tip_reset_heads, G, B, 0, stream_, corr_.tiprec.p, (const unsigned int *)(ctl_.p + 4),
+                               corr_.tip_head.p);
+            HIPCHK(hipGetLastError());
+            if (int rc = apply_marks(g, corr_.mark, corr_.removed, s_tip, err)) return rc;
         }
-        times_.add("correct_total", t.stop());
+        if (bubbles) {
+            HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
+            hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
+                               corr_.cand.p, (unsigned int *)(ctl_.p + 3));
+            hipLaunchKernelGGL(k_bubble<W>, G, B, 0, stream_, g, corr_.cand.p, (const unsigned int *)(ctl_.p + 3), corr_.mark.p);
+            HIPCHK(hipGetLastError());
+            if (int rc = apply_marks(g, corr_.mark, corr_.removed, s_bub, err)) return rc;
+        }
+        return 0;
+    }
+    // the first round's outcome is known (n1 tips, n2 bubble nodes removed): run the remaining rounds, if any
+    int finish_correction(unsigned int n1, unsigned int n2, std::string &err) {
+        corr_pending_ = false;
+        tips_removed_ += n1; bubbles_removed_ += n2; rounds_ = 1;
+        EvTimer t(stream_);
+        for (int round = 1; round < 32 && n1 + n2 != 0; round++) {
+            if (int rc = correction_round(round, err)) return rc;
+            HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC, ctl_.p + 5, 16, hipMemcpyDeviceToHost, stream_));
+            WAIT_STREAM();
+            n1 = (unsigned int)mbox64()[MB_MISC]; n2 = (unsigned int)mbox64()[MB_MISC + 1];
+            tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
+        }
+        if (rounds_ > 1) times_.add("correct_total", t.stop());
+        corr_.release();                                  // (the stream is idle or holds nothing that uses them)
         return 0;
     }
 
@@ -1487,16 +1634,30 @@ public:
         HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 .. 8 as above, 9 = alive oriented nodes, 10 = nodes walked
         const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
         EvTimer t1(stream_);
-        hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
-                           alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9);
         const uint32_t tile_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_TILE_ROWS", LF_ROWS), 1), LF_TILE / 2u);
         const int lf_grid = (int)((n + tile_rows - 1) / tile_rows);
-        stage("k_succ_split");
-        hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask);
-        HIPCHK(hipGetLastError());
-        stage("k_local_frag");
         unsigned int n_spl = 0;
-        if (int rc = read_ctl(n_spl, 5, err)) return rc;
+        for (int pass = 0; pass < 2; pass++) {
+            // (pass 0 may run behind a first correction round whose outcome is not known yet: the two kernels return at once
+            // when that round removed something — ctl_[16], ctl_[17] — and run again, pass 1, once the correction is complete)
+            const unsigned long long *skip = (pass == 0 && corr_pending_) ? ctl_.p + 16 : (const unsigned long long *)nullptr;
+            hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
+                               alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9, skip);
+            stage("k_succ_split");
+            hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask, skip);
+            HIPCHK(hipGetLastError());
+            stage("k_local_frag");
+            HIPCHK(hipMemcpyAsync(mbox64() + MB_CTL, ctl_.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, stream_));
+            WAIT_STREAM();
+            const unsigned long long *hc0 = mbox64() + MB_CTL;
+            if (int rc = check_graph_flags(err)) return rc;
+            n_spl = (unsigned int)hc0[5];
+            if (!corr_pending_) break;
+            const unsigned int r1 = (unsigned int)hc0[16], r2 = (unsigned int)hc0[17];
+            if (int rc = finish_correction(r1, r2, err)) return rc;
+            if (r1 + r2 == 0) break;
+            HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));
+        }
         times_.add("collapse_succ_split", t1.stop());
         times_.add("collapse_n_splitters_x1e-3", n_spl * 1e-3);
         // circular unitigs without a sampled node add one splitter each (k_orphan_cycles): room for them
@@ -1557,12 +1718,15 @@ public:
         unsigned long long hc[4];
         // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
         // round trip just for them is 30-40 us of idle GPU)
-        constexpr unsigned int HEADS_SPEC = 512;
+        constexpr unsigned int HEADS_SPEC = 512;                           // (40 bytes each, into the pinned mailbox)
+        static_assert(MB_MISC * 8 + 4 * 8 + HEADS_SPEC * sizeof(HeadRec) <= MBOX_BYTES, "mailbox");
         std::vector<HeadRec> &heads = cs.heads;
         heads.assign(HEADS_SPEC, HeadRec());
-        HIPCHK(hipMemcpyAsync(hc, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipMemcpyAsync(heads.data(), cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC + 4, cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
         WAIT_STREAM();
+        memcpy(hc, mbox64() + MB_MISC, sizeof hc);
+        memcpy(heads.data(), mbox64() + MB_MISC + 4, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec));
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
@@ -1578,9 +1742,10 @@ public:
         return 0;
     }
 
-    int collapse(std::vector<RawContig> &out, std::string &err, const char **json, size_t *json_len, uint64_t *n_contigs) override {
+    int collapse(std::vector<RawContig> &out, std::string &err, const char **json, size_t *json_len, uint64_t *n_contigs, TextArrival **arrival) override {
         out.clear();
         if (json) *json = nullptr;
+        if (arrival) *arrival = nullptr;
         if (!graph_ready_) { err = "graph not built"; return -2; }
         const uint32_t n = (uint32_t)n_solid_;
         if (n == 0) return 0;
@@ -1646,14 +1811,44 @@ public:
             HIPCHK(hipGetLastError());
             times_.add("collapse_emit", t3.stop());
             auto tcp = std::chrono::steady_clock::now();
-            HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
-            WAIT_STREAM();
             out.reserve(emitted.size());
             for (uint32_t i : emitted) {
                 RawContig rc; rc.kc = heads[i].kc;
                 rc.ext = hout.p + head_off[i].off; rc.ext_n = heads[i].len + (uint64_t)(k_ - 1);
                 out.push_back(std::move(rc));
             }
+            const uint64_t pipe_min = env_u64("SHK_ARRIVAL_MIN", 1u << 20);
+            if (arrival && out_bytes >= pipe_min && emitted.size() <= 4096) {
+                // ---- megabases of text: the writer starts while the text is still crossing PCIe.  First the ends of every
+                // contig (all that order, links and strand checks read), then the text slab by slab, a flag behind each.
+                const uint32_t E = (uint32_t)std::max(k_, 32), nc = (uint32_t)emitted.size();
+                std::vector<unsigned long long> &src = ends_src_host_;       // (a member: read by an asynchronous copy)
+                src.resize(2 * (size_t)nc);
+                for (uint32_t c = 0; c < nc; c++) { src[2 * c] = head_off[emitted[c]].off; src[2 * c + 1] = heads[emitted[c]].len + (uint64_t)(k_ - 1); }
+                const uint32_t n_slabs = (uint32_t)((out_bytes + ARRIVAL_SLAB - 1) / ARRIVAL_SLAB);
+                if (int rc = ends_src_.alloc(2 * (size_t)nc, err)) return rc;
+                if (int rc = hends_.alloc((size_t)nc * 2 * E, err)) return rc;
+                if (int rc = hflags_.alloc(((size_t)n_slabs + 16) * 4, err)) return rc;
+                volatile uint32_t *flags = (volatile uint32_t *)hflags_.p;       // [0] the ends, [16 ..] the slabs
+                memset(hflags_.p, 0, ((size_t)n_slabs + 16) * 4);
+                HIPCHK(hipMemcpyAsync(ends_src_.p, src.data(), src.size() * 8, hipMemcpyHostToDevice, stream_));
+                hipLaunchKernelGGL(k_ends_to_host, dim3(1), dim3(1024), 0, stream_, d_out.p, ends_src_.p, nc, E, hends_.p, (uint32_t *)hflags_.p);
+                const uint32_t grid = (uint32_t)std::min<uint64_t>(n_slabs, env_u64("SHK_ARRIVAL_BLOCKS", 64));
+                hipLaunchKernelGGL(k_text_to_host, dim3(grid), dim3(256), 0, stream_, d_out.p, hout.p, (unsigned long long)out_bytes, n_slabs, (uint32_t *)hflags_.p + 16);
+                HIPCHK(hipGetLastError());
+                d_out_keep_.swap(d_out);                                     // (the source of a copy that outlives this function)
+                arrival_.set(hout.p, out_bytes, flags + 16, n_slabs, stream_);
+                if (!SlabArrival::spin_until(flags, arrival_.failed_)) { (void)hipStreamSynchronize(stream_); err = "collapse: the contigs' ends did not arrive"; return -5; }
+                for (uint32_t c = 0; c < nc; c++) {
+                    out[c].head = hends_.p + (size_t)c * 2 * E; out[c].tail = out[c].head + E;
+                    out[c].ends_n = (uint32_t)std::min<uint64_t>(E, out[c].ext_n);
+                }
+                *arrival = &arrival_;
+                times_.add("collapse_ends_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
+                return 0;
+            }
+            HIPCHK(hipMemcpyAsync(hout.p, d_out.p, out_bytes, hipMemcpyDeviceToHost, stream_));
+            WAIT_STREAM();
             times_.add("collapse_d2h_contigs_host_clock", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tcp).count());
         }
         return 0;
@@ -1835,7 +2030,6 @@ public:
         std::vector<uint64_t> all((size_t)row * world);
         HIPCHK(hipMemcpyAsync(all.data(), rt_all_.p, all.size() * 8, hipMemcpyDeviceToHost, stream_));
         WAIT_STREAM();
-        times_.add("shard_host_waits_x1", 1.0);
         bool peer_failed = false;
         for (uint32_t s = 0; s < world; s++) if (all[(size_t)s * row + world] & LOCAL_FAIL) peer_failed = true;
         if (peer_failed) {                                    // every rank sees the same row: all leave here
@@ -1882,12 +2076,17 @@ public:
     int shard_assemble(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) override {
         sh_agreed_ = false;
         wd_comm_ = (c && comm_world(c) > 1) ? c : nullptr;
+        const uint64_t waits0 = n_host_waits_;
         const int rc = shard_assemble_impl(c, tips, bubbles, out, err);
+        times_.add("shard_host_waits_x1", (double)(n_host_waits_ - waits0));     // stream waits + host-side collectives of this call
         if (rc && wd_comm_ && !sh_agreed_) comm_abort_now(c);
         drain();                                           // (through the watchdog: the stream may hold collectives of a call that failed)
         wd_comm_ = nullptr;
         return rc;
     }
+    // (the host-side collectives wait for the stream: counted like the stream waits)
+    int counted_allreduce_host_u64(ShardComm *c, uint64_t *v, size_t n, void *st, std::string &e) { n_host_waits_++; return comm_allreduce_host_u64(c, v, n, st, e); }
+    int counted_allgather_host_u64(ShardComm *c, const uint64_t *in, size_t n, uint64_t *out, void *st, std::string &e) { n_host_waits_++; return comm_allgather_host_u64(c, in, n, out, st, e); }
     int shard_assemble_impl(ShardComm *c, bool tips, bool bubbles, std::vector<RawContig> &out, std::string &err) {
         // SHK_STAGE_LOG=1: after every step the stream is drained and the step's name goes to stderr (which step a fault belongs to)
         const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;
@@ -1906,7 +2105,7 @@ public:
         auto agree = [&](int local_rc, const char *stage) -> int {
             uint64_t f = local_rc ? 1u : 0u;
             std::string e2;
-            if (int rc = comm_allreduce_host_u64(c, &f, 1, stream_, e2)) { if (local_rc) return local_rc; err = e2; return rc; }
+            if (int rc = counted_allreduce_host_u64(c, &f, 1, stream_, e2)) { if (local_rc) return local_rc; err = e2; return rc; }
             if (f) sh_agreed_ = true;                        // (every rank has seen the flag and leaves)
             if (local_rc) return local_rc;
             if (f) { err = std::string("sharded assembly: another rank failed during ") + stage; return -5; }
@@ -1981,7 +2180,7 @@ public:
         {
             uint64_t mine[2] = {rc_chain ? 0u : n_lch, rc_chain ? 1u : 0u};
             std::vector<uint64_t> all2((size_t)world * 2);
-            if (int rc = comm_allgather_host_u64(c, mine, 2, all2.data(), stream_, err)) { if (rc_chain) return rc_chain; return rc; }
+            if (int rc = counted_allgather_host_u64(c, mine, 2, all2.data(), stream_, err)) { if (rc_chain) return rc_chain; return rc; }
             if (rc_chain) { sh_agreed_ = true; return rc_chain; }
             for (uint32_t r = 0; r < world; r++) { if (all2[2 * r + 1]) { sh_agreed_ = true; err = "sharded assembly: another rank failed during the local contraction"; return -5; } lcnt[r] = all2[2 * r]; }
             for (uint32_t r = 0; r < world; r++) lbase[r + 1] = lbase[r] + lcnt[r];
@@ -2156,7 +2355,7 @@ public:
                 HIPCHK(hipMemcpyAsync(h_pmin.data(), pmin.p, (size_t)n_rings * 8, hipMemcpyDeviceToHost, stream_));
                 WAIT_STREAM();
             }
-            if (int rc = comm_allgather_host_u64(c, h_pmin.data(), n_rings, all_pmin.data(), stream_, err)) return rc;
+            if (int rc = counted_allgather_host_u64(c, h_pmin.data(), n_rings, all_pmin.data(), stream_, err)) return rc;
             for (uint32_t i = 0; i < n_rings; i++) for (uint32_t r = 0; r < world; r++) h_pmin[i] = std::min(h_pmin[i], all_pmin[(size_t)r * n_rings + i]);
             std::vector<uint64_t> h_rep((size_t)n_rings * (W + 2), ~0ull), all_rep((size_t)world * n_rings * (W + 2));
             if (n_lch) {
@@ -2167,7 +2366,7 @@ public:
                 HIPCHK(hipMemcpyAsync(h_rep.data(), rep.p, h_rep.size() * 8, hipMemcpyDeviceToHost, stream_));
                 WAIT_STREAM();
             }
-            if (int rc = comm_allgather_host_u64(c, h_rep.data(), h_rep.size(), all_rep.data(), stream_, err)) return rc;
+            if (int rc = counted_allgather_host_u64(c, h_rep.data(), h_rep.size(), all_rep.data(), stream_, err)) return rc;
             std::vector<UnitigMinKey> mk(n_u);
             for (uint32_t i = 0; i < n_rings; i++) {
                 UnitigMinKey best;
@@ -2268,6 +2467,17 @@ private:
     std::vector<EvTimer::Pending> pending_timers_;
     int n_cus_ = 256;
     DevBuf<unsigned long long> ctl_;
+    PinnedBuf mbox_;                                 // pinned host words the small device-to-host copies land in (truly asynchronous)
+    unsigned long long *mbox64() { return (unsigned long long *)mbox_.p; }
+    static constexpr size_t MBOX_BYTES = 32768;
+    static constexpr int MB_P1 = 0 /* 2 words: pass 1's flags */, MB_CTL = 8 /* CTL_WORDS words: a copy of ctl_ */, MB_MISC = 64;
+    struct P1Pending { bool on; const uint32_t *d_bases, *d_seg_off; uint64_t n_seg, n_bases, cap; };
+    P1Pending p1_{false, nullptr, nullptr, 0, 0, 0};
+    uint64_t n_host_waits_ = 0;                      // host waits on the stream so far (WAIT_STREAM, host-side collectives)
+    bool graph_check_pending_ = false, corr_pending_ = false, corr_tips_ = false, corr_bubbles_ = false;
+    CorrScratch corr_;
+    bool defer_p1_ = false;                          // set by the packed entry points: the batch is the only one and its reads outlive histogram()
+    uint64_t cap_override_ = 0;
     // count table
     DevBuf<uint64_t> tkeys_[W]; DevBuf<uint32_t> tcnt_, tstate_; uint64_t tslots_ = 0;
     struct Batch { const uint32_t *bases, *seg_off; uint64_t n_seg; };
@@ -2299,6 +2509,10 @@ private:
     DevBuf<uint8_t> adj_, adj0_, alive_;
     DevBuf<uint32_t> row_starts_;                    // one bit per solid row: a group of rows of one minimiser partition starts here (k_row_starts)
     PinnedBuf hout_;                  // contigs as downloaded; RawContig::ext points into it
+    PinnedBuf hends_, hflags_;        // their first / last bases (RawContig::head / tail) and the arrival flags when the text arrives slab by slab
+    SlabArrival arrival_;
+    DevBuf<char> d_out_keep_; DevBuf<unsigned long long> ends_src_;
+    std::vector<unsigned long long> ends_src_host_;
     PinnedBuf hjson_;                 // the JSON of a fragmented assembly, written on the device (device_write_json)
     DevBuf<uint32_t> nb_;
     bool graph_ready_ = false;

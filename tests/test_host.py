@@ -410,3 +410,56 @@ def test_peak_device_memory_counter(lib):
         p, c = C.c_uint64(0), C.c_uint64(0)
         lib.shk_host_mem_counter(arr, len(deltas), C.byref(p), C.byref(c))
         assert (p.value, c.value) == (peak, cur)
+
+
+def _writer_json_arriving(lib, contigs, k, piece, delay_us=0):
+    seqs = "".join(s for s, _ in contigs).encode()
+    off = np.zeros(len(contigs) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s, _ in contigs])
+    kc = np.array([c for _, c in contigs], dtype=np.uint64)
+    p = lib.shk_host_assembly_json_arriving(seqs, off.ctypes.data, kc.ctypes.data, len(contigs), k, piece, delay_us)
+    assert p
+    try:
+        return C.string_at(p).decode()
+    finally:
+        lib.shk_host_free(p)
+
+
+def test_writer_on_text_that_is_still_arriving(lib, monkeypatch):
+    """The device path hands the writer contigs whose text is still crossing PCIe (pipeline.h: TextArrival): order, links
+    and the strand check read the contigs' ENDS, the copies wait for their bytes.  With text released piece by piece from
+    another thread — buffer pre-filled with garbage — the JSON must equal the one of the complete text: big contigs
+    (copied in pieces), small ones (copied inline), contigs handed in on the larger strand (a reverse complement has to be
+    built: the writer waits for everything), palindromes and ties on length + 32 bases (the ends do not decide)."""
+    rng = np.random.default_rng(11)
+
+    def rnd(n):
+        return "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+
+    def canon(s):
+        r = revcomp(s)
+        return min(s, r)
+    k = 31
+    big = canon(rnd(2_500_000))
+    mid = [canon(rnd(int(n))) for n in rng.integers(300_000, 400_000, 3)]
+    small = [canon(rnd(int(n))) for n in rng.integers(k, 3000, 40)]
+    half = rnd(500)
+    pal = half + revcomp(half)                                   # its own reverse complement
+    tie_a = rnd(40) + "A" + rnd(200); tie_b = tie_a[:41][:-1] + "C" + rnd(200)    # same length, same first 32 bases
+    tie_a, tie_b = canon(tie_a), canon(tie_b)
+    cases = [
+        [(big, 5)],
+        [(big, 5)] + [(s, 3) for s in mid] + [(s, 2) for s in small],
+        [(revcomp(big), 5), (mid[0], 1)],                        # the larger strand: revcomp needed
+        [(pal, 4), (big, 9), (tie_a, 1), (tie_b, 1)],
+        [(s, 2) for s in small],
+    ]
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("SHK_WRITER_PAR_MIN", "1")
+        for items in cases:
+            ref = _writer_json(lib, items, k)
+            for piece, delay in ((1 << 16, 0), (300_000, 50), (1 << 22, 0), (7919, 0)):
+                if piece < 50_000 and sum(len(s) for s, _ in items) > 1_000_000:
+                    continue
+                assert _writer_json_arriving(lib, items, k, piece, delay) == ref, (forced, len(items), piece)
