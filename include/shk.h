@@ -45,7 +45,11 @@ typedef void (*shk_progress_cb)(const char *state, void *user);
 
 /* AssemblyHelper::new(k, verbose, min_count, min_qual, chunk_size, do_bloom, do_fit,
  *                     no_bubble_collapse, no_dead_end_removal)        Assembler.ts:15-29,94-99
- * Same nine parameters, same order.  Returns NULL on failure; shk_new_error() tells why. */
+ * Same nine parameters, same order.  Returns NULL on failure; shk_new_error() tells why.
+ * verbose: results never depend on it.  A verbose handle also records per-stage HIP-event timers (shk_get_timings) and keeps
+ * the initial adjacency bytes for shk_get_adjacency; a quiet one times the two counting passes only — an event between two
+ * kernels costs the GPU ~10 us — and drops what only the inspection reads (SHK_STAGE_TIMERS=1 / SHK_KEEP_STAGES=1 turn
+ * either on for quiet handles). */
 shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qual,
                     uint64_t chunk_size, int do_bloom, int do_fit,
                     int no_bubble_collapse, int no_dead_end_removal);

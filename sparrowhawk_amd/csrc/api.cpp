@@ -156,6 +156,7 @@ shk_handle *shk_new(uint32_t k, int verbose, uint32_t min_count, uint32_t min_qu
     }
     if (!h->pipe) { g_new_err = SHK_E_DEVICE; g_new_msg = err; delete h; return nullptr; }
     h->pipe->set_bloom(h->do_bloom);
+    h->pipe->set_verbose(h->verbose);
     return h;
 }
 

@@ -193,8 +193,12 @@ __global__ __launch_bounds__(LF_THREADS) void k_local_frag(uint32_t n_rows, cons
                                                            const uint8_t *__restrict__ alive,
                                                            const uint2 *__restrict__ winfo, uint2 *__restrict__ ol,
                                                            FragRec *__restrict__ frag, uint32_t split_mask,
-                                                           const unsigned long long *__restrict__ skip = nullptr /* as k_succ_split */) {
+                                                           const unsigned long long *__restrict__ skip = nullptr /* as k_succ_split */,
+                                                           unsigned int *__restrict__ n_spl_p = nullptr, uint32_t seg_cap = 0, uint32_t *__restrict__ flags = nullptr) {
     if (skip && (skip[0] | skip[1])) return;
+    // (k_succ_split is complete: its splitter count is final.  More splitters than the ranking has room for — the host sized
+    // it from a bound, without reading the count: the ranking is called off (flag 4, the count beside it) and repeated)
+    if (n_spl_p && blockIdx.x == 0 && threadIdx.x == 0 && *n_spl_p > seg_cap) { flags[1] = *n_spl_p; flags[0] = 4; *n_spl_p = 0; }
     __shared__ uint16_t l_succ[LF_TILE];       // local index of the successor; LF_STOP: the fragment ends here; LF_DONE: a walker has passed
     __shared__ uint32_t l_cnt[LF_TILE];        // count; once passed: (local head << 13) | position in the fragment
     __shared__ uint16_t l_heads[LF_TILE];
@@ -272,11 +276,12 @@ static constexpr uint32_t HEAD_LINEAR = 1, HEAD_ORPHAN = 2;
 // one walker per splitter: from fragment to fragment until the next splitter (a fragment that starts at a splitter
 // got its owner in k_succ_split; the others get theirs here)
 template <int W>
-__global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__ spl, uint32_t n_spl,
+__global__ __launch_bounds__(256) void k_walk_frags(const uint32_t *__restrict__ spl, const unsigned int *__restrict__ n_spl_p,
                                                     FragRec *__restrict__ frag, SegRec *__restrict__ segs,
                                                     uint32_t split_mask, unsigned long long *__restrict__ n_covered /* += nodes walked */,
                                                     uint32_t total /* oriented nodes */, uint32_t *__restrict__ flags) {
     unsigned long long my_cov = 0;
+    const uint32_t n_spl = *n_spl_p;                           // (the count stays on the device; 0 when the ranking was called off)
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_spl; i += gridDim.x * blockDim.x) {
         const uint32_t s = spl[i];
         uint32_t cur = s, len = 0, nxt, last, is_head = 0;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(256) void k_orphan_cycles(Graph<W> g, const uint8_t
                                                        uint32_t seg_cap, uint32_t *__restrict__ flags,
                                                        const unsigned long long *__restrict__ n_alive,
                                                        const unsigned long long *__restrict__ n_covered) {
-    if (*n_alive == *n_covered) return;                    // every alive node has an owner: no such ring (the usual case)
+    if (*n_alive == *n_covered || flags[0] == 4u) return;  // every alive node has an owner: no such ring (the usual case); or the ranking was called off
     const uint32_t total = g.n * 2;
     for (uint32_t v = blockIdx.x * blockDim.x + threadIdx.x; v < total; v += gridDim.x * blockDim.x) {
         if (!alive[v >> 1]) continue;
@@ -371,8 +376,17 @@ __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ se
 // ceil(log2 n) launches of two); heads point to themselves with A = K = 0, so overshooting adds nothing
 static constexpr int RANK_HOPS = 4;
 __global__ __launch_bounds__(256) void k_rank_jump(const unsigned int *__restrict__ n_spl_p,
-                                                   const RankRec *__restrict__ Ri, RankRec *__restrict__ Ro) {
+                                                   const RankRec *__restrict__ Ri, RankRec *__restrict__ Ro, uint32_t round = 0) {
     const uint32_t n_spl = *n_spl_p;
+    // (the host launches ceil(log4(room)) rounds without knowing the count; once 4^round covers the list every pointer has
+    // reached its head and every window spans its ring: the round only carries the records over to the other buffer)
+    {
+        unsigned long long reach = 1; for (uint32_t r = 0; r < round; r++) reach *= RANK_HOPS;
+        if (reach >= (unsigned long long)n_spl + 1ull) {
+            for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) Ro[s] = Ri[s];
+            return;
+        }
+    }
     for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_spl; s += gridDim.x * blockDim.x) {
         uint32_t p = s, a = 0, bm = 0xFFFFFFFFu, bd = 0;
         unsigned long long kc = 0, bdk = 0;
@@ -464,7 +478,11 @@ __global__ __launch_bounds__(256) void k_rank_fin(const SegRec *__restrict__ seg
 // chunks as k_local_frag (a fragment never leaves its chunk); nodes that k_orphan_cycles re-homed are fragments of their own.
 __global__ __launch_bounds__(LF_THREADS) void k_tile_final(uint32_t n_rows, const uint32_t *__restrict__ row_starts, uint32_t tile_rows,
                                                            uint2 *__restrict__ ol, const FragRec *__restrict__ frag,
-                                                           const FinRec *__restrict__ fin) {
+                                                           const FinRec *__restrict__ fin,
+                                                           const unsigned long long *__restrict__ skip = nullptr /* as k_succ_split */,
+                                                           const uint32_t *__restrict__ flags = nullptr /* [0] == 4: the ranking was called off */) {
+    if (skip && (skip[0] | skip[1])) return;
+    if (flags && flags[0] == 4u) return;
     __shared__ uint2 l_chain[LF_TILE];         // per local fragment head: {chain record, nodes of the chain before the fragment}
     __shared__ uint32_t t_lo, t_hi;
     tile_bounds(row_starts, n_rows, tile_rows, &t_lo, &t_hi);

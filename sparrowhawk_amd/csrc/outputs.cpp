@@ -537,9 +537,7 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     char *base = (char *)js.data();
     base[total] = 0;
     // sequences above `big` bytes are cut out of their record and copied in pieces by all threads
-    struct Copy { const char *src; char *dst; size_t n; };
     const size_t big = std::max<size_t>(par_min / 4, 1);
-    const size_t piece = (size_t)256 << 10;
     std::vector<std::pair<char *, std::pair<const char *, size_t>>> deferred;     // (filled by PtrSink::seq)
     std::mutex deferred_mu;
     for (size_t p = 0; p < parts.size(); p++) memcpy(base + part_off[p], parts[p].lit.data(), parts[p].lit.size());
@@ -551,21 +549,31 @@ void build_assembly_text(std::vector<RawContig> &contigs, uint32_t k, AssemblyTe
     if (ranges.size() > 1 && (many || seq_bytes >= par_min)) wp.run(ranges.size(), write_range);
     else for (size_t r = 0; r < ranges.size(); r++) write_range(r);
     if (!deferred.empty()) {
-        std::vector<Copy> copies;
-        for (auto &d : deferred)
-            for (size_t o = 0; o < d.second.second; o += piece)
-                copies.push_back(Copy{d.second.first + o, d.first + o, std::min(piece, d.second.second - o)});
-        if (arrival) {
-            // the pieces in the order of their arrival: the three copies of a piece (FASTA, GFA1, GFA2) follow one another
-            std::sort(copies.begin(), copies.end(), [](const Copy &a, const Copy &b) { return a.src != b.src ? a.src < b.src : a.dst < b.dst; });
-            TextArrival *arr = arrival;
-            wp.run(copies.size(), [&copies, arr](size_t i) {
-                const Copy &c = copies[i];
-                if (c.src >= arr->base() && c.src < arr->base() + arr->total()) { const size_t o = (size_t)(c.src - arr->base()); arr->wait_range(o, o + c.n); }
-                memcpy(c.dst, c.src, c.n);
-            });
-        } else
-        wp.run(copies.size(), [&](size_t i) { memcpy(copies[i].dst, copies[i].src, copies[i].n); });
+        // one task = one piece of a source sequence and ALL its destinations (a contig goes into FASTA, GFA1 and GFA2): the
+        // piece is read from memory once — text that has just arrived over PCIe sits in no cache — and written three times
+        // from the core's cache.  Tasks are taken in the order of the sources, which is the order the text arrives in.
+        std::sort(deferred.begin(), deferred.end(), [](const auto &x, const auto &y) { return x.second.first != y.second.first ? x.second.first < y.second.first : x.first < y.first; });
+        struct Task { const char *src; size_t n; uint32_t first, count; };         // destinations: dsts[first .. first + count)
+        std::vector<char *> dsts;
+        std::vector<Task> tasks;
+        const size_t piece2 = (size_t)128 << 10;
+        for (size_t i = 0; i < deferred.size();) {
+            size_t j = i;
+            while (j < deferred.size() && deferred[j].second.first == deferred[i].second.first && deferred[j].second.second == deferred[i].second.second) j++;
+            const char *src = deferred[i].second.first; const size_t n = deferred[i].second.second;
+            for (size_t o = 0; o < n; o += piece2) {
+                Task t{src + o, std::min(piece2, n - o), (uint32_t)dsts.size(), (uint32_t)(j - i)};
+                for (size_t q = i; q < j; q++) dsts.push_back(deferred[q].first + o);
+                tasks.push_back(t);
+            }
+            i = j;
+        }
+        TextArrival *arr = arrival;
+        wp.run(tasks.size(), [&tasks, &dsts, arr](size_t i) {
+            const Task &t = tasks[i];
+            if (arr && t.src >= arr->base() && t.src < arr->base() + arr->total()) { const size_t o = (size_t)(t.src - arr->base()); arr->wait_range(o, o + t.n); }
+            for (uint32_t q = 0; q < t.count; q++) memcpy(dsts[t.first + q], t.src, t.n);
+        });
     }
     if (arrival) arrival->wait_all();
     WorkPool::get().prewarm(0);                         // the writer is done: the workers go back to sleep

@@ -61,6 +61,9 @@ public:
     // do_bloom (docs/src/assembly.md:18): partitions that go through the k-mer-level repartition pass a Bloom
     // pre-filter first, so their singletons are never stored; counts may then be one too high, never too low
     virtual void set_bloom(bool on) = 0;
+    // verbose handle (AssemblyHelper.new's second argument): per-stage HIP-event timers and the stage data the inspection
+    // calls serve (initial adjacency) are kept; a quiet handle times the two counting passes only
+    virtual void set_verbose(bool on) = 0;
     // the next count_batch / count_batch_host hands over the ONLY batch of this handle and its packed reads stay where they are
     // until histogram() has returned: pass 2 may then be launched behind pass 1 without a host round trip in between
     virtual void single_batch_resident(bool on) = 0;

@@ -274,6 +274,8 @@ DeferScope::~DeferScope() {
 // handle's stream ends in a synchronize, so a pooled stream is idle
 static std::mutex g_stream_mu;
 static std::multimap<int, hipStream_t> &stream_cache() { static auto *c = new std::multimap<int, hipStream_t>(); return *c; }
+// (key: device, or device + 1000 for the copy streams of the host-buffer entry points — creating and destroying one per
+// handle cost ~1 ms of the 5.7 ms a step from host pinned memory took: profiles/r04)
 static hipStream_t stream_pool_get(int dev) {
     std::lock_guard<std::mutex> lk(g_stream_mu);
     auto it = stream_cache().find(dev);
@@ -281,10 +283,14 @@ static hipStream_t stream_pool_get(int dev) {
     hipStream_t s = it->second; stream_cache().erase(it); return s;
 }
 static void stream_pool_put(int dev, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    if (stream_cache().size() < 16) { stream_cache().emplace(dev, s); return; }
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        if (stream_cache().size() < 32) { stream_cache().emplace(dev, s); return; }
+    }
     (void)hipStreamDestroy(s);
 }
+
+static std::mutex &upload_token(int dev) { static std::mutex m[16]; return m[(unsigned)dev % 16u]; }
 
 static inline int grid_for(uint64_t work, int block = 256, int max_blocks = 256 * 16) {
     uint64_t b = (work + block - 1) / block;
@@ -311,10 +317,14 @@ static inline hipError_t stream_wait(hipStream_t s) {
 
 struct EvTimer {
     hipEvent_t a, b; hipStream_t st; bool ok = false;
-    explicit EvTimer(hipStream_t s) : st(s) {
+    // (an event recorded between two kernels costs the GPU a bubble of ~10 us on the stream — measured, profiles/r04: the
+    // stage timers are therefore off unless asked for; `on` = false makes every method a no-op that reports 0)
+    explicit EvTimer(hipStream_t s, bool on = true) : st(s) {
+        if (!on) return;
         ok = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
         if (ok) (void)hipEventRecord(a, st);
     }
+    bool on() const { return ok; }
     double stop() {
         if (!ok) return 0.0;
         (void)hipEventRecord(b, st); (void)hipEventSynchronize(b);
@@ -440,7 +450,7 @@ public:
     ~Pipeline() override {
         drain();                                            // (the member buffers go back to the pool idle)
         EvTimer::resolve(pending_timers_, times_);
-        if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); (void)hipStreamDestroy(copy_stream_); }
+        if (copy_stream_) { (void)hipStreamSynchronize(copy_stream_); stream_pool_put(stream_dev_ + 1000, copy_stream_); }
         if (stream_) stream_pool_put(stream_dev_, stream_);
     }
     int init(std::string &err) {
@@ -620,13 +630,18 @@ public:
                 uint64_t C = env_u64("SHK_H2D_PIECES", 4);
                 if (C < 1) C = 1;
                 while (C > 1 && n_seg / C < (uint64_t)PART_THREADS * pp_.G) C--;          // every piece fills the chip
+                if (!copy_stream_) copy_stream_ = stream_pool_get(stream_dev_ + 1000);
                 if (!copy_stream_) HIPCHK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
                 const uint64_t n_words = (n_bases + 15) / 16 + 1;
                 std::vector<hipEvent_t> evs((size_t)C, nullptr);
                 struct EvGuard { std::vector<hipEvent_t> &v; ~EvGuard() { for (auto e : v) if (e) (void)hipEventDestroy(e); } } evg{evs};
                 // on every way out, errors included, the copy stream is idle: the caller's host buffers and the device
                 // blocks (which go back to a pool without stream-ordering bookkeeping) are no longer read or written
-                struct CopyDrain { hipStream_t s; ~CopyDrain() { (void)hipStreamSynchronize(s); } } copy_drain{copy_stream_};
+                // ONE upload at a time per device: two handles in flight that upload together halve each other's PCIe rate while the
+                // GPU waits for both (measured: both at 42 GB/s for 3.2 ms, kernels idle meanwhile); in turn, one uploads at the
+                // full rate under the kernels of the other.  The token is held until this upload has drained.
+                struct CopyDrain { hipStream_t s; std::unique_lock<std::mutex> token; ~CopyDrain() { (void)hipStreamSynchronize(s); } }
+                    copy_drain{copy_stream_, std::unique_lock<std::mutex>(upload_token(stream_dev_))};
                 for (uint64_t c = 0; c < C; c++) {
                     const uint64_t s0 = n_seg * c / C, s1 = n_seg * (c + 1) / C;
                     const uint64_t w0 = h_seg_off[s0] >> 4, w1 = std::min<uint64_t>(n_words, (((uint64_t)h_seg_off[s1] + 15) >> 4) + 1);
@@ -726,10 +741,10 @@ public:
         for (uint32_t p = 0; p < pp_.P; p++) b->part_off[p + 1] = b->part_off[p] + h[p];
         if (int rc = b->dense.alloc(b->part_off[pp_.P] * RW + 2, err)) return rc;
         HIPCHK(hipMemcpyAsync(base.p, b->part_off.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         hipLaunchKernelGGL((k_pack_partition<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, recs_.p, fill_.p, pp_, base.p, b->dense.p);
         HIPCHK(hipGetLastError());
-        times_.add("batch_pack_kernel", t.stop());
+        if (t.on()) times_.add("batch_pack_kernel", t.stop());
         WAIT_STREAM();
         batches_.push_back(std::move(b));
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
@@ -758,7 +773,7 @@ public:
         EvTimer t(stream_);
         hipLaunchKernelGGL((k_merge_runs<RW>), dim3(pp_.P), dim3(256), 0, stream_, run_view_, base.p, m->dense.p);
         HIPCHK(hipGetLastError());
-        times_.add("batch_merge_kernel", t.stop());
+        if (t.on()) times_.add("batch_merge_kernel", t.stop());
         WAIT_STREAM();
         batches_.clear();
         batches_.push_back(std::move(m));
@@ -796,6 +811,7 @@ public:
         return 0;
     }
     void set_bloom(bool on) override { bloom_ = on; }
+    void set_verbose(bool on) override { if (on) { stage_timers_ = true; keep_stages_ = true; } }
     void single_batch_resident(bool on) override { defer_p1_ = on && !global_mode_; }
     void expect_more_batches() override { if (!forced_P_ && batches_.empty() && !have_parts_) forced_P_ = (uint32_t)PART_MAX_P; }
 
@@ -841,7 +857,6 @@ public:
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
             // (two-kernel path: the sample is ONE round of the fused kernel — a partition per CU)
             const uint32_t n_sample = split && n_probe ? std::min<uint32_t>(n_probe / 2, (uint32_t)n_cus_) : 0u;
-            EvTimer t_split(stream_);
             EvTimer t(stream_);
             if (split) {
                 // (every attempt: the partitions the dedupe hands over are reported in d_ovf / ctl_, which an attempt starts empty)
@@ -860,7 +875,7 @@ public:
                                        (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_sample, n_probe / 8);
                     HIPCHK(hipGetLastError());
                 }
-                EvTimer t_a(stream_);
+                EvTimer t_a(stream_, stage_timers_);
                 hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(n_parts - n_sample, 2u * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
                                    rv, n_sample, n_parts, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
                                    d_ovf.p, (uint32_t *)(ctl_.p + 3), n_sample ? n_probe / 8 : 0u, (S / 10) * 9);
@@ -887,12 +902,11 @@ public:
             }
             HIPCHK(hipGetLastError());
             t.mark();
-            if (split) t_split.mark();
             unsigned long long h[4];
             HIPCHK(hipMemcpyAsync(h, ctl_.p, sizeof h, hipMemcpyDeviceToHost, stream_));
             HIPCHK(hipMemcpyAsync(hist_out, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));   // (final unless partitions overflowed)
             WAIT_STREAM();          // one host round trip: counters, histogram and the timer
-            ms_out = split ? t_split.elapsed() : t.elapsed();      // (dedupe + count)
+            ms_out = t.elapsed();      // (sample + dedupe + count)
             const uint32_t n_ovf = (uint32_t)h[3];
             // rows written by the bucket path are ordered by key hash, not grouped by minimiser partition (build_graph regroups)
             rows_scattered_ = (uint64_t)n_ovf * 4u > n_parts;
@@ -1088,11 +1102,11 @@ public:
         if (int rc = dh.alloc(500, err)) return rc;
         HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
         if (tslots_) {
-            EvTimer t(stream_);
+            EvTimer t(stream_, stage_timers_);
             hipLaunchKernelGGL(k_histogram<W>, dim3(grid_for(tslots_)), dim3(256), 0, stream_, table_view(),
                                tslots_, dh.p);
             HIPCHK(hipGetLastError());
-            times_.add("histogram_kernel", t.stop());
+            if (t.on()) times_.add("histogram_kernel", t.stop());
         }
         HIPCHK(hipMemcpyAsync(histo, dh.p, 500 * 8, hipMemcpyDeviceToHost, stream_));
         WAIT_STREAM();
@@ -1130,7 +1144,7 @@ public:
         if (threshold >= 500) { err = "threshold out of range"; return -1; }
         for (uint32_t c = 1; c <= 500; c++) if (c > threshold) expect += histo_[c - 1];
         if (expect >= 0x7FFFFFFFull) { err = "too many solid k-mers for 32-bit node ids"; return -1; }
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         if (global_mode_) {
             if (int rc = compact_into(threshold, expect, skeys_, scnt_, err)) return rc;
         } else if (threshold == emit_threshold_ || n_emitted_ == 0) {
@@ -1156,7 +1170,7 @@ public:
             for (int j = 0; j < W; j++) ekeys_[j].release();
             ecnt_.release();
         }
-        times_.add("filter_kernel", t.stop());
+        if (t.on()) times_.add("filter_kernel", t.stop());
         n_solid_ = expect;
         graph_ready_ = false;
         return 0;
@@ -1226,11 +1240,11 @@ public:
         DevBuf<unsigned long long> base;
         if (int rc = base.alloc(pp_.P, err)) return rc;
         HIPCHK(hipMemcpyAsync(base.p, base_records, (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         hipLaunchKernelGGL((k_pack_partition<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, recs_.p, fill_.p, pp_, base.p,
                            (uint64_t *)d_send);
         HIPCHK(hipGetLastError());
-        times_.add("shard_pack_kernel", t.stop());
+        if (t.on()) times_.add("shard_pack_kernel", t.stop());
         WAIT_STREAM();
         // the local slices are no longer needed once packed
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
@@ -1252,7 +1266,7 @@ public:
         if (int rc = dd_w_.alloc(n_raw + 2, err)) return rc;
         HIPCHK(hipMemcpyAsync(dd_base_.p, base.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
         HIPCHK(hipMemsetAsync(ctl_.p + 12, 0, 8, stream_));
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
                            run_view_, 0u, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
                            (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
@@ -1276,11 +1290,11 @@ public:
         DevBuf<unsigned long long> base;
         if (int rc = base.alloc(pp_.P, err)) return rc;
         HIPCHK(hipMemcpyAsync(base.p, base_records, (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         hipLaunchKernelGGL((k_pack_dedup<2 * W>), dim3(pp_.P), dim3(256), 0, stream_, dd_recs_.p, dd_w_.p, dd_base_.p, dd_n_.p, base.p,
                            (uint64_t *)d_send, (uint32_t *)d_send_w);
         HIPCHK(hipGetLastError());
-        times_.add("shard_pack_kernel", t.stop());
+        if (t.on()) times_.add("shard_pack_kernel", t.stop());
         WAIT_STREAM();
         shard_drop_dedup();
         recs_.release(); fill_.release(); run_off_.release(); run_cnt_.release(); have_parts_ = false;
@@ -1395,7 +1409,7 @@ public:
         DevBuf<unsigned long long> queries;              // 8 slots per row, grouped by partition; only a prefix is touched
         if (int rc = queries.alloc(8 * n + 8, err)) return rc;
         if (int rc = adj_.alloc((n + 8) & ~3ull, err)) return rc;
-        if (int rc = adj0_.alloc(n, err)) return rc;
+        if (keep_stages_) if (int rc = adj0_.alloc(n, err)) return rc;
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
         if (int rc = row_starts_.alloc(((n + 63) / 64) * 2 + 2, err)) return rc;
@@ -1408,7 +1422,7 @@ public:
         // from tables nobody had built and took a memory fault)
         if (n || sh_active_) {
             Graph<W> g = graph_view();
-            EvTimer t(stream_);
+            EvTimer t(stream_, stage_timers_);
             hipLaunchKernelGGL(k_gp_count<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g.keys, (uint32_t)n, k_, g.gt,
                                gp_of.p, gp_cnt.p);
             hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, gp_roff.p,
@@ -1440,7 +1454,7 @@ public:
             hipLaunchKernelGGL(k_row_starts, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, std::min<uint32_t>(gp_, 256u) - 1u,
                                row_starts_.p, alive_.p);
             t.stop_later("graph_table_kernel", pending_timers_);
-            EvTimer t2(stream_);
+            EvTimer t2(stream_, stage_timers_);
             hipLaunchKernelGGL(k_graph_local<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, gp_rows.p,
                                adj_.p, nb_.p, queries.p, gp_cnt.p, (uint32_t *)(ctl_.p + 1));
             hipLaunchKernelGGL(k_graph_remote<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, g.gt, gp_roff.p, queries.p,
@@ -1464,7 +1478,7 @@ public:
                     HIPCHK(hipGetLastError());
                 }
             }
-            HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));
+            if (keep_stages_) HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));      // (stage inspection only)
             // (the overflow flags of the tables are read with the next counters that come back anyway — the correction's or the
             // collapse's: check_graph_flags(); the sharded assembly reads them here)
             graph_check_pending_ = true;
@@ -1529,7 +1543,7 @@ public:
             if (int rc = corr_.kill.alloc(2ull * n, err)) return rc;
             // (tip_head := NIL by k_tip_candidates in the first round)
         }
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         if (int rc = correction_round(0, err)) return rc;
         t.stop_later("correct_total", pending_timers_);
         corr_pending_ = true;
@@ -1574,7 +1588,7 @@ public:
     int finish_correction(unsigned int n1, unsigned int n2, std::string &err) {
         corr_pending_ = false;
         tips_removed_ += n1; bubbles_removed_ += n2; rounds_ = 1;
-        EvTimer t(stream_);
+        EvTimer t(stream_, stage_timers_);
         for (int round = 1; round < 32 && n1 + n2 != 0; round++) {
             if (int rc = correction_round(round, err)) return rc;
             HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC, ctl_.p + 5, 16, hipMemcpyDeviceToHost, stream_));
@@ -1582,7 +1596,7 @@ public:
             n1 = (unsigned int)mbox64()[MB_MISC]; n2 = (unsigned int)mbox64()[MB_MISC + 1];
             tips_removed_ += n1; bubbles_removed_ += n2; rounds_++;
         }
-        if (rounds_ > 1) times_.add("correct_total", t.stop());
+        if (rounds_ > 1) if (t.on()) times_.add("correct_total", t.stop());
         corr_.release();                                  // (the stream is idle or holds nothing that uses them)
         return 0;
     }
@@ -1592,6 +1606,7 @@ public:
         if (!graph_ready_) { err = "graph not built"; return -2; }
         if (cap < n_solid_) { err = "buffer too small"; return -1; }
         if (!n_solid_) return 0;
+        if (adj_initial && !keep_stages_) { err = "the initial adjacency is kept for inspection only on a verbose handle (or with SHK_KEEP_STAGES=1)"; return -2; }
         if (adj_initial) HIPCHK(hipMemcpy(adj_initial, adj0_.p, n_solid_, hipMemcpyDeviceToHost));
         if (adj_final) HIPCHK(hipMemcpy(adj_final, adj_.p, n_solid_, hipMemcpyDeviceToHost));
         if (alive) HIPCHK(hipMemcpy(alive, alive_.p, n_solid_, hipMemcpyDeviceToHost));
@@ -1617,6 +1632,12 @@ public:
     };
     // rings: also find the smallest k-mer of every circular chain and the strand / rotation it is spelled with (single GPU);
     // the sharded assembly settles rings across ranks itself (shard_graph.h)
+    // ONE host round trip: everything from the simple links to the ranked chains is launched back to back and the counters
+    // come home with the first chain records.  What the host used to fetch in between is handled on the device or by a
+    // bound: the splitter list gets room for total/12 + 65536 entries (a 1/64 sample plus the heads: ~2-4 % of the oriented
+    // nodes; if a graph needs more the kernels stop and the pass is repeated with room for all), the number of pointer-jumping
+    // rounds comes from that room, and the launch may sit behind a first correction round whose outcome is not known yet —
+    // then the kernels return at once when that round removed something, the correction is finished and the pass repeated.
     int rank_chains(ChainState &cs, bool rings, std::string &err, uint32_t keep_on_device_from = 0xFFFFFFFFu) {
         const uint32_t n = (uint32_t)n_solid_;
         const uint32_t total = 2 * n;
@@ -1631,106 +1652,103 @@ public:
         if (int rc = cs.frag.alloc(total, err)) return rc;
         if (int rc = cs.spl.alloc(total, err)) return rc;
         if (int rc = cs.ol.alloc(total, err)) return rc;
-        HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 .. 8 as above, 9 = alive oriented nodes, 10 = nodes walked
         const uint32_t split_mask = (1u << (uint32_t)env_u64("SHK_SPLIT_LOG", SPLIT_LOG_DEFAULT)) - 1u;
-        EvTimer t1(stream_);
         const uint32_t tile_rows = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_TILE_ROWS", LF_ROWS), 1), LF_TILE / 2u);
         const int lf_grid = (int)((n + tile_rows - 1) / tile_rows);
-        unsigned int n_spl = 0;
-        for (int pass = 0; pass < 2; pass++) {
-            // (pass 0 may run behind a first correction round whose outcome is not known yet: the two kernels return at once
-            // when that round removed something — ctl_[16], ctl_[17] — and run again, pass 1, once the correction is complete)
-            const unsigned long long *skip = (pass == 0 && corr_pending_) ? ctl_.p + 16 : (const unsigned long long *)nullptr;
+        const uint64_t cap_all = std::min<uint64_t>((uint64_t)total + 1024u, 0xFFFFFFF0ull);      // every alive oriented node a splitter or an orphan ring of its own
+        uint64_t seg_cap64 = std::min<uint64_t>(cap_all, env_u64("SHK_SEG_CAP", (uint64_t)total / 12u + 65536u));
+        constexpr unsigned int HEADS_SPEC = 512;                           // (40 bytes each, into the pinned mailbox)
+        static_assert(MB_MISC * 8 + HEADS_SPEC * sizeof(HeadRec) <= MBOX_BYTES, "mailbox");
+        std::vector<HeadRec> &heads = cs.heads;
+        unsigned long long hc[4] = {0, 0, 0, 0};
+        uint32_t seg_cap = 0;
+        EvTimer tr(stream_, stage_timers_);
+        for (int attempt = 0;; attempt++) {
+            if (attempt > 3) { err = "collapse: the chain ranking did not settle"; return -6; }
+            seg_cap = (uint32_t)seg_cap64;
+            cs.seg_cap = seg_cap;
+            if (int rc = cs.segs.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.Ra.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.Rb.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.slot_of.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.fin.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.d_heads.alloc(seg_cap, err)) return rc;
+            if (int rc = cs.ringmin.alloc(seg_cap, err)) return rc;
+            const unsigned long long *skip = corr_pending_ ? ctl_.p + 16 : (const unsigned long long *)nullptr;
+            HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 splitters, 6 chains, 7 ring splitters, 8 flags, 9 alive oriented nodes, 10 nodes walked
+            HIPCHK(hipMemsetAsync(cs.slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
+            unsigned int *d_nspl = (unsigned int *)(ctl_.p + 5);
+            uint32_t *d_flags = (uint32_t *)(ctl_.p + 8);
             hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
-                               alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, (unsigned int *)(ctl_.p + 5), split_mask, ctl_.p + 9, skip);
+                               alive_.p, cs.winfo.p, cs.spl.p, cs.ol.p, d_nspl, split_mask, ctl_.p + 9, skip);
             stage("k_succ_split");
-            hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask, skip);
-            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_local_frag<W>, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, alive_.p, cs.winfo.p, cs.ol.p, cs.frag.p, split_mask, skip,
+                               d_nspl, seg_cap, d_flags);
             stage("k_local_frag");
+            // (grids: the expected 1/64 sample plus a margin; the kernels loop to the device-side count)
+            hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for((uint64_t)total / 64u + 16384u, 256, 1 << 20)), dim3(256), 0, stream_,
+                               cs.spl.p, (const unsigned int *)d_nspl, cs.frag.p, cs.segs.p, split_mask, ctl_.p + 10, total, d_flags);
+            stage("k_walk_frags");
+            hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, cs.winfo.p, cs.ol.p,
+                               cs.frag.p, cs.spl.p, cs.segs.p, d_nspl, seg_cap, d_flags, ctl_.p + 9, ctl_.p + 10);
+            HIPCHK(hipGetLastError());
+            stage("k_orphan_cycles");
+            // ---- rank the splitter list on the device: prefix sums by pointer jumping, rings in the same pass (collapse.h)
+            const int gr = grid_for((uint64_t)total / 64u + 65536u);
+            // (a chain has at most seg_cap splitters; rounds past the point where every pointer has reached its head add nothing)
+            int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)seg_cap + 1u) { reach *= RANK_HOPS; rounds++; } }
+            hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, cs.segs.p, (const unsigned int *)d_nspl, cs.Ra.p);
+            RankRec *Ri = cs.Ra.p, *Ro = cs.Rb.p;
+            for (int r = 0; r < rounds; r++) {
+                hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, (const unsigned int *)d_nspl, Ri, Ro, (uint32_t)r);
+                std::swap(Ri, Ro);
+            }
+            stage("k_rank_jump");
+            const unsigned int *d_ncyc = (const unsigned int *)(ctl_.p + 7);
+            hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, cs.segs.p, (const unsigned int *)d_nspl, Ri, cs.d_heads.p, cs.slot_of.p, cs.ringmin.p,
+                               (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
+            hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, cs.segs.p, (const unsigned int *)d_nspl, Ri, cs.slot_of.p, cs.fin.p);
+            stage("k_rank_tails + k_rank_fin");
+            hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, cs.ol.p, cs.frag.p, cs.fin.p, skip, (const uint32_t *)d_flags);
+            stage("k_tile_final");
+            if (rings) {
+                // rings: their smallest k-mer (these three return at once when there is none)
+                hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
+                hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
+                hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), cs.ringmin.p,
+                                   cs.winfo.p, cs.ol.p, d_ncyc, d_flags);
+            }
+            HIPCHK(hipGetLastError());
+            // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
+            // round trip just for them is 30-40 us of idle GPU)
+            heads.assign(HEADS_SPEC, HeadRec());
             HIPCHK(hipMemcpyAsync(mbox64() + MB_CTL, ctl_.p, CTL_WORDS * 8, hipMemcpyDeviceToHost, stream_));
+            HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC, cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
             WAIT_STREAM();
             const unsigned long long *hc0 = mbox64() + MB_CTL;
             if (int rc = check_graph_flags(err)) return rc;
-            n_spl = (unsigned int)hc0[5];
-            if (!corr_pending_) break;
-            const unsigned int r1 = (unsigned int)hc0[16], r2 = (unsigned int)hc0[17];
-            if (int rc = finish_correction(r1, r2, err)) return rc;
-            if (r1 + r2 == 0) break;
-            HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));
-        }
-        times_.add("collapse_succ_split", t1.stop());
-        times_.add("collapse_n_splitters_x1e-3", n_spl * 1e-3);
-        // circular unitigs without a sampled node add one splitter each (k_orphan_cycles): room for them
-        const uint32_t seg_cap = n_spl + total / 8u + 1024u;
-        cs.seg_cap = seg_cap;
-        if (int rc = cs.segs.alloc(seg_cap, err)) return rc;
-        const unsigned int *d_nspl = (const unsigned int *)(ctl_.p + 5);
-        {
-            EvTimer t2(stream_);
-            if (n_spl) {
-                hipLaunchKernelGGL(k_walk_frags<W>, dim3(grid_for(n_spl, 256, 1 << 20)), dim3(256), 0, stream_,
-                                   cs.spl.p, n_spl, cs.frag.p, cs.segs.p, split_mask, ctl_.p + 10, total, (uint32_t *)(ctl_.p + 8));
+            if (corr_pending_) {
+                // the first correction round's outcome: if it removed nodes the kernels above returned at once (or did nothing:
+                // no splitters) — the remaining rounds run now, then the pass is repeated on the final graph
+                const unsigned int r1 = (unsigned int)hc0[16], r2 = (unsigned int)hc0[17];
+                if (int rc = finish_correction(r1, r2, err)) return rc;
+                if (r1 + r2 != 0) continue;
             }
-            stage("k_walk_frags");
-            hipLaunchKernelGGL(k_orphan_cycles<W>, dim3(grid_for(total)), dim3(256), 0, stream_, g, alive_.p, cs.winfo.p, cs.ol.p,
-                               cs.frag.p, cs.spl.p, cs.segs.p, (unsigned int *)(ctl_.p + 5), seg_cap, (uint32_t *)(ctl_.p + 8), ctl_.p + 9, ctl_.p + 10);
-            HIPCHK(hipGetLastError());
-            t2.stop_later("collapse_walk", pending_timers_);
+            memcpy(hc, hc0 + 5, sizeof hc);
+            const uint32_t flag = (uint32_t)hc[3];
+            if ((flag == 4 || flag == 2) && seg_cap64 < cap_all) {        // more splitters (4) or orphan rings (2) than the room: once more with room for all
+                times_.add("collapse_seg_cap_retry_x1", 1.0);
+                seg_cap64 = cap_all;
+                continue;
+            }
+            memcpy(heads.data(), mbox64() + MB_MISC, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec));
+            break;
         }
-        // ---- rank the splitter list on the device: prefix sums by pointer jumping, rings in the same pass (collapse.h)
-        if (int rc = cs.Ra.alloc(seg_cap, err)) return rc;
-        if (int rc = cs.Rb.alloc(seg_cap, err)) return rc;
-        if (int rc = cs.slot_of.alloc(seg_cap, err)) return rc;
-        if (int rc = cs.fin.alloc(seg_cap, err)) return rc;
-        if (int rc = cs.d_heads.alloc(seg_cap, err)) return rc;
-        if (int rc = cs.ringmin.alloc(seg_cap, err)) return rc;
-        // (the list may have grown by the orphan cycles; grids cover the n_spl the host knows plus a margin, the
-        // kernels loop to the device-side count)
-        const int gr = grid_for((uint64_t)n_spl + 65536u);
-        // (a chain has at most n_spl splitters: the ones k_orphan_cycles appends are chains of their own)
-        int rounds = 1; { uint64_t reach = RANK_HOPS; while (reach < (uint64_t)n_spl + 1u) { reach *= RANK_HOPS; rounds++; } }
-        stage("k_orphan_cycles");
-        EvTimer tr(stream_);
-        HIPCHK(hipMemsetAsync(cs.slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
-        hipLaunchKernelGGL(k_rank_init, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, cs.Ra.p);
-        stage("k_rank_init");
-        RankRec *Ri = cs.Ra.p, *Ro = cs.Rb.p;
-        for (int r = 0; r < rounds; r++) {
-            hipLaunchKernelGGL(k_rank_jump, dim3(gr), dim3(256), 0, stream_, d_nspl, Ri, Ro);
-            std::swap(Ri, Ro);
-        }
-        stage("k_rank_jump");
-        const unsigned int *d_ncyc = (const unsigned int *)(ctl_.p + 7);
-        hipLaunchKernelGGL(k_rank_tails<W>, dim3(gr), dim3(256), 0, stream_, g, cs.segs.p, d_nspl, Ri, cs.d_heads.p, cs.slot_of.p, cs.ringmin.p,
-                           (unsigned int *)(ctl_.p + 6), (unsigned int *)(ctl_.p + 7));
-        hipLaunchKernelGGL(k_rank_fin, dim3(gr), dim3(256), 0, stream_, cs.segs.p, d_nspl, Ri, cs.slot_of.p, cs.fin.p);
-        stage("k_rank_tails + k_rank_fin");
-        hipLaunchKernelGGL(k_tile_final, dim3(lf_grid), dim3(LF_THREADS), 0, stream_, n, row_starts_.p, tile_rows, cs.ol.p, cs.frag.p, cs.fin.p);
-        stage("k_tile_final");
-        if (rings) {
-            // rings: their smallest k-mer (these three return at once when there is none)
-            hipLaunchKernelGGL(k_ring_min1<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
-            hipLaunchKernelGGL(k_ring_min2<W>, dim3(1024), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, cs.ringmin.p, d_ncyc);
-            hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), cs.ringmin.p,
-                               cs.winfo.p, cs.ol.p, d_ncyc, (uint32_t *)(ctl_.p + 8));
-        }
-        HIPCHK(hipGetLastError());
-        unsigned long long hc[4];
-        // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
-        // round trip just for them is 30-40 us of idle GPU)
-        constexpr unsigned int HEADS_SPEC = 512;                           // (40 bytes each, into the pinned mailbox)
-        static_assert(MB_MISC * 8 + 4 * 8 + HEADS_SPEC * sizeof(HeadRec) <= MBOX_BYTES, "mailbox");
-        std::vector<HeadRec> &heads = cs.heads;
-        heads.assign(HEADS_SPEC, HeadRec());
-        HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC, ctl_.p + 5, sizeof hc, hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipMemcpyAsync(mbox64() + MB_MISC + 4, cs.d_heads.p, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec), hipMemcpyDeviceToHost, stream_));
-        WAIT_STREAM();
-        memcpy(hc, mbox64() + MB_MISC, sizeof hc);
-        memcpy(heads.data(), mbox64() + MB_MISC + 4, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec));
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
+        times_.add("collapse_n_splitters_x1e-3", (double)(unsigned int)hc[0] * 1e-3);
         times_.add("collapse_cycle_splitters_x1e-3", (double)(unsigned int)hc[2] * 1e-3);
         const unsigned int n_heads = (unsigned int)hc[1];
-        times_.add("collapse_rank_device", tr.stop());
+        if (tr.on()) times_.add("collapse_rank_device", tr.stop());
         cs.n_heads = n_heads;
         // (sharded assembly, and fragmented assemblies headed for the device writer: the chain records stay on the device —
         // only their number is needed here)
@@ -1777,12 +1795,12 @@ public:
             if (int rc = d_out2.alloc(out_bytes2 + 16, err)) return rc;
             HIPCHK(hipMemsetAsync(ctl_.p + 14, 0, 8, stream_));
             hipLaunchKernelGGL(k_w_plan_fill, dim3(grid_for(nh)), dim3(256), 0, stream_, cs.d_heads.p, nh, (uint32_t)k_, off.p, idx.p, d_off2.p, d_c.p, (uint32_t *)(ctl_.p + 14));
-            EvTimer t3(stream_);
+            EvTimer t3(stream_, stage_timers_);
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off2.p, d_out2.p);
             HIPCHK(hipGetLastError());
             unsigned int fl9 = 0;
             if (int rc = read_ctl(fl9, 14, err)) return rc;
-            times_.add("collapse_emit", t3.stop());
+            if (t3.on()) times_.add("collapse_emit", t3.stop());
             if (fl9) { err = "device writer: a contig beyond 2^32 bases"; return -1; }
             if (n_emit == 0) { if (json) *json = nullptr; return 0; }
             if (int rc = device_write_json(g, cs, d_c, (uint32_t)n_emit, nh, d_out2.p, out_bytes2, json, json_len, err)) return rc;
@@ -1806,10 +1824,10 @@ public:
             if (int rc = d_off.alloc(head_off.size(), err)) return rc;
             if (int rc = d_out.alloc(out_bytes, err)) return rc;
             HIPCHK(hipMemcpyAsync(d_off.p, head_off.data(), head_off.size() * sizeof(EmitRec), hipMemcpyHostToDevice, stream_));
-            EvTimer t3(stream_);
+            EvTimer t3(stream_, stage_timers_);
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off.p, d_out.p);
             HIPCHK(hipGetLastError());
-            times_.add("collapse_emit", t3.stop());
+            t3.stop_later("collapse_emit", pending_timers_);
             auto tcp = std::chrono::steady_clock::now();
             out.reserve(emitted.size());
             for (uint32_t i : emitted) {
@@ -1817,7 +1835,10 @@ public:
                 rc.ext = hout.p + head_off[i].off; rc.ext_n = heads[i].len + (uint64_t)(k_ - 1);
                 out.push_back(std::move(rc));
             }
-            const uint64_t pipe_min = env_u64("SHK_ARRIVAL_MIN", 1u << 20);
+            // (off by default — SHK_ARRIVAL_MIN = smallest text in bytes that takes this path: measured on the bench isolate, one
+            // handle at a time 3.24 against 3.26 ms per step, two handles in flight 2.93 against 2.67: the writer's pool then waits
+            // for the GPU while the other handle's writer waits for the pool.  DESIGN.md section 4)
+            const uint64_t pipe_min = env_u64("SHK_ARRIVAL_MIN", ~0ull);
             if (arrival && out_bytes >= pipe_min && emitted.size() <= 4096) {
                 // ---- megabases of text: the writer starts while the text is still crossing PCIe.  First the ends of every
                 // contig (all that order, links and strand checks read), then the text slab by slab, a flag behind each.
@@ -1867,7 +1888,7 @@ public:
     int device_write_json(Graph<W> &g, ChainState &cs, DevBuf<WContig> &d_c, uint32_t nc, uint32_t n_slots, const char *d_text, uint64_t text_bytes,
                           const char **json, size_t *json_len, std::string &err) {
         typedef unsigned long long u64;
-        EvTimer tw(stream_);
+        EvTimer tw(stream_, stage_timers_);
         DevBuf<u64> keys, keys2, slen, skc; DevBuf<uint32_t> vals, vals2, rank_of_slot, rank_of_contig; DevBuf<char> tmp;
         if (int rc = keys.alloc(nc, err)) return rc;
         if (int rc = keys2.alloc(nc, err)) return rc;
@@ -1965,7 +1986,7 @@ public:
         hipLaunchKernelGGL(k_w_copy_seqs, dim3(grid_for((text_bytes + 7) / 8)), dim3(256), 0, stream_, d_text, (u64)text_bytes, d_c.p, nc, rank_of_contig.p,
                            o_fa.p, o_1s.p, o_2s.p, skc.p, B, d_js.p);
         HIPCHK(hipGetLastError());
-        times_.add("device_writer_kernels", tw.stop());
+        if (tw.on()) times_.add("device_writer_kernels", tw.stop());
         const double t0 = now_ms_();
         HIPCHK(hipMemcpyAsync(hjson_.p, d_js.p, total + 1, hipMemcpyDeviceToHost, stream_));
         WAIT_STREAM();
@@ -2116,7 +2137,7 @@ public:
         // (every buffer a collective or a kernel of this call touches lives until the call's last wait: no wait is needed for
         // a buffer's sake; the waits that remain are the ones whose RESULT the host needs)
         xq_n_ = 0;
-        EvTimer tg(stream_);
+        EvTimer tg(stream_, stage_timers_);
         const int rc_local = build_graph(err);
         if (world == 1 && rc_local) return rc_local;
         Graph<W> g = graph_view();
@@ -2141,14 +2162,14 @@ public:
             if (xq_n_) {
                 hipLaunchKernelGGL(k_xq_apply, dim3(grid_for(xq_n_)), dim3(256), 0, stream_, xq_meta_.p, rq.sidx.p, xback.p, xq_n_, adj_.p, nb_.p, xnb.p);
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));    // (stage inspection: the complete initial adjacency)
+                if (keep_stages_) HIPCHK(hipMemcpyAsync(adj0_.p, adj_.p, n, hipMemcpyDeviceToDevice, stream_));    // (stage inspection: the complete initial adjacency)
             }
         } else if (int rc = xnb.alloc(1, err)) return rc;
         tg.stop_later("shard_graph_adjacency_total", pending_timers_);
         times_.add("shard_graph_cross_queries_x1e-3", xq_n_ * 1e-3);
         stage("1 adjacency");
         // ---- 2. half links: which links across ranks are simple
-        EvTimer th(stream_);
+        EvTimer th(stream_, stage_timers_);
         DevBuf<uint32_t> xpred;                          // per local oriented node: record of hl.recv that names its simple predecessor on another rank
         if (int rc = xpred.alloc(2ull * n + 2, err)) return rc;
         HIPCHK(hipMemsetAsync(xpred.p, 0xFF, (2ull * n + 2) * 4, stream_));
@@ -2175,7 +2196,7 @@ public:
         const uint32_t n_lch = n ? (uint32_t)cs.n_heads : 0u;
         stage("3 local chains");
         // ---- 4. stitching: the local chains of all ranks, ranked by every rank
-        EvTimer ts(stream_);
+        EvTimer ts(stream_, stage_timers_);
         std::vector<uint64_t> lcnt(world, 0), lbase(world + 1, 0);
         {
             uint64_t mine[2] = {rc_chain ? 0u : n_lch, rc_chain ? 1u : 0u};
@@ -2264,7 +2285,7 @@ public:
             uheads.resize(n_u);
             if (n_u) HIPCHK(hipMemcpy(uheads.data(), d_uheads.p, (size_t)n_u * sizeof(UHead), hipMemcpyDeviceToHost));
         }
-        times_.add("shard_graph_stitch", ts.stop());
+        if (ts.on()) times_.add("shard_graph_stitch", ts.stop());
         times_.add("shard_graph_local_chains_x1e-3", n_lch * 1e-3);
         times_.add("shard_graph_unitigs_x1", (double)n_u);
         stage("4 stitching");
@@ -2408,7 +2429,7 @@ public:
         times_.add("shard_graph_unitig_host_clock", now_ms_() - t_host0);
         stage("5 unitig graph");
         // ---- 6. emission
-        EvTimer te(stream_);
+        EvTimer te(stream_, stage_timers_);
         const uint64_t text_w32 = ((text_bytes + 15) / 16 + 1) & ~1ull;           // 2-bit words (16 bases each), an even number: all-reduced as u64
         DevBuf<ULayout> d_lay; DevBuf<char> d_text; DevBuf<uint32_t> d_pack;
         if (int rc = d_lay.alloc(n_u + 1, err)) return rc;
@@ -2435,7 +2456,7 @@ public:
         }
         stage("6 emission kernels");
         WAIT_STREAM();
-        times_.add("shard_graph_emit", te.stop());
+        if (te.on()) times_.add("shard_graph_emit", te.stop());
         out.reserve(res.contigs.size());
         for (size_t i = 0; i < res.contigs.size(); i++) {
             RawContig rcg; rcg.kc = res.contigs[i].kc;
@@ -2474,6 +2495,8 @@ private:
     struct P1Pending { bool on; const uint32_t *d_bases, *d_seg_off; uint64_t n_seg, n_bases, cap; };
     P1Pending p1_{false, nullptr, nullptr, 0, 0, 0};
     uint64_t n_host_waits_ = 0;                      // host waits on the stream so far (WAIT_STREAM, host-side collectives)
+    bool stage_timers_ = env_u64("SHK_STAGE_TIMERS", 0) != 0;    // per-stage HIP-event timers (the two counting passes are always timed: the roofline needs them)
+    bool keep_stages_ = env_u64("SHK_KEEP_STAGES", 0) != 0;      // keep what only the stage inspection reads (the initial adjacency bytes)
     bool graph_check_pending_ = false, corr_pending_ = false, corr_tips_ = false, corr_bubbles_ = false;
     CorrScratch corr_;
     bool defer_p1_ = false;                          // set by the packed entry points: the batch is the only one and its reads outlive histogram()

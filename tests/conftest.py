@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the parity tests inspect stages on quiet handles too (include/shk.h: shk_new, `verbose`): keep the stage data everywhere
+    os.environ.setdefault("SHK_KEEP_STAGES", "1")
+    # ... and several tests tell from the stage timers which path a handle took ("count_dedupe_kernel", "batch_pack_kernel",
+    # "shard_graph_stitch", "device_writer_kernels"): quiet handles record them too here (bench.py runs without them)
+    os.environ.setdefault("SHK_STAGE_TIMERS", "1")
     # torch bundles its own libamdhip64 (same soname): import it BEFORE libshk_hip.so is loaded so
     # that one HIP runtime serves both and device pointers can be shared (bench.py does the same)
     try:

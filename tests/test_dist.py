@@ -578,7 +578,7 @@ def test_sharded_graph_work_per_rank_falls_with_the_rank_count():
     from util import make_dataset
     g, fq = make_dataset(3000000, 30, seed=8500)
     pr = dict(k=31, min_count=3, min_qual=20, timings=True)
-    keys = ("graph_table_kernel", "adjacency_kernel", "collapse_succ_split", "collapse_walk", "collapse_rank_device")
+    keys = ("graph_table_kernel", "adjacency_kernel", "collapse_rank_device")        # (the last one: simple links to ranked chains, one launch sequence)
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
     per_world = {}
     try:

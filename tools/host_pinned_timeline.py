@@ -1,6 +1,6 @@
-"""Two handles in flight on one GPU (two host threads, two streams): the steps bench.py times as `value_two_in_flight`,
-alone in a process so that a rocprofv3 kernel trace of it can be read by tools/busy_report.py.
-Usage: python tools/two_in_flight.py [steps] [threads]"""
+"""Packed reads in host PINNED memory -> contigs (the SURVEY 8(d) clock), one or two handles in flight, alone in a process:
+under `rocprofv3 --kernel-trace --memory-copy-trace` the trace shows whether the uploads of one handle run under the kernels
+of the other (tools/timeline_report.py).  Usage: python tools/host_pinned_timeline.py [steps] [threads]"""
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,13 +12,15 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 n_thr = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 dev = torch.device("cuda", 0)
 d_bases, d_seg, n_reads, n_bases, genome = bench.make_reads_on_device(torch, dev, 5_000_000, 100, 150, 0xEC02)
+hw = torch.empty(d_bases.numel(), dtype=torch.int32).pin_memory(); hs = torch.empty(d_seg.numel(), dtype=torch.int32).pin_memory()
+hw.copy_(d_bases); hs.copy_(d_seg); torch.cuda.synchronize()
 
 
 def step():
     h = AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
-    h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
+    h.preprocess_packed_host(hw.data_ptr(), hs.data_ptr(), n_reads, n_bases, n_reads)
     h.assemble()
-    assert raw_get_assembly(h._h)
+    assert raw_get_assembly(h._h)        # (the pointer: no 15 MB Python copy inside the timed loop)
     h.free()
 
 
@@ -42,4 +44,4 @@ for n in (4, steps):
     [t.start() for t in ths]
     [t.join() for t in ths]
     torch.cuda.synchronize()
-    print("%d steps, %d in flight: %.3f ms per step" % (n, n_thr, (time.perf_counter() - t0) / n * 1e3), flush=True)
+    print("%d steps, %d in flight, host pinned: %.3f ms per step" % (n, n_thr, (time.perf_counter() - t0) / n * 1e3), flush=True)
