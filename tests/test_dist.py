@@ -546,14 +546,21 @@ def test_sharded_graph_several_ranks(world):
     cases.append(((f"@r0\n{'A' * 60}\n+\n{'I' * 60}\n" * 2).encode(), dict(k=31, min_count=0, min_qual=0)))
     cases.append((b"@r0\nACGTACGT\n+\nIIIIIIII\n", dict(k=31, min_count=0, min_qual=0)))
     os.environ["SHK_RCCL_LIBRARY"] = mock_rccl_library()
+    # the stand-in transport at its most hostile for 3 and 4 ranks (random per-peer delays, out-of-order completion across
+    # peers, eager sends, no barrier anywhere: tests/mock_rccl/mock_rccl.cpp), plain for 2; MOCK_RCCL_JITTER overrides
+    jitter_was = os.environ.get("MOCK_RCCL_JITTER")
+    if jitter_was is None:
+        os.environ["MOCK_RCCL_JITTER"] = "1" if world >= 3 else "0"
     try:
         with tempfile.TemporaryDirectory() as d:
             cfgp = _write_cases(d, cases)
             out = os.path.join(d, "res")
-            launch(world, ["rccl_many", out, cfgp], 29800 + world, timeout=420 + 2 * int(os.environ.get("SHK_DIST_FUZZ_CASES", 30)))
+            launch(world, ["rccl_many", out, cfgp], 29800 + world, timeout=420 + 3 * int(os.environ.get("SHK_DIST_FUZZ_CASES", 30)))
             res = [json.load(open(f"{out}.{r}")) for r in range(world)]
     finally:
         os.environ.pop("SHK_RCCL_LIBRARY", None)
+        if jitter_was is None:
+            os.environ.pop("MOCK_RCCL_JITTER", None)
     for i, (fq, pr) in enumerate(cases):
         pre, asm = _oracle_jsons(fq, pr)
         for r in range(world):
@@ -598,4 +605,6 @@ def test_sharded_graph_work_per_rank_falls_with_the_rank_count():
     print("node-level kernel ms: one rank", t1, "four ranks sharing the GPU", t4, "rows", rows, "local chains", chains)
     assert max(rows) < 0.3 * sum(rows), rows
     assert all(0.03 * r < c < 0.25 * r for r, c in zip(rows, chains)), (rows, chains)
-    assert max(t4) / 4 < 0.5 * t1, (t1, t4)        # GPU time per rank ~ elapsed / ranks on the card
+    # (GPU time per rank ~ elapsed / ranks on the card; the ranks are not in step — the stand-in transport has no barrier — so
+    # a rank's elapsed stage time also holds what it waited for the card: loose bound)
+    assert max(t4) / 4 < 0.6 * t1, (t1, t4)
