@@ -117,6 +117,16 @@ bool ring_get(Comm *c, int src, char *dst, size_t n, size_t keep, bool dev) {   
     return true;
 }
 
+// a random part of the n bytes that could move now, a multiple of 16 (device addresses stay 16-byte aligned: copies of odd
+// sizes from odd device addresses are not what the library ever asks a transport for — the first jittered campaign ended in a
+// GPU memory fault at a page boundary that a run with the stages serialised did not show, and odd pieces were the one thing
+// only this stand-in did)
+size_t jitter_piece(Comm *c, size_t n) {
+    size_t m = 1 + (size_t)(c->next() % n);
+    m &= ~(size_t)15;
+    return m ? m : std::min<size_t>(n, 16);
+}
+
 // one step of one transfer; returns 1 progress, 0 none, <0 error (ncclResult as negative)
 int progress(Comm *c, Xfer &x) {
     if (x.is_send) {
@@ -131,7 +141,7 @@ int progress(Comm *c, Xfer &x) {
         }
         if (x.done == x.bytes) return 0;
         size_t n = std::min({space, x.bytes - x.done, PIECE_MAX});
-        if (c->jitter && n > 64) n = 1 + (size_t)(c->next() % n);
+        if (c->jitter && n > 64) n = jitter_piece(c, n);
         if (!n) return 0;
         const bool dev = x.hsrc == nullptr;
         if (!ring_put(c, x.peer, (dev ? x.dsrc : x.hsrc) + x.done, n, dev)) return -(int)ncclUnhandledCudaError;
@@ -154,7 +164,7 @@ int progress(Comm *c, Xfer &x) {
     }
     if (x.done == x.bytes) return 0;
     size_t n = std::min({avail, x.bytes - x.done, PIECE_MAX});
-    if (c->jitter && n > 64) n = 1 + (size_t)(c->next() % n);
+    if (c->jitter && n > 64) n = jitter_piece(c, n);
     if (!n) return 0;
     const size_t keep = x.done >= x.deliver ? 0 : std::min(n, x.deliver - x.done);
     const bool dev = x.ddst != nullptr;
