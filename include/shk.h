@@ -219,6 +219,11 @@ void shk_host_free(void *p);
  * has handled in this process so far; *reader_seconds (optional): the time the reader itself took (without the copy into
  * *out).  SHK_GUNZIP_THREADS (environment): its thread count, 0 or 1 = zlib only. */
 int shk_host_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, uint64_t *mt_members, double *reader_seconds);
+/* the DEVICE inflater alone (csrc/inflate_gpu.hip; needs a GPU): shk_preprocess hands a plain gzip member of >= 4 MiB
+ * (SHK_GUNZIP_DEVICE_MIN) to it first — the compressed bytes are what crosses PCIe — and reads on the host whatever it does
+ * not take.  0: *out (malloc'd, shk_host_free) holds the member's bytes, equal to zlib's; 1: not taken, *why (optional) says
+ * why; < 0: error.  *ms_total (optional): upload + kernels + checks. */
+int shk_device_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, const char **why, double *ms_total);
 /* SPEC S9 (tips, bubbles) and S10 (chains of simple links, the circular cut) on UNITIG records instead of k-mers — what the
  * sharded assembly runs on every rank's host once the k-mer-level contraction is done on the GPUs (csrc/unitig_graph.h:
  * one record per strand of a unitig; first / last: [n_recs][W] words of its first / last k-mer as spelled; min_*: the

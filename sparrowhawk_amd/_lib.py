@@ -71,6 +71,7 @@ SIGNATURES = {
     "shk_host_assembly_json_arriving": (_vp, [_cp, _vp, _vp, _u64, _u32, _u64, _u32]),
     "shk_host_free": (None, [_vp]),
     "shk_host_gunzip": (_int, [_cp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_u64), C.POINTER(C.c_double)]),
+    "shk_device_gunzip": (_int, [_cp, _sz, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(C.c_char_p), C.POINTER(C.c_double)]),
     "shk_host_unitig_assemble": (_vp, [_u32, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int]),
     "shk_release_cached_memory": (None, []),
     "shk_measure_stream_read": (_int, [_sz, _int, C.POINTER(C.c_double)]),

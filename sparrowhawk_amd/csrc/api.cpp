@@ -17,6 +17,7 @@
 
 #include "fastq.h"
 #include "fastq_gpu.h"
+#include "inflate_gpu.h"
 #include "inflate_mt.h"
 #include "outputs.h"
 #include "pipeline.h"
@@ -434,6 +435,70 @@ static int preprocess_device_pieces(shk_handle *h, const uint8_t *t1, size_t l1,
     return finish_counting(h);
 }
 
+// Both files (or the one) are plain gzip members the device inflater takes: inflate -> device parser -> one batch.
+// handled = false (nothing counted, nothing posted beyond what the host path posts again) when any file is not taken or
+// turns out not to be regular 4-line FASTQ: the caller's host reader then starts over.
+static int preprocess_device_gzip(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2, size_t total, bool &handled) {
+    handled = false;
+    const uint8_t *gz[2] = {fq1, fq2}; const size_t gn[2] = {n1, fq2 ? n2 : 0};
+    const int nf = fq2 ? 2 : 1;
+    for (int f = 0; f < nf; f++) if (gn[f] < 18 || gz[f][0] != 0x1F || gz[f][1] != 0x8B) return SHK_OK;
+    std::string err;
+    const double t0 = now_ms();
+    GpuText text[2];
+    GpuPacked packed[2];
+    auto drop = [&]() { for (int f = 0; f < 2; f++) { gpu_text_free(text[f]); gpu_packed_free(packed[f]); } };
+    double ms_h2d = 0, ms_search = 0, ms_decode = 0, ms_resolve = 0;
+    for (int f = 0; f < nf; f++) {
+        GpuInflateStats st;
+        const int rc = gpu_inflate_member(gz[f], gn[f], h->pipe->device(), h->pipe->stream(), text[f], err, &st);
+        if (rc == 1) { drop(); h->pipe->times().add("gunzip_device_not_taken_x1", 1.0); return SHK_OK; }
+        if (rc) { drop(); return fail(h, rc == -4 ? SHK_E_OOM : SHK_E_DEVICE, err); }
+        ms_h2d += st.h2d_ms; ms_search += st.search_ms; ms_decode += st.decode_ms; ms_resolve += st.resolve_ms;
+    }
+    const double t1 = now_ms();
+    uint64_t text_total = 0;
+    for (int f = 0; f < nf; f++) text_total += text[f].e;
+    if (text_total / 2 > batch_bases()) { drop(); return SHK_OK; }             // (several batches: the host reader's piece-wise path)
+    uint64_t reads_done = 0, text_before = 0;
+    for (int f = 0; f < nf; f++) {
+        const int rc = gpu_pack_fastq(nullptr, 0, nullptr, 0, h->k, h->min_qual, h->progress_every(), h->pipe->stream(), packed[f], err, reads_done, &text[f]);
+        if (rc < 0) { drop(); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+        if (rc == 1) { drop(); h->pipe->times().add("gunzip_device_not_taken_x1", 1.0); return SHK_OK; }      // not regular FASTQ: the host parser owns the messages
+        // progress as the text path posts it: every `every` reads, with the share of the (inflated) text consumed so far
+        const uint64_t every = h->progress_every();
+        for (size_t j = 0; j < packed[f].progress_bytes.size(); j++) {
+            const uint64_t bytes = packed[f].progress_bytes[j] & ~(1ull << 63);
+            const uint64_t pct = text_total ? (100 * (text_before + bytes)) / text_total : 100;
+            h->post_mode(("loop:" + std::to_string(every * (packed[f].first_mark + j + 1)) + ":" + std::to_string(pct)).c_str());
+        }
+        reads_done += packed[f].n_reads;
+        text_before += text[f].e;
+        h->pipe->times().add("fastq_device_kernels", packed[f].kernels_ms);
+        gpu_text_free(text[f]);
+    }
+    (void)total;
+    h->pipe->times().add("gunzip_device_host_clock", t1 - t0);
+    h->pipe->times().add("gunzip_device_h2d", ms_h2d);
+    h->pipe->times().add("gunzip_device_search", ms_search);
+    h->pipe->times().add("gunzip_device_decode", ms_decode);
+    h->pipe->times().add("gunzip_device_windows_resolve_crc", ms_resolve);
+    h->pipe->times().add("gunzip_device_members_x1", (double)nf);
+    h->pipe->times().add("fastq_device_parse_pack_host_clock", now_ms() - t1);
+    h->n_reads = reads_done;
+    std::vector<DevPiece> pcs;
+    for (int f = 0; f < nf; f++) if (packed[f].n_seg) pcs.push_back(DevPiece{packed[f].d_bases, packed[f].d_seg_off, packed[f].n_seg, packed[f].n_bases});
+    const double tc = now_ms();
+    h->batches_started++;
+    const int rc = h->pipe->count_batch_pieces(pcs.data(), pcs.size(), err);
+    h->pipe->times().add("preprocess_device_total_host_clock", now_ms() - tc);
+    if (rc) { drop(); return fail(h, rc == -4 ? SHK_E_OOM : (rc == -1 ? SHK_E_PARAM : SHK_E_DEVICE), err); }
+    handled = true;
+    const int rf = finish_counting(h);
+    drop();
+    return rf;
+}
+
 static int preprocess_impl(shk_handle *h, const uint8_t *fq1, size_t n1, const uint8_t *fq2, size_t n2) {
     if (!h) return SHK_E_PARAM;
     if (h->st != St::Fresh) return fail(h, SHK_E_STATE, "preprocess: handle already used (Assembler.ts:92: one preprocess per handle)");
@@ -448,6 +513,18 @@ static int preprocess_impl(shk_handle *h, const uint8_t *fq1, size_t n1, const u
     // packed by streaming kernels.  Irregular input and every malformed record go to the host parser
     // below, which owns the error messages.
     // gzip (plain members: one thread per file; BGZF: block-parallel) is inflated once, for either parser
+    // ---- .fastq.gz (the reference's real input: fastx_wasm.rs:53-70): a plain gzip member of some size is inflated ON THE
+    // DEVICE — the compressed bytes are what crosses PCIe — and its text goes straight to the device parser; whatever the
+    // device inflater does not take (several members, BGZF, binary data, a damaged stream) is read on the host below
+    {
+        const char *gd = getenv("SHK_GUNZIP_DEVICE");
+        const char *fh = getenv("SHK_HOST_PARSER");
+        if (!(gd && *gd == '0') && !(fh && *fh == '1')) {
+            bool handled = false;
+            const int rc = preprocess_device_gzip(h, fq1, n1, fq2, n2, total, handled);
+            if (rc || handled) return rc;
+        }
+    }
     ByteVec st1, st2;
     const uint8_t *t1 = nullptr, *t2 = nullptr; size_t l1 = 0, l2 = 0;
     {
@@ -1264,6 +1341,30 @@ char *shk_host_assembly_json_arriving(const char *seqs, const uint64_t *offsets,
     } catch (...) { return nullptr; }
 }
 void shk_host_free(void *p) { free(p); }
+// the device inflater alone (csrc/inflate_gpu.hip): 0 = *out (malloc'd, shk_host_free) holds the member's bytes; 1 = the
+// member was not taken (*why says why: the product then reads it on the host); < 0 = error
+int shk_device_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, const char **why, double *ms_total) {
+    try {
+        if (!gz || !out || !out_n) return SHK_E_PARAM;
+        *out = nullptr; *out_n = 0;
+        static thread_local std::string msg;
+        std::string err;
+        GpuText text; GpuInflateStats st;
+        const int rc = gpu_inflate_member(gz, n, current_device(), nullptr, text, err, &st, true);
+        if (why) { msg = rc == 1 ? st.why_not : err; *why = msg.c_str(); }
+        if (ms_total) *ms_total = st.total_ms;
+        if (rc == 1) return 1;
+        if (rc) return rc == -4 ? SHK_E_OOM : SHK_E_DEVICE;
+        const size_t bytes = text.e;
+        uint8_t *o = (uint8_t *)malloc(bytes ? bytes : 1);
+        if (!o) { gpu_text_free(text); return SHK_E_OOM; }
+        const int rd = device_download(o, text.d, bytes, err);
+        gpu_text_free(text);
+        if (rd) { free(o); if (why) { msg = err; *why = msg.c_str(); } return SHK_E_DEVICE; }
+        *out = o; *out_n = bytes;
+        return SHK_OK;
+    } catch (...) { return SHK_E_OOM; }
+}
 int shk_host_gunzip(const uint8_t *gz, size_t n, uint8_t **out, size_t *out_n, uint64_t *mt_members, double *reader_seconds) {
     try {
         if (!gz || !out || !out_n) return SHK_E_PARAM;

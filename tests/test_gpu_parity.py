@@ -193,10 +193,12 @@ def test_paired_gzip_and_streaming_equal_single_file():
     compare_all(b, o)
 
 
-def test_large_single_member_gzip_goes_through_the_multithreaded_reader():
+def test_large_single_member_gzip_goes_through_the_multithreaded_reader(monkeypatch):
     """a single-member .fastq.gz of >= 64 MB of text (the reference's real input: fastx_wasm.rs:53-70,
     docs/src/assembly.md:28) is inflated by csrc/inflate_mt.cpp; the assembly equals the one from the plain text and, as
-    file 2 of a pair next to a plain file 1, the pooled result equals the oracle's."""
+    file 2 of a pair next to a plain file 1, the pooled result equals the oracle's.  (SHK_GUNZIP_DEVICE=0: the HOST reader —
+    since round 4 a member like this goes to the device inflater first: the tests below.)"""
+    monkeypatch.setenv("SHK_GUNZIP_DEVICE", "0")
     g = synth.random_genome(300000, 5)
     codes, quals = synth.sample_reads(g, 230000, 150, 6, err=0.01)
     fq = bytes(synth.to_fastq_fixed(codes, quals))
@@ -211,6 +213,97 @@ def test_large_single_member_gzip_goes_through_the_multithreaded_reader():
     assert c.timings().get("gunzip_mt_members_x1", 0) == 1
     o = run_oracle([small, fq], k=31, min_count=3)
     compare_all(c, o, check_graph=False)
+
+
+def _device_gunzip(lib, z):
+    import ctypes as C
+    out, n, why = C.c_void_p(), C.c_size_t(), C.c_char_p()
+    rc = lib.shk_device_gunzip(z, len(z), C.byref(out), C.byref(n), C.byref(why), None)
+    if rc == 0:
+        got = C.string_at(out.value, n.value)
+        lib.shk_host_free(out)
+        return 0, got, ""
+    return rc, None, (why.value or b"").decode()
+
+
+def test_device_inflater_gives_zlibs_bytes_or_declines(lib, monkeypatch):
+    """csrc/inflate_gpu.hip alone (shk_device_gunzip): members of FASTQ text at several levels, windows and chunk sizes come
+    back byte for byte as zlib gives them; several members, BGZF, binary data, truncated and bit-flipped streams are DECLINED
+    (the product then reads them on the host) or — harmless damage — still equal zlib's bytes.  Never other bytes."""
+    import zlib
+    monkeypatch.setenv("SHK_GUNZIP_DEVICE_MIN", "32768")
+    rng = np.random.default_rng(77)
+    g = synth.random_genome(100000, 9)
+    taken = 0
+    for level, wbits, n_reads, rl, chunk in ((1, 31, 60000, 150, 0), (6, 31, 60000, 150, 16384), (9, 31, 20000, 251, 4096), (6, 28, 30000, 100, 0),
+                                             (1, 31, 5000, 75, 0), (4, 31, 120000, 150, 65536)):
+        codes, quals = synth.sample_reads(g, n_reads, rl, int(rng.integers(1 << 30)), err=0.01)
+        fq = bytes(synth.to_fastq_fixed(codes, quals))
+        co = zlib.compressobj(level, zlib.DEFLATED, wbits)
+        z = co.compress(fq) + co.flush()
+        if chunk:
+            monkeypatch.setenv("SHK_GUNZIP_DEVICE_CHUNK", str(chunk))
+        else:
+            monkeypatch.delenv("SHK_GUNZIP_DEVICE_CHUNK", raising=False)
+        rc, got, why = _device_gunzip(lib, z)
+        assert rc in (0, 1), (rc, why)
+        if rc == 0:
+            assert got == fq, (level, wbits, len(got), len(fq))
+            taken += 1
+        # two members behind one another: not this reader's case
+        rc2, got2, why2 = _device_gunzip(lib, z + z)
+        assert rc2 == 1, why2
+        # damaged: declined, or zlib's bytes
+        for _ in range(4):
+            pos = int(rng.integers(12, len(z)))
+            bad = bytearray(z); bad[pos] ^= 1 << int(rng.integers(0, 8)); bad = bytes(bad)
+            try:
+                ref = zlib.decompress(bad, 31)
+            except zlib.error:
+                ref = None
+            rc3, got3, _ = _device_gunzip(lib, bad)
+            assert rc3 == 1 or (rc3 == 0 and ref is not None and got3 == ref), (pos, rc3)
+        rc4, _, _ = _device_gunzip(lib, z[:len(z) // 2])
+        assert rc4 == 1
+    assert taken >= 4, taken
+    # binary data, a tiny member: declined
+    assert _device_gunzip(lib, gzip.compress(rng.integers(0, 256, 3_000_000, dtype=np.uint8).tobytes()))[0] == 1
+    assert _device_gunzip(lib, gzip.compress(b"@r\nACGT\n+\nIIII\n"))[0] == 1
+
+
+def test_fastq_gz_is_inflated_on_the_device(monkeypatch):
+    """The reference's real input (a .fastq.gz, or a pair of them: fastx_wasm.rs:53-70, docs/src/assembly.md:25-28) through
+    shk_preprocess: a plain gzip member is inflated on the device (csrc/inflate_gpu.hip — the compressed bytes are what
+    crosses PCIe) and its text goes straight to the device parser; results equal those of the plain text and the oracle's,
+    one file and two, with masked bases and with the host reader taking over what the device inflater declines."""
+    monkeypatch.setenv("SHK_GUNZIP_DEVICE_MIN", "65536")
+    g = synth.random_genome(200000, 15)
+    codes, quals = synth.sample_reads(g, 60000, 150, 16, err=0.01)
+    fq = bytes(synth.to_fastq_fixed(codes, quals))
+    z = gzip.compress(fq, compresslevel=6)
+    a = product(fq, k=31, min_count=3)
+    b = product(z, k=31, min_count=3)
+    assert b.timings().get("gunzip_device_members_x1", 0) == 1, b.timings()
+    assert a.get_assembly() == b.get_assembly() and a.get_preprocessing_info() == b.get_preprocessing_info()
+    o = run_oracle([fq], k=31, min_count=3)
+    compare_all(b, o, check_graph=False)
+    # a pair of .fastq.gz: both on the device, pooled
+    recs = fq.decode().split("@r")[1:]
+    half = len(recs) // 2
+    f1 = ("@r" + "@r".join(recs[:half])).encode(); f2 = ("@r" + "@r".join(recs[half:])).encode()
+    c = product(gzip.compress(f1, compresslevel=1), gzip.compress(f2, compresslevel=9), k=31, min_count=3)
+    assert c.timings().get("gunzip_device_members_x1", 0) == 2
+    assert c.get_assembly() == a.get_assembly() and c.get_preprocessing_info() == a.get_preprocessing_info()
+    # file 2 is two members: the device inflater declines, the host reader takes the pair
+    two = gzip.compress(f2[:f2.rfind(b"@r", 0, len(f2) // 2)]) + gzip.compress(f2[f2.rfind(b"@r", 0, len(f2) // 2):])
+    e = product(gzip.compress(f1), two, k=31, min_count=3)
+    assert e.timings().get("gunzip_device_members_x1", 0) == 0 and e.timings().get("gunzip_device_not_taken_x1", 0) == 1
+    assert e.get_assembly() == a.get_assembly() and e.get_preprocessing_info() == a.get_preprocessing_info()
+    # a damaged stream: the error is the host reader's
+    bad = bytearray(z); bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(ShkError) as ei:
+        product(bytes(bad), k=31, min_count=3)
+    assert ei.value.code == -3
 
 
 def test_metamorphic_read_order_and_strand():

@@ -15,8 +15,8 @@ import numpy as np
 from sparrowhawk_amd import _lib, synth
 
 L = _lib.load()
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 0)
 
 
 def gunzip(z):
@@ -87,49 +87,50 @@ def compress(text):
     return b"".join(out), dict(level=level, strategy=strategy, wbits=wbits, memlevel=memlevel, flushes=n_flush)
 
 
-t0 = time.time()
-n_mt = 0
-for case in range(n_cases):
-    n_members = int(rng.choice([1, 1, 1, 2, 3]))
-    size = int(rng.choice([1, 100, 70000, 3_000_000, 8_000_000, 20_000_000]))
-    members, texts, descs = [], [], []
-    for _ in range(n_members):
-        t = make_text(size) if size > 1 else (b"" if rng.random() < 0.5 else b"A")
-        z, d = compress(t)
-        members.append(z); texts.append(t); descs.append(d)
-    z, want = b"".join(members), b"".join(texts)
-    os.environ["SHK_GUNZIP_THREADS"] = str(int(rng.choice([1, 2, 3, 8])))
-    desc = dict(case=case, members=n_members, size=size, zlen=len(z), threads=os.environ["SHK_GUNZIP_THREADS"], how=descs)
-    try:
-        assert zlib_gunzip(z) == want
-        rc, got, mt_a = gunzip(z)
-        assert rc == 0 and got == want, ("intact stream", rc, None if got is None else len(got), len(want))
-        # truncated: an error (never a crash, never silently short)
-        for cut in (int(rng.integers(1, len(z))), len(z) - 1, len(z) - 8, 10, 3):
-            if 0 < cut < len(z):
-                rc, got, _ = gunzip(z[:cut])
-                if n_members > 1 and rc == 0:                # (a cut exactly between two members is a valid, shorter stream)
-                    assert got == zlib_gunzip(z[:cut])
+if __name__ == "__main__":
+    t0 = time.time()
+    n_mt = 0
+    for case in range(n_cases):
+        n_members = int(rng.choice([1, 1, 1, 2, 3]))
+        size = int(rng.choice([1, 100, 70000, 3_000_000, 8_000_000, 20_000_000]))
+        members, texts, descs = [], [], []
+        for _ in range(n_members):
+            t = make_text(size) if size > 1 else (b"" if rng.random() < 0.5 else b"A")
+            z, d = compress(t)
+            members.append(z); texts.append(t); descs.append(d)
+        z, want = b"".join(members), b"".join(texts)
+        os.environ["SHK_GUNZIP_THREADS"] = str(int(rng.choice([1, 2, 3, 8])))
+        desc = dict(case=case, members=n_members, size=size, zlen=len(z), threads=os.environ["SHK_GUNZIP_THREADS"], how=descs)
+        try:
+            assert zlib_gunzip(z) == want
+            rc, got, mt_a = gunzip(z)
+            assert rc == 0 and got == want, ("intact stream", rc, None if got is None else len(got), len(want))
+            # truncated: an error (never a crash, never silently short)
+            for cut in (int(rng.integers(1, len(z))), len(z) - 1, len(z) - 8, 10, 3):
+                if 0 < cut < len(z):
+                    rc, got, _ = gunzip(z[:cut])
+                    if n_members > 1 and rc == 0:                # (a cut exactly between two members is a valid, shorter stream)
+                        assert got == zlib_gunzip(z[:cut])
+                    else:
+                        assert rc != 0, ("truncated at", cut, "accepted")
+            # one byte changed: an error, or — when the change is harmless (header fields zlib ignores too) — zlib's bytes
+            for _ in range(3):
+                pos = int(rng.integers(2, len(z)))              # (not the two magic bytes: without them the input is taken as plain text, by contract)
+                bad = bytearray(z); bad[pos] ^= 1 << int(rng.integers(0, 8)); bad = bytes(bad)
+                try:
+                    ref = zlib_gunzip(bad)
+                except zlib.error:
+                    ref = None
+                rc, got, _ = gunzip(bad)
+                if ref is None:
+                    assert rc != 0, ("corrupt byte at", pos, "accepted")
                 else:
-                    assert rc != 0, ("truncated at", cut, "accepted")
-        # one byte changed: an error, or — when the change is harmless (header fields zlib ignores too) — zlib's bytes
-        for _ in range(3):
-            pos = int(rng.integers(2, len(z)))              # (not the two magic bytes: without them the input is taken as plain text, by contract)
-            bad = bytearray(z); bad[pos] ^= 1 << int(rng.integers(0, 8)); bad = bytes(bad)
-            try:
-                ref = zlib_gunzip(bad)
-            except zlib.error:
-                ref = None
-            rc, got, _ = gunzip(bad)
-            if ref is None:
-                assert rc != 0, ("corrupt byte at", pos, "accepted")
-            else:
-                assert rc == 0 and got == ref, ("corrupt byte at", pos, "harmless for zlib", rc)
-        rc, got, mt_b = gunzip(z)
-        n_mt += mt_b - mt_a
-    except Exception as e:
-        print("FAIL", desc, repr(e), flush=True)
-        raise
-    if case % 10 == 0:
-        print("case", case, "ok  %.0f s" % (time.time() - t0), desc, flush=True)
-print("all", n_cases, "cases: zlib's bytes or an error as zlib gives; the multi-threaded inflater took", n_mt, "members; %.0f s" % (time.time() - t0))
+                    assert rc == 0 and got == ref, ("corrupt byte at", pos, "harmless for zlib", rc)
+            rc, got, mt_b = gunzip(z)
+            n_mt += mt_b - mt_a
+        except Exception as e:
+            print("FAIL", desc, repr(e), flush=True)
+            raise
+        if case % 10 == 0:
+            print("case", case, "ok  %.0f s" % (time.time() - t0), desc, flush=True)
+    print("all", n_cases, "cases: zlib's bytes or an error as zlib gives; the multi-threaded inflater took", n_mt, "members; %.0f s" % (time.time() - t0))
