@@ -221,9 +221,11 @@ def run_legs(torch, dev, args, raw_get_assembly):
     fq = fq_plain
     legs["fastq_gz"] = {
         "workload": base + f"k={args.k}, error-free, as a single-member .fastq.gz of {len(gz) / 1e9:.2f} GB ({len(fq) / 1e9:.2f} GB of text) in host "
-                    "memory -> shk_preprocess (multi-threaded inflate: csrc/inflate_mt.cpp, then as fastq_text) -> contigs; PCIe-inclusive",
+                    "memory -> shk_preprocess (the compressed bytes cross PCIe, inflated on the device: csrc/inflate_gpu.hip, then the device parser) -> contigs; PCIe-inclusive",
         "value": input_bases / dtz / 1e9, "unit": "Gbases/s", "clock": "host text (PCIe-inclusive)", "ms_per_step": dtz * 1e3, "steps": args.leg_steps, "ncontigs": state["ncontigs"],
-        "gunzip_GB_per_s_of_text": len(fq) / 1e9 / (sum(t.get("gunzip_host_clock", 0.0) for t in tsz) / len(tsz) * 1e-3),
+        # (since round 4 the member is inflated on the device: csrc/inflate_gpu.hip; "host" only when it declined)
+        "gunzip_where": "device" if all(t.get("gunzip_device_members_x1", 0) for t in tsz) else "host",
+        "gunzip_GB_per_s_of_text": len(fq) / 1e9 / max(1e-9, (sum(t.get("gunzip_device_host_clock", 0.0) or t.get("gunzip_host_clock", 0.0) for t in tsz) / len(tsz) * 1e-3)),
         "stage_ms": {kk: sum(t.get(kk, 0.0) for t in tsz) / len(tsz) for kk in sorted(tsz[-1]) if not kk.endswith("_x1")},
     }
     legs["fastq_text"] = {

@@ -8,6 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("SHK_KEEP_STAGES", "1")               # quiet handles keep the initial adjacency too (compare_all reads it)
 import numpy as np
 import torch  # noqa: F401
 from sparrowhawk_amd import AssemblyHelper, synth
@@ -80,6 +81,9 @@ for case in range(n_cases):
     if rng.random() < 0.3: env["SHK_COUNT_SPLIT"] = "0"            # pass 2 fused (default: dedupe + weighted count as two kernels)
     if rng.random() < 0.3: env["SHK_COUNT_MERGE"] = str(int(rng.choice([1, 4])))   # partitions per table of k_count_weighted
     if rng.random() < 0.5: env["SHK_TILE_ROWS"] = str(int(rng.choice([1, 3, 17, 64, 300, 1000, 4096])))   # collapse: many small LDS tiles
+    if rng.random() < 0.25: env["SHK_SEG_CAP"] = str(int(rng.choice([1, 8, 64])))   # round 4: the splitter list outgrows its room -> the ranking is called off and repeated
+    if rng.random() < 0.25: env["SHK_ARRIVAL_MIN"] = "1"           # round 4: the writer starts on contig text that is still arriving (slab-copy kernel + host flags)
+    if rng.random() < 0.3: env["SHK_GUNZIP_DEVICE_MIN"] = "2048"   # round 4: gzip members go to the device inflater first (it declines most of these tiny ones)
     old = {e: os.environ.get(e) for e in env}
     os.environ.update(env)
     desc = dict(case=case, k=k, glen=glen, rl=rl, cov=cov, err=err, circ=circular, mc=min_count, mq=min_qual, fit=do_fit,
@@ -105,6 +109,15 @@ for case in range(n_cases):
             from sparrowhawk_amd import pack_fastq
             bases, seg, nbases, nreads = pack_fastq(files[0], k, min_qual)
             h.preprocess_packed_host(bases.ctypes.data, seg.ctypes.data, len(seg) - 1, nbases, nreads)
+        elif len(files) == 1 and rng.random() < 0.2:         # packed reads already in HBM (bench.py's entry point), on a QUIET handle half of the time
+            from sparrowhawk_amd import pack_fastq
+            bases, seg, nbases, nreads = pack_fastq(files[0], k, min_qual)
+            dev = torch.device("cuda", 0)
+            d_bases = torch.from_numpy(bases.view(np.int32)).to(dev); d_seg = torch.from_numpy(seg.view(np.int32)).to(dev)
+            torch.cuda.synchronize()
+            if rng.random() < 0.5:
+                h.free(); h = AssemblyHelper.new(k, False, min_count, min_qual, csize, do_bloom, do_fit, nb, nd)
+            h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nbases, nreads)
         else:
             h.preprocess(sent[0], sent[1] if len(sent) > 1 else None)
         h.assemble()
