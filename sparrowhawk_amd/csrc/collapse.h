@@ -647,11 +647,43 @@ __global__ __launch_bounds__(256) void k_ring_rot(Graph<W> g, HeadRec *__restric
 // one key load and one 16-byte read of ol for the two; the base an oriented node appends is the last base of its
 // k-mer (orientation 1: the complement of the first), so a reverse complement is only built for the first node of a
 // chain (which spells its whole k-mer).
+// The emission plan of an assembly with few chains, on the device (a fragmented one is planned by writer_gpu.h, any other by
+// the host): which chain records are emitted and where their text starts — so that k_emit and the download of the text can be
+// launched BEHIND the ranking, before the host has seen a single chain record.  plan[0] = 1: done, plan[1] = bytes of text,
+// plan[2] = chains emitted; plan[0] = 2: not planned (more chains than max_heads, more text than out_cap, or none ranked:
+// the host does it).  One workgroup.  Offsets in chain-record order, as the host's loop assigns them.
+__global__ __launch_bounds__(1024) void k_plan_emit(const HeadRec *__restrict__ heads, const unsigned int *__restrict__ n_heads_p, uint32_t k,
+                                                   uint32_t max_heads, unsigned long long out_cap, const uint32_t *__restrict__ flags,
+                                                   EmitRec *__restrict__ off, unsigned long long *__restrict__ plan) {
+    __shared__ unsigned long long wsum[16];
+    __shared__ uint32_t wcnt[16];
+    const uint32_t nh = *n_heads_p;
+    if (nh == 0 || nh > max_heads || flags[0] != 0u) { if (threadIdx.x == 0) plan[0] = 2ull; return; }
+    const uint32_t t = threadIdx.x, lane = t & 63u, wid = t >> 6;
+    // (max_heads <= 1024: one chain record per thread)
+    unsigned long long sz = 0; uint32_t em = 0; HeadRec h{};
+    if (t < nh) { h = heads[t]; if (h.emit) { sz = h.len + (unsigned long long)(k - 1u); em = 1u; } }
+    unsigned long long incl = sz; uint32_t cincl = em;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long u = __shfl_up(incl, o); const uint32_t cu = (uint32_t)__shfl_up((int)cincl, o);
+        if ((int)lane >= o) { incl += u; cincl += cu; }
+    }
+    if (lane == 63u) { wsum[wid] = incl; wcnt[wid] = cincl; }
+    __syncthreads();
+    unsigned long long base = 0, total = 0; uint32_t ctotal = 0;
+    for (uint32_t w = 0; w < 16u; w++) { if (w < wid) base += wsum[w]; total += wsum[w]; ctotal += wcnt[w]; }
+    if (total > out_cap) { if (t == 0) plan[0] = 2ull; return; }
+    if (t < nh) { EmitRec e; e.off = em ? base + incl - sz : ~0ull; e.rot = h.rot; e.len = (uint32_t)h.len; off[t] = e; }
+    if (t == 0) { plan[1] = total; plan[2] = ctotal; __threadfence(); plan[0] = 1ull; }
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_emit(Graph<W> g, const uint8_t *__restrict__ alive,
                                               const uint2 *__restrict__ ol,
                                               const EmitRec *__restrict__ head_off,
-                                              char *__restrict__ out) {
+                                              char *__restrict__ out,
+                                              const unsigned long long *__restrict__ plan = nullptr /* k_plan_emit's verdict: [0] == 1 or nothing is written */) {
+    if (plan && plan[0] != 1ull) return;
     const uint32_t ACGT = 0x54474341u;                     // 'A','C','G','T' little-endian
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) {
         if (!alive[i]) continue;

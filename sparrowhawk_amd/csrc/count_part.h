@@ -1075,11 +1075,17 @@ __global__ __launch_bounds__(COUNT_THREADS) void k_count_partitions(
 // that finds the table saturated is passed through with weight 1.  Persistent workgroups over the partitions
 // [p_first, n_parts), handed out by a work counter.
 // ovf != nullptr (single GPU): reads with errors do not deduplicate and their partitions do not fit the k-mer table of
-// the counting kernel.  The partitions below p_first were counted by k_count_partitions in the same stream — the sample
-// (ovf_n[1]: tried | overflowed << 16).  If most of them overflowed, every partition here is only read for its k-mer
-// count and reported in ovf[] as "not tried" (n_out[p] = 0): the k-mer-level repartition counts it from its raw records.
-// So is a partition that ends with more distinct records than the k-mer table has room for keys (kmer_cap), or that
-// lost less than half of its records as duplicates.
+// the counting kernel.  The partitions tried here are the sample: each reports "tried" and, if it ended with more distinct
+// records than the k-mer table has room for keys (kmer_cap) or lost less than half of its records as duplicates, "handed
+// over" (ovf_n[1]: tried | handed over << 16; n_out[p] = 0 and an entry in ovf[]: the k-mer-level repartition counts it
+// from its raw records).  The report returns the tally: once >= defer_after were handed over and they are at least HALF of
+// those tried, the workgroup only reads its further partitions for their k-mer counts and reports them "not tried".
+// (HALF, not the 3/4 k_count_partitions asks of its sample of whole counts: the records' repeats are the weaker sign — with
+// 1 % errors left in 63 % of the partitions show it, and every one of them overflows the k-mer table.)
+// Which partitions are tried depends on timing; the counts never do.
+// (rounds 2–3: a sample of 256 partitions went through k_count_partitions in front of this kernel, 74 us of a 0.74 ms pass 2
+// on clean reads.  Measured on the GPU box, alternating runs of bench.py: pass 2 0.75 -> 0.68 ms, configs[2] with its errors
+// left in 10.7 -> 10.5 ms.)
 template <int W> struct DedupeShared {
     RecTable<W, (W == 1 ? 3072u : ((69632u / (16u * W + 6u)) & ~63u))> rt;   // 3072 / 1792 / 1280 / 960 records: two workgroups share a CU's LDS
 };
@@ -1090,7 +1096,8 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
                                                                      uint64_t *__restrict__ out_recs, uint32_t *__restrict__ out_w,
                                                                      uint32_t *__restrict__ n_out, uint32_t *__restrict__ work_counter,
                                                                      OvfRec *__restrict__ ovf /* nullable */, uint32_t *__restrict__ ovf_n,
-                                                                     uint32_t defer_after, uint32_t kmer_cap) {
+                                                                     uint32_t defer_after, uint32_t kmer_cap,
+                                                                     uint32_t *__restrict__ verdict_out /* nullable: k_count_weighted's tally word — the verdict is passed on */) {
     constexpr int RW = 2 * W;
     __shared__ DedupeShared<W> tb;
     __shared__ CountCtl ctl;
@@ -1100,24 +1107,16 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
     const int k = rvw.k;
     const uint32_t S_runs = rvw.S;
     const uint32_t n_here = n_parts - p_first;
-    // (the sample's verdict is final before this kernel starts: same stream)
     __shared__ uint32_t forced_sh;
-    if (threadIdx.x == 0) {
-        uint32_t force = 0;
-        if (ovf && defer_after) {
-            const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
-            force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
-        }
-        forced_sh = force;
-    }
+    if (threadIdx.x == 0) forced_sh = 0;
     __syncthreads();
-    const bool forced = forced_sh != 0;
+    bool forced = false;
     uint32_t pi_next = 0;
     for (uint32_t pi = blockIdx.x; pi < n_here; pi = pi_next) {
         const uint32_t p = p_first + pi;
         uint32_t f = 0; unsigned long long addr = 0;
         if (threadIdx.x < S_runs) { f = rvw.run_cnt[(uint64_t)p * S_runs + threadIdx.x]; addr = rvw.run_addr16[(uint64_t)p * S_runs + threadIdx.x]; }
+        forced = forced_sh != 0;                         // (written behind a barrier of the previous partition, see below)
         if (forced) {
             // error-rich reads: no dedupe — a thread per run adds up the k-mer counts of its records, the partition is handed over
             unsigned long long inst = 0;
@@ -1242,7 +1241,21 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_dedupe_partit
         __syncthreads();
         // (fewer than half of the records were duplicates: the partition count gives a partition ~20 table sizes of k-mer
         // instances, so reads that repeat that little bring far more distinct k-mers than the table holds)
-        if (ovf && (ctl.n_recs > kmer_cap || (R > kmer_cap / 4u && 2u * ctl.n_recs > R))) { hand_over(); continue; }   // (uniform)
+        const bool hand = ovf && (ctl.n_recs > kmer_cap || (R > kmer_cap / 4u && 2u * ctl.n_recs > R));     // (uniform)
+        if (ovf && threadIdx.x == 0 && R) {
+            // (the tally comes back with this partition's report: the verdict for this workgroup's next partition — read at the
+            // top of the loop, behind the barrier in hand_over() or the one in front of n_out[p] below)
+            const uint32_t add = hand ? 0x10001u : 1u;
+            const uint32_t x = atomicAdd(&ovf_n[1], add) + add;
+            const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
+            if (defer_after && n_over >= defer_after && 2u * n_over >= n_tried) {
+                forced_sh = 1u;
+                // (k_count_weighted starts handing over at once: the partitions that did pass the dedupe before the verdict
+                // would fail there one by one, each after filling the table — 1.1 ms of 11 on configs[2] with its errors left in)
+                if (verdict_out) atomicOr(verdict_out, 0x80000000u);
+            }
+        }
+        if (hand) { hand_over(); continue; }
         for (uint32_t s = threadIdx.x; s < (SHK_DBG(rvw.dbg) == 23 ? 0u : SR); s += COUNT_THREADS) {     // (23: timing experiment, nothing written)
             const uint32_t st = rt.rst[s];
             if (st < 3u) continue;
@@ -1273,7 +1286,9 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighte
     unsigned long long *__restrict__ histo, KeyArr<W> out_keys, uint32_t *__restrict__ out_cnt,
     unsigned long long out_cap, unsigned long long *__restrict__ out_cursor,
     unsigned long long *__restrict__ n_inst, OvfRec *__restrict__ ovf, uint32_t *__restrict__ ovf_n,
-    uint32_t *__restrict__ work_counter, uint32_t probe_groups, uint32_t defer_after, uint32_t dbg_arg /* timing experiments (ABLATE builds) */) {
+    unsigned long long *__restrict__ work_and_tally /* low word: groups handed out, zero at launch; high word: this kernel's tally, tried |
+                                                       overflowed << 16, which k_dedupe_partitions starts at its verdict — ONE atomic fetches both */,
+    uint32_t probe_groups, uint32_t defer_after, uint32_t dbg_arg /* timing experiments (ABLATE builds) */) {
     constexpr int RW = 2 * W;
     constexpr uint32_t S = KmerTable<W>::S;
     const uint32_t dbg = SHK_DBG(dbg_arg);
@@ -1372,6 +1387,8 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighte
         else table_emit<W>(tb, ctl, mine, threshold, histo, out_keys, out_cnt, out_cap, out_cursor, tb.state, 0u, whist);
     };
     // hand partition p to the k-mer-level repartition: exact instances, estimated distinct k-mers (of the attempt just made)
+    uint32_t *const tally = reinterpret_cast<uint32_t *>(work_and_tally) + 1;
+    bool in_sample = true;                               // (this workgroup's first group: see the loop below)
     auto defer = [&](uint32_t p, bool was_tried) {
         const uint32_t R = n_recs[p];
         const uint64_t *src = recs + base[p] * RW;
@@ -1394,10 +1411,13 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighte
             OvfRec o; o.p = p; o.est_distinct = !was_tried ? 0u /* not tried */ : est > 4.0e9 ? 0xFFFFFFFFu : est < 1.0 ? 1u : (uint32_t)est; o.instances = ctl.part_inst;
             ovf[slot] = o;
         }
-        if (threadIdx.x == 0 && was_tried && defer_after) atomicAdd(&ovf_n[1], 0x10001u);         // tried, and it overflowed
+        if (threadIdx.x == 0 && was_tried && defer_after && in_sample) atomicAdd(tally, 0x10001u);         // tried, and it overflowed
     };
+    // (the tally is kept by every workgroup's FIRST group only — they run side by side, a sample of 2 x CUs groups: an atomic per
+    // group on one word, 8192 of them, cost 35 us of the 0.35 ms this kernel takes on clean reads: thread 0 waits for it to
+    // retire before it sees its next group's number)
     uint32_t g_next = 0;
-    for (uint32_t g = blockIdx.x; g < n_groups; g = g_next) {
+    for (uint32_t g = blockIdx.x; g < n_groups; in_sample = false, g = g_next) {
         uint32_t pm[4] = {0, 0, 0, 0}, nm = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
@@ -1409,14 +1429,10 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighte
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            next_g_sh = gridDim.x + atomicAdd(work_counter, 1u);
-            uint32_t force = 0;
-            if (defer_after && g >= probe_groups) {      // (probe_groups = 0 when k_count_partitions counted a sample of partitions first)
-                const uint32_t x = __hip_atomic_load(&ovf_n[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t n_over = x >> 16, n_tried = x & 0xFFFFu;
-                force = (n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
-            }
-            force_sh = force;
+            const unsigned long long wt = atomicAdd(work_and_tally, 1ull);       // (the next group's number and the tally in one round trip)
+            const uint32_t x = (uint32_t)(wt >> 32), n_over = x >> 16, n_tried = x & 0xFFFFu;
+            next_g_sh = gridDim.x + (uint32_t)wt;
+            force_sh = (defer_after && g >= probe_groups && n_over >= defer_after && 4u * n_over >= 3u * n_tried) ? 1u : 0u;
         }
         __syncthreads();
         g_next = next_g_sh;
@@ -1428,14 +1444,14 @@ __global__ __launch_bounds__(COUNT_THREADS, W <= 2 ? 8 : 4) void k_count_weighte
         }
         if (nm > 1 && count_range(pm, nm)) {
             emit();
-            if (threadIdx.x == 0 && defer_after) atomicAdd(&ovf_n[1], nm);                        // tried, and they fitted
+            if (threadIdx.x == 0 && defer_after && in_sample) atomicAdd(tally, nm);                        // tried, and they fitted
             continue;
         }
 #pragma unroll
         for (uint32_t j = 0; j < 4; j++) {
             if (j >= nm) continue;
             const uint32_t one[4] = {pm[j], 0, 0, 0};
-            if (count_range(one, 1u)) { emit(); if (threadIdx.x == 0 && defer_after) atomicAdd(&ovf_n[1], 1u); }
+            if (count_range(one, 1u)) { emit(); if (threadIdx.x == 0 && defer_after && in_sample) atomicAdd(tally, 1u); }
             else defer(pm[j], true);
         }
     }

@@ -411,6 +411,17 @@ __global__ __launch_bounds__(1024) void k_ends_to_host(const char *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag_host, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// the same copy when the host does not know the size yet (k_plan_emit's plan): plan[0] == 1 or nothing is copied, plan[1] = bytes
+__global__ __launch_bounds__(256) void k_text_to_host_planned(const char *__restrict__ src, char *__restrict__ dst_host,
+                                                              const unsigned long long *__restrict__ plan) {
+    if (plan[0] != 1ull) return;
+    const unsigned long long bytes = plan[1];
+    const unsigned long long nv = bytes >> 4;
+    const uint4 *a = reinterpret_cast<const uint4 *>(src);
+    uint4 *d = reinterpret_cast<uint4 *>(dst_host);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256u + threadIdx.x; i < nv; i += (unsigned long long)gridDim.x * 256u) d[i] = a[i];
+    if (blockIdx.x == 0 && threadIdx.x < (bytes & 15ull)) dst_host[(nv << 4) + threadIdx.x] = src[(nv << 4) + threadIdx.x];
+}
 class SlabArrival : public TextArrival {
 public:
     void set(char *dst, size_t bytes, volatile uint32_t *flags, uint32_t n_slabs, hipStream_t st) { base_ = dst; total_ = bytes; flags_ = flags; n_slabs_ = n_slabs; st_ = st; failed_.store(false); }
@@ -855,8 +866,6 @@ public:
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
-            // (two-kernel path: the sample is ONE round of the fused kernel — a partition per CU)
-            const uint32_t n_sample = split && n_probe ? std::min<uint32_t>(n_probe / 2, (uint32_t)n_cus_) : 0u;
             EvTimer t(stream_);
             if (split) {
                 // (every attempt: the partitions the dedupe hands over are reported in d_ovf / ctl_, which an attempt starts empty)
@@ -865,20 +874,13 @@ public:
                 if (int rc = dd_recs_.alloc(split_total_ * 2 * W + 2, err)) return rc;
                 if (int rc = dd_w_.alloc(split_total_ + 2, err)) return rc;
                 HIPCHK(hipMemcpyAsync(dd_base_.p, split_base_.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_));
-                // The first n_probe partitions are counted by the fused kernel: they are the sample.  Its tallies (tried /
-                // overflowed) tell the two kernels behind it — same stream, no host round trip — whether the reads are
-                // error-rich; then the dedupe only reads its partitions for their k-mer counts and hands them over.
-                if (n_sample) {
-                    hipLaunchKernelGGL((k_count_partitions<W, false>), dim3(n_sample), dim3(COUNT_THREADS), 0, stream_, rv, n_sample, threshold,
-                                       dh.p, ok, cnt.p, (unsigned long long)cap, ctl_.p + 0, ctl_.p + 1,
-                                       (uint32_t *)(ctl_.p + 2), (const uint32_t *)nullptr, d_ovf.p,
-                                       (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 11), n_sample, n_probe / 8);
-                    HIPCHK(hipGetLastError());
-                }
+                // (no sample launch in front: the partitions the dedupe tries are the sample, and its verdict is where the counting
+                // kernel's own tally starts — count_part.h)
+                const uint32_t defer_after = n_probe / 8;
                 EvTimer t_a(stream_, stage_timers_);
-                hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(n_parts - n_sample, 2u * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
-                                   rv, n_sample, n_parts, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
-                                   d_ovf.p, (uint32_t *)(ctl_.p + 3), n_sample ? n_probe / 8 : 0u, (S / 10) * 9);
+                hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(n_parts, 2u * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
+                                   rv, 0u, n_parts, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
+                                   d_ovf.p, (uint32_t *)(ctl_.p + 3), defer_after, (S / 10) * 9, (uint32_t *)(ctl_.p + 14) + 1);
                 HIPCHK(hipGetLastError());
                 if (attempt == 0) t_a.stop_later("count_dedupe_kernel", pending_timers_);
                 const uint32_t per_cu = 2u;
@@ -889,8 +891,10 @@ public:
                 while (merge > 1 && (n_parts % merge != 0 || (n_parts / merge) % 256u != 0 || n_parts / merge < 2u * per_cu * (uint32_t)n_cus_)) merge >>= 1;
                 const uint32_t n_groups = (n_parts + merge - 1) / merge;
                 hipLaunchKernelGGL(k_count_weighted<W>, dim3(std::min<uint32_t>(n_groups, per_cu * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
-                                   dd_recs_.p, dd_w_.p, dd_base_.p, dd_n_.p, n_sample, n_parts, merge, rv.k, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
-                                   ctl_.p + 0, ctl_.p + 1, d_ovf.p, (uint32_t *)(ctl_.p + 3), (uint32_t *)(ctl_.p + 14), n_sample ? 0u : 0xFFFFFFFFu, n_sample ? n_probe / 8 : 0u,
+                                   dd_recs_.p, dd_w_.p, dd_base_.p, dd_n_.p, 0u, n_parts, merge, rv.k, threshold, dh.p, ok, cnt.p, (unsigned long long)cap,
+                                   // (ctl_[14]: the groups handed out and, in its high word, this kernel's tally — it starts at the dedupe's verdict
+                                   // and covers reads whose records repeat but whose k-mers do not fit)
+                                   ctl_.p + 0, ctl_.p + 1, d_ovf.p, (uint32_t *)(ctl_.p + 3), ctl_.p + 14, 0u, defer_after,
                                    env_dbg("SHK_DEBUG_P2"));
             } else {
                 // (persistent workgroups, one per CU: the tables take the whole LDS)
@@ -908,6 +912,8 @@ public:
             WAIT_STREAM();          // one host round trip: counters, histogram and the timer
             ms_out = t.elapsed();      // (sample + dedupe + count)
             const uint32_t n_ovf = (uint32_t)h[3];
+            if (env_u64("SHK_VERBOSE_TALLY", 0)) fprintf(stderr, "[shk] pass 2: %u partitions, %u handed over, tally tried %u / over %u, split %d\n", n_parts, n_ovf,
+                                                    (unsigned)((h[3] >> 32) & 0xFFFFu), (unsigned)(h[3] >> 48), (int)split);
             // rows written by the bucket path are ordered by key hash, not grouped by minimiser partition (build_graph regroups)
             rows_scattered_ = (uint64_t)n_ovf * 4u > n_parts;
             if (n_ovf) {
@@ -1269,7 +1275,7 @@ public:
         EvTimer t(stream_, stage_timers_);
         hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
                            run_view_, 0u, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
-                           (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u);
+                           (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
         t.mark();
         std::vector<uint32_t> h(pp_.P);
@@ -1638,10 +1644,15 @@ public:
     // nodes; if a graph needs more the kernels stop and the pass is repeated with room for all), the number of pointer-jumping
     // rounds comes from that room, and the launch may sit behind a first correction round whose outcome is not known yet —
     // then the kernels return at once when that round removed something, the correction is finished and the pass repeated.
-    int rank_chains(ChainState &cs, bool rings, std::string &err, uint32_t keep_on_device_from = 0xFFFFFFFFu) {
+    // (plan: an assembly with few chains has its emission planned on the device — k_plan_emit —, its text written and sent to
+    // the host behind the ranking, inside the same launch sequence: the host's ONE wait brings the counters, the chain records
+    // and the text.  planned = the device did it; otherwise the caller plans as before.)
+    struct EmitPlan { EmitRec *d_off; char *d_out; char *h_out; uint32_t max_heads; unsigned long long out_cap; bool planned; unsigned long long out_bytes; uint32_t n_emit; };
+    int rank_chains(ChainState &cs, bool rings, std::string &err, uint32_t keep_on_device_from = 0xFFFFFFFFu, EmitPlan *plan = nullptr) {
         const uint32_t n = (uint32_t)n_solid_;
         const uint32_t total = 2 * n;
         Graph<W> g = graph_view();
+        if (plan) plan->planned = false;
         const bool stage_log = getenv("SHK_STAGE_LOG") != nullptr;          // (see shard_assemble)
         auto stage = [&](const char *what) {
             if (!stage_log) return;
@@ -1718,6 +1729,13 @@ public:
                 hipLaunchKernelGGL(k_ring_rot<W>, dim3(gr), dim3(256), 0, stream_, g, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), cs.ringmin.p,
                                    cs.winfo.p, cs.ol.p, d_ncyc, d_flags);
             }
+            if (plan) {
+                HIPCHK(hipMemsetAsync(ctl_.p + 18, 0, 3 * 8, stream_));
+                hipLaunchKernelGGL(k_plan_emit, dim3(1), dim3(1024), 0, stream_, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), (uint32_t)k_, plan->max_heads,
+                                   plan->out_cap, (const uint32_t *)d_flags, plan->d_off, ctl_.p + 18);
+                hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, plan->d_off, plan->d_out, (const unsigned long long *)(ctl_.p + 18));
+                hipLaunchKernelGGL(k_text_to_host_planned, dim3(64), dim3(256), 0, stream_, plan->d_out, plan->h_out, (const unsigned long long *)(ctl_.p + 18));
+            }
             HIPCHK(hipGetLastError());
             // (the first chain records travel with the counters: an isolate has a handful of chains, and a second
             // round trip just for them is 30-40 us of idle GPU)
@@ -1742,6 +1760,7 @@ public:
                 continue;
             }
             memcpy(heads.data(), mbox64() + MB_MISC, (size_t)std::min<uint32_t>(HEADS_SPEC, seg_cap) * sizeof(HeadRec));
+            if (plan && hc0[18] == 1ull) { plan->planned = true; plan->out_bytes = hc0[19]; plan->n_emit = (uint32_t)hc0[20]; }
             break;
         }
         if ((uint32_t)hc[3]) { err = (uint32_t)hc[3] == 2 ? "collapse: too many short circular unitigs" : ((uint32_t)hc[3] == 3 ? "collapse: ring without a smallest k-mer" : "collapse: broken cycle"); return -6; }
@@ -1770,8 +1789,40 @@ public:
         Graph<W> g = graph_view();
         ChainState cs;
         const uint64_t dw_min = env_u64("SHK_DEVICE_WRITER_MIN", 20000);
+        // an isolate (a handful of chains): emission planned on the device, text written and sent home inside the ranking's launch
+        // sequence — room for 512 chain records and n + 512 (k - 1) bases (what does not fit is planned on the host as before)
+        constexpr uint32_t PLAN_HEADS = 512;
+        EmitPlan plan{}; EmitPlan *use_plan = nullptr;
+        DevBuf<EmitRec> d_plan_off; DevBuf<char> d_plan_out;
+        // (off by default — SHK_DEVICE_PLAN=1: measured on the bench isolate, three alternating runs of 30 steps each: 3.30 / 3.22 /
+        // 3.20 ms per step with the plan on the host against 3.37 / 3.22 / 3.27 with it on the device — the round trip it saves is
+        // paid back by the text crossing PCIe through a kernel instead of the copy engine.  DESIGN.md section 4)
+        if (env_u64("SHK_DEVICE_PLAN", 0) != 0 && dw_min > PLAN_HEADS) {
+            const unsigned long long cap = (unsigned long long)n + (unsigned long long)PLAN_HEADS * (unsigned long long)(k_ - 1) + 64ull;
+            if (int rc = d_plan_off.alloc(PLAN_HEADS, err)) return rc;
+            if (int rc = d_plan_out.alloc(cap + 16, err)) return rc;
+            if (int rc = hout_.alloc(cap + 16, err)) return rc;
+            plan.d_off = d_plan_off.p; plan.d_out = d_plan_out.p; plan.h_out = hout_.p; plan.max_heads = PLAN_HEADS; plan.out_cap = cap;
+            use_plan = &plan;
+        }
         // (chains come on both strands: 2 x dw_min chain records mean at least dw_min contigs)
-        if (int rc = rank_chains(cs, true, err, json ? (uint32_t)std::min<uint64_t>(2 * dw_min, 0xFFFFFFFFull) : 0xFFFFFFFFu)) return rc;
+        if (int rc = rank_chains(cs, true, err, json ? (uint32_t)std::min<uint64_t>(2 * dw_min, 0xFFFFFFFFull) : 0xFFFFFFFFu, use_plan)) return rc;
+        if (use_plan && plan.planned && cs.heads_on_host) {
+            // the text is on the host already (hout_): the contigs in chain-record order, as k_plan_emit laid them out
+            std::vector<HeadRec> &hd = cs.heads;
+            unsigned long long at = 0; uint32_t ne = 0;
+            out.reserve(plan.n_emit);
+            for (size_t i = 0; i < hd.size(); i++) {
+                if (!hd[i].emit) continue;
+                RawContig rc; rc.kc = hd[i].kc;
+                rc.ext = hout_.p + at; rc.ext_n = hd[i].len + (uint64_t)(k_ - 1);
+                at += rc.ext_n; ne++;
+                out.push_back(std::move(rc));
+            }
+            if (at != plan.out_bytes || ne != plan.n_emit) { err = "collapse: the device's emission plan and the chain records disagree"; return -6; }
+            times_.add("collapse_planned_on_device_x1", 1.0);
+            return 0;
+        }
         if (!cs.heads_on_host) {
             // ---- a fragmented assembly: which chains are emitted, where, and the whole get_assembly() text on the device
             const uint32_t nh = cs.n_heads;

@@ -68,7 +68,7 @@ for case in range(n_cases):
     if rng.random() < 0.3: env["SHK_HOST_PARSER"] = "1"
     if rng.random() < 0.2: env["SHK_BATCH_BASES"] = str(int(rng.integers(2000, 200000)))
     if rng.random() < 0.3: env["SHK_PART_P"] = str(int(rng.choice([2, 8, 64, 256, 16384])))   # few partitions: LDS tables overflow
-    if rng.random() < 0.15: env["SHK_PROBE_PARTS"] = str(int(rng.choice([0, 1, 4])))
+    if rng.random() < 0.15: env["SHK_PROBE_PARTS"] = str(int(rng.choice([0, 1, 4, 8, 16])))     # (8, 16: the verdict "error-rich" after 1 or 2 partitions handed over)
     if rng.random() < 0.1: env["SHK_OVF_CAP_PCT"] = "60"            # bucket regions overflow: re-scatter / residue classes
     if rng.random() < 0.1: env["SHK_NO_REPARTITION"] = "1"
     if rng.random() < 0.35: env["SHK_SPLIT_LOG"] = str(int(rng.choice([0, 1, 3, 7, 10, 14])))   # rings with many / one / no splitter
@@ -82,6 +82,7 @@ for case in range(n_cases):
     if rng.random() < 0.3: env["SHK_COUNT_MERGE"] = str(int(rng.choice([1, 4])))   # partitions per table of k_count_weighted
     if rng.random() < 0.5: env["SHK_TILE_ROWS"] = str(int(rng.choice([1, 3, 17, 64, 300, 1000, 4096])))   # collapse: many small LDS tiles
     if rng.random() < 0.25: env["SHK_SEG_CAP"] = str(int(rng.choice([1, 8, 64])))   # round 4: the splitter list outgrows its room -> the ranking is called off and repeated
+    if rng.random() < 0.3: env["SHK_DEVICE_PLAN"] = "1"            # round 4: emission planned on the device for <= 512 chain records (default: on the host)
     if rng.random() < 0.25: env["SHK_ARRIVAL_MIN"] = "1"           # round 4: the writer starts on contig text that is still arriving (slab-copy kernel + host flags)
     if rng.random() < 0.3: env["SHK_GUNZIP_DEVICE_MIN"] = "2048"   # round 4: gzip members go to the device inflater first (it declines most of these tiny ones)
     old = {e: os.environ.get(e) for e in env}
