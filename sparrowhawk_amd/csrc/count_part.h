@@ -46,6 +46,7 @@ struct PartParams {
     int k, m;
     uint32_t max_n;
     uint32_t dbg_nostore;        // timing experiments only (SHK_DEBUG_NOSTORE): 1 = every record to slot 0 of its slice, 2 = no flush
+    unsigned long long *dbg_clk; // timing experiments only (SHK_DEBUG_P1CLK, ABLATE builds): wave-cycles per phase of k_partition, summed over the waves
 };
 
 template <int RW> struct Rec { uint64_t w[RW]; };
@@ -66,40 +67,73 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 // list fills up and at the end of the tile, so the walk needs no workgroup barrier (the first
 // version shared one list and paid two 16-wave barriers per 16 bases: 68 % of the wave cycles were
 // waits, profiles/r01_s2_start).
+//
+// The runs of a lane follow one another without a gap (a run starts at the k-mer where the one before
+// it ended, the first at k-mer 0 of the segment), so a descriptor is just {partition, length}: the
+// flush adds the lengths up from the position it has reached (`fpos`).  Closing a run costs the walk
+// three vector instructions and one LDS store (round 3: eight and two).
+//
+// The window of a k-mer is NBLK blocks of WBLK m-mers (m = k - NBLK*WBLK + 1).  With one block the
+// minimum of the window is min(suffix of the block before, prefix of this block); with two it is
+// min3(suffix of the block before the last, the whole last block, prefix of this block) — the same
+// instruction count per base, a window of 20 m-mers instead of 16, runs of 10.5 k-mers on average
+// instead of 8.5: a fifth fewer records to build, store and fetch again.
 static constexpr int PART_WAVES = PART_THREADS / 64;
-static constexpr uint32_t LDESC_CAP = 8;             // descriptors per lane
-static constexpr int DESC_CHECK = 2;                 // steps between room checks (one new per lane and step at most)
-static constexpr int STAGE_PF = (STAGE_WORDS + 8 + PART_THREADS - 1) / PART_THREADS;   // prefetch registers per thread
+static constexpr uint32_t LDESC_CAP = 12;            // descriptors per lane
+static constexpr int STAGE_PF = 12;                  // prefetch registers per lane: ceil(WSTAGE / 64)
 
+static constexpr uint32_t WSTAGE = 724;              // packed words of a wave's own tile (11 584 bases: 64 reads of 181)
+static constexpr uint32_t LONG_NK = 2048;            // a segment with more k-mers is walked in pieces, a lane per piece
+static constexpr uint32_t PIECE_K = 160;             // k-mers per piece (64 pieces and their k-1 bases of overlap fit a stage)
 struct PartShared {
-    uint32_t stage[STAGE_WORDS + 24];         // the next tile is fetched into registers while this one is walked
-    uint32_t desc_a[PART_WAVES][LDESC_CAP][64];   // tile-relative base offset (18 bits) | (n-1) << 18
-    uint16_t desc_p[PART_WAVES][LDESC_CAP][64];
+    uint2 nt_lut[16];                 // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1); first: the address fits the instruction's offset field
+    uint32_t stage[PART_WAVES * WSTAGE + 24]; // one tile per WAVE: the next one is fetched into registers while this one is walked
+    uint32_t desc[PART_WAVES][LDESC_CAP][64]; // partition | (n-1) << 14
     uint32_t cursor[PART_MAX_P];
-    uint2 nt_lut[16];                 // [out<<2|in]: x = rol(seed[out],m)^seed[in], y = ror(seed[~out],1)^rol(seed[~in],m-1)
     uint32_t red[PART_WAVES];
 };
+// + for records of up to four words: the bit mask of a record of n k-mers (one 16-byte LDS read per two words instead
+// of two 64-bit shifts, two selects and two compares per word)
+template <int RW> struct PartSharedT : PartShared {
+    static constexpr bool HAS_MASKS = RW <= 4;
+    __attribute__((aligned(16))) uint32_t rmask[HAS_MASKS ? 64 * 2 * RW : 4];
+};
 
-// build one record from the staged tile
+// build one record from the staged tile: bases [off, off + n + k - 1), n = n1 + 1; rmask = the mask row of n1
 template <int RW>
-__device__ __forceinline__ void part_build_record(const uint32_t *stage, uint32_t off, uint32_t n, int k, uint64_t (&out)[RW]) {
-    const uint32_t bit0 = 2u * off;
-    const uint32_t wi = bit0 >> 5, s = bit0 & 31u;
-    const uint32_t nbits = 2u * (n + (uint32_t)k - 1u);
+__device__ __forceinline__ void part_build_record(const uint32_t *stage, const uint32_t *rmask, uint32_t off, uint32_t n1, int k,
+                                                  uint64_t (&out)[RW]) {
+    const uint32_t wi = off >> 4, s = 2u * off;                // (the funnel shift takes the low five bits of s)
     uint32_t w[2 * RW + 1];
 #pragma unroll
     for (int o = 0; o < 2 * RW + 1; o++) w[o] = stage[wi + o];
+    if constexpr (PartSharedT<RW>::HAS_MASKS) {
+        uint32_t mk[2 * RW];
 #pragma unroll
-    for (int o = 0; o < RW; o++) {
-        const uint32_t lo = __builtin_amdgcn_alignbit(w[2 * o + 1], w[2 * o], s);
-        const uint32_t hi = __builtin_amdgcn_alignbit(w[2 * o + 2], w[2 * o + 1], s);
-        uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
-        const int rem = (int)nbits - 64 * o;            // bits of this word that belong to the run
-        if (rem <= 0) v = 0;
-        else if (rem < 64) v &= (1ull << rem) - 1ull;
-        out[o] = v;
+        for (int o = 0; o < 2 * RW; o += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(rmask + o);
+            mk[o] = q.x; mk[o + 1] = q.y; mk[o + 2] = q.z; mk[o + 3] = q.w;
+        }
+#pragma unroll
+        for (int o = 0; o < RW; o++) {
+            const uint32_t lo = __builtin_amdgcn_alignbit(w[2 * o + 1], w[2 * o], s) & mk[2 * o];
+            const uint32_t hi = __builtin_amdgcn_alignbit(w[2 * o + 2], w[2 * o + 1], s) & mk[2 * o + 1];
+            out[o] = (uint64_t)lo | ((uint64_t)hi << 32);
+        }
+    } else {
+        const uint32_t nbits = 2u * (n1 + (uint32_t)k);
+#pragma unroll
+        for (int o = 0; o < RW; o++) {
+            const uint32_t lo = __builtin_amdgcn_alignbit(w[2 * o + 1], w[2 * o], s);
+            const uint32_t hi = __builtin_amdgcn_alignbit(w[2 * o + 2], w[2 * o + 1], s);
+            uint64_t v = (uint64_t)lo | ((uint64_t)hi << 32);
+            const int rem = (int)nbits - 64 * o;            // bits of this word that belong to the run
+            if (rem <= 0) v = 0;
+            else if (rem < 64) v &= (1ull << rem) - 1ull;
+            out[o] = v;
+        }
     }
-    out[RW - 1] |= (uint64_t)(n - 1u) << 58;
+    out[RW - 1] |= (uint64_t)n1 << 58;
 }
 // A record and its reverse complement describe the same k-mers (pass 2 canonicalises every k-mer it expands),
 // and at high coverage every locus is read on both strands: the smaller of the two spellings is stored, so
@@ -162,35 +196,56 @@ __device__ __forceinline__ void part_store_record(const uint64_t (&out)[RW], uin
 // back to flat loads with 64-bit address arithmetic for every stage / descriptor access)
 #define SHK_LDS __attribute__((address_space(3)))
 #define SHK_GLOBAL __attribute__((address_space(1)))
+// The wave's descriptor lists -> records.  `cnt` descriptors in this lane's list, `fpos` = tile-relative base position of
+// its first unflushed run; returns the position behind the last one.
+// (Inlined: as a function, everything the walk keeps across the call had to sit in the callee-saved half of the
+// registers — the next tile's words, three rounds of offsets, the block's hashes and suffix minima — and what did not fit
+// was spilled around EVERY load, a wait for memory each.)
 template <int RW>
-__device__ __noinline__ void wave_flush(SHK_LDS PartShared *sh_l, const SHK_LDS uint32_t *stage_l, uint32_t wave, uint32_t cnt,
-                                        int k, uint32_t G, uint32_t slice_cap, uint32_t g, SHK_GLOBAL uint64_t *recs_g,
-                                        uint32_t dbg_arg = 0) {
+__device__ __forceinline__ uint32_t wave_flush(SHK_LDS PartSharedT<RW> *sh_l, uint32_t wave, uint32_t cnt, uint32_t fpos,
+                                            int k, uint32_t G, uint32_t slice_cap, uint32_t g, SHK_GLOBAL uint64_t *recs_g,
+                                            uint32_t dbg_arg = 0) {
     const uint32_t dbg = SHK_DBG(dbg_arg);
-    PartShared *sh = (PartShared *)sh_l;                 // address space is inferred from the cast
+    PartSharedT<RW> *sh = (PartSharedT<RW> *)sh_l;       // address space is inferred from the cast
     uint64_t *recs = (uint64_t *)recs_g;
-    const uint32_t *stage = (const uint32_t *)stage_l;
     const uint32_t lane = threadIdx.x & 63u;
-    if (dbg == 2) return;                                // timing experiment: the walk alone
     uint32_t mx = 0;                                     // longest list in the wave (cnt <= LDESC_CAP): ballots, no shuffles
 #pragma unroll
     for (uint32_t c = 1; c <= LDESC_CAP; c++) if (__ballot(cnt >= c)) mx = c;
+    // One LDS round trip per record on the critical path: the next descriptor is fetched while this one is worked on, and
+    // the bases and the mask of a record are requested together with its slot (a record whose slice is full is built
+    // and dropped: the host repeats the pass with more room).
+    uint32_t ds = sh->desc[wave][0][lane];
     for (uint32_t d = 0; d < mx; d++) {
+        const uint32_t ds_next = sh->desc[wave][min(d + 1u, LDESC_CAP - 1u)][lane];
         if (d < cnt) {
-            const uint32_t a = sh->desc_a[wave][d][lane];
-            const uint32_t p = sh->desc_p[wave][d][lane];
-            const uint32_t idx = atomicAdd(&sh->cursor[p], 1u);          // LDS cursor of slice [p][g]
-            if (idx < slice_cap) {
+            const uint32_t p = ds & 0x3FFFu, n1 = ds >> 14;
+            const uint32_t off = fpos;
+            fpos += n1 + 1u;
+            if (dbg != 2) {                                      // (2: timing experiment, the walk alone)
+                // LDS cursor of slice [p][g].  No branch on the room: a record behind the end of its slice goes to the slice's last
+                // slot (the cursor keeps counting, the host sees the overflow and repeats both passes with the exact room, so what
+                // pass 2 read from that slot meanwhile is thrown away) — with a branch the compiler sinks the loads of the bases
+                // behind the wait for the cursor, one more LDS round trip per record
+                // (timing experiments 3 .. 6: no cursor atomic / no bases and mask / no store / no mask)
+                const uint32_t idx = dbg == 3 ? (fpos & 15u) : min(atomicAdd(&sh->cursor[p], 1u), slice_cap - 1u);
                 uint64_t r[RW];
-                part_build_record<RW>(stage, a & 0x3FFFFu, (a >> 18) + 1u, k, r);
-                part_store_record<RW>(r, recs + (((uint64_t)p * G + g) * slice_cap + (dbg == 1 ? 0u : idx)) * RW);
+                if (dbg == 4) {
+#pragma unroll
+                    for (int o = 0; o < RW; o++) r[o] = ((uint64_t)off << 20) | n1;
+                } else part_build_record<RW>(sh->stage + wave * WSTAGE, dbg == 6 ? sh->rmask : sh->rmask + n1 * (2 * RW), off, n1, k, r);
+                const uint32_t slice = p * G + g;                            // (P * G <= 2^22)
+                if (dbg != 5) part_store_record<RW>(r, recs + ((uint64_t)slice * slice_cap + (dbg == 1 ? 0u : idx)) * RW);
+                else if (r[0] == 0x1234567ull) recs[0] = r[1];               // (keeps the record alive)
             }
         }
+        ds = ds_next;
     }
+    return fpos;
 }
 
-// W: key words (records have RW = 2W words); WBLK: k-mers per minimiser window block (= w)
-template <int W, int WBLK>
+// W: key words (records have RW = 2W words); the window of a k-mer = NBLK blocks of WBLK m-mers
+template <int W, int WBLK, int NBLK>
 __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__restrict__ bases,
                                                             const uint32_t *__restrict__ seg_off,
                                                             uint32_t n_seg, PartParams pp,
@@ -198,11 +253,16 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                                                             uint32_t *__restrict__ fill,
                                                             uint32_t *__restrict__ flags) {
     constexpr int RW = 2 * W;
-    static_assert(WBLK <= 16 && WBLK % 2 == 0, "a block of m-mers must fit one 32-bit window");
-    __shared__ PartShared sh;
+    static_assert(WBLK <= 16, "a block of m-mers must fit one 32-bit window");
+    static_assert(NBLK == 1 || NBLK == 2, "one or two blocks per window");
+    constexpr int DESC_CHECK = WBLK % 3 == 0 ? 3 : WBLK % 4 == 0 ? 4 : 2;   // steps between room checks (one new descriptor per lane and step at most)
+    static_assert(WBLK % DESC_CHECK == 0, "checks at equal distances across blocks");
+    __shared__ PartSharedT<RW> sh;
     const uint32_t g = blockIdx.x;
     const int lane = threadIdx.x & 63;
-    const uint32_t wave = threadIdx.x >> 6;
+    // (told to the compiler as wave-uniform: every wave iterates over tiles of its own, and with a "divergent" wave number
+    // the whole tile loop was compiled as predicated vector code)
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = pp.k, m = pp.m;
     const uint32_t pmask = pp.P - 1u;
     const uint32_t max_n = pp.max_n;
@@ -217,72 +277,131 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
         v.y = ror32(nt32_seed(3u - out), 1) ^ rol32(nt32_seed(3u - in), (unsigned)(m - 1));
         sh.nt_lut[threadIdx.x] = v;
     }
-    __syncthreads();
-
-    // ---- tiles: [first, first+cnt) segments whose packed words [w0, w0+nwords) fit one LDS stage.  The
-    // iterator is wave-uniform; tile i+1 is fetched into registers before tile i is walked and stored
-    // to the stage afterwards: HBM latency behind the walk.
-    struct Tile { uint32_t first, cnt, w0, nwords; };
-    uint32_t it_st = g * PART_THREADS, it_first = it_st;
-    auto next_tile = [&](Tile &t) -> bool {
-        for (;;) {
-            if (it_st >= n_seg) return false;
-            const uint32_t st_end = min(it_st + (uint32_t)PART_THREADS, n_seg);
-            if (it_first >= st_end) { it_st += gridDim.x * PART_THREADS; it_first = it_st; continue; }
-            uint32_t cnt = st_end - it_first;
-            const uint32_t w0 = seg_off[it_first] >> 4;
-            while (cnt > 1 && ((seg_off[it_first + cnt] + 15u) >> 4) - w0 > (uint32_t)STAGE_WORDS) cnt >>= 1;
-            const uint32_t nwords = ((seg_off[it_first + cnt] + 15u) >> 4) - w0;
-            const uint32_t f = it_first;
-            it_first += cnt;
-            if (nwords > (uint32_t)STAGE_WORDS) {            // a single segment longer than the stage
-                if (threadIdx.x == 0) flags[1] = 1;
-                continue;
-            }
-            t.first = f; t.cnt = cnt; t.w0 = w0; t.nwords = nwords;
-            return true;
-        }
-    };
-    Tile cur{0, 0, 0, 0}, nxt{0, 0, 0, 0};
-    bool have_cur = next_tile(cur);
-    uint32_t L = 0, rel = 0;
-    if (have_cur) {
-        for (uint32_t i = threadIdx.x; i < cur.nwords + 8; i += PART_THREADS)
-            sh.stage[i] = (i < cur.nwords + 1) ? bases[cur.w0 + i] : 0u;        // +1: the spare word
-        if (threadIdx.x < cur.cnt) {
-            const uint32_t s0 = seg_off[cur.first + threadIdx.x], s1 = seg_off[cur.first + threadIdx.x + 1];
-            L = s1 - s0; rel = s0 - (cur.w0 << 4);
+    if constexpr (PartSharedT<RW>::HAS_MASKS) {
+        for (uint32_t e = threadIdx.x; e < 64u * 2u * RW; e += PART_THREADS) {
+            const uint32_t n1 = e / (2u * RW), o = e % (2u * RW);
+            const int rem = (int)(2u * (n1 + (uint32_t)k)) - 32 * (int)o;        // bits of dword o that belong to a record of n1 + 1 k-mers
+            sh.rmask[e] = rem <= 0 ? 0u : rem >= 32 ? 0xFFFFFFFFu : ((1u << rem) - 1u);
         }
     }
     __syncthreads();
-    while (have_cur) {
-        {
-            const uint32_t *stage = sh.stage;
-            // ---- prefetch of the next tile (registers)
-            const bool have_nxt = next_tile(nxt);
-            uint32_t pf[STAGE_PF];
-            uint32_t Ln = 0, reln = 0;
-            if (have_nxt) {
+
+    // ---- tiles.  Every WAVE has a tile of its own (round 4; before, the 16 waves of the workgroup shared one tile and met
+    // at two barriers per tile: measured with s_memtime, a wave spent 30 % of its cycles between its last step and the next
+    // tile's first — waiting for the slowest wave, the oldest wave of a SIMD being served first — and 12 % finding the next
+    // tile).  Wave v of the grid takes the 64 segments [64 T, 64 T + 64), T = v, v + waves, ...; their offsets are requested
+    // one round ahead, the packed words of the round's first tile travel in registers while the tile before is walked.  A
+    // round is one tile when its 64 segments fit the stage (150-base reads: always); otherwise as many consecutive segments
+    // as fit, and a segment of more than LONG_NK k-mers is walked in pieces of PIECE_K k-mers, a lane per piece (a piece is
+    // a segment of its own to the walk: runs end at piece edges, the k-mers are the same).  No barrier until the end.
+    static_assert((WSTAGE + 63) / 64 <= STAGE_PF, "prefetch registers");
+    static_assert(64u * PIECE_K + 256u + 32u <= 16u * (WSTAGE - 1u), "64 pieces fit a stage");
+    const uint32_t n_super = (n_seg + 63u) >> 6, n_waves = gridDim.x * PART_WAVES;
+    SHK_LDS uint32_t *const stage_l = (SHK_LDS uint32_t *)&sh.stage[wave * WSTAGE];
+    const uint32_t *const stage = (const uint32_t *)stage_l;
+    SHK_LDS uint32_t *const dbase = (SHK_LDS uint32_t *)&sh.desc[wave][0][lane];
+#if SHK_ABLATE
+    unsigned long long clk_pre = 0, clk_walk = 0, clk_flush = 0, clk_tail = 0, clk_t0 = 0;
+#define SHK_CLK(x) x
+#else
+#define SHK_CLK(x)
+#endif
+    auto load_seg = [&](uint32_t T, uint32_t &s0, uint32_t &s1) {      // lanes behind the last segment get an empty one
+        const uint32_t i = min(64u * T + (uint32_t)lane, n_seg);
+        s0 = seg_off[i]; s1 = seg_off[min(i + 1u, n_seg)];
+    };
+    // a tile of whole segments [start, end) of the round, or (end == start) the long segment `start` alone
+    struct Plan { uint32_t end, w0, nwords; };
+    auto plan = [&](uint32_t s0, uint32_t s1, uint32_t start) -> Plan {
+        const uint32_t Ls = s1 - s0;
+        const uint32_t w0 = __builtin_amdgcn_readlane(s0, start) >> 4;
+        const bool is_long = Ls >= (uint32_t)k + LONG_NK;
+        const bool fits = ((s1 + 15u) >> 4) - w0 <= WSTAGE - 1u;
+        const unsigned long long stop = __ballot((uint32_t)lane >= start && (is_long || !fits));
+        const uint32_t end = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
+        Plan pl; pl.end = end; pl.w0 = w0;
+        pl.nwords = end > start ? ((__builtin_amdgcn_readlane(s1, end - 1u) + 15u) >> 4) - w0 : 0u;
+        return pl;
+    };
+    uint32_t T = g * PART_WAVES + wave;                        // this wave's round
+    uint32_t s0c = 0, s1c = 0, s0n = 0, s1n = 0, s0nn = 0, s1nn = 0;     // offsets of this round, the next, the one after it
+    if (T < n_super) load_seg(T, s0c, s1c);
+    if (T + n_waves < n_super) load_seg(T + n_waves, s0n, s1n);
+    bool prefetched = false;                                   // pf[] holds the first tile of the round (plan pl_pf)
+    uint32_t pf[STAGE_PF];
+    Plan pl_pf{0, 0, 0};
+    for (; T < n_super; T += n_waves) {
+        uint32_t start = 0, round = 0;                         // next segment of the round / next 64 pieces of a long segment
+        const uint32_t n_here = min(64u, n_seg - 64u * T);
+        bool first_tile = true;
+        while (start < n_here) {
+            SHK_CLK(clk_t0 = __builtin_amdgcn_s_memtime();)
+            // ---- the tile: which lanes walk what
+            const Plan pl = (first_tile && prefetched) ? pl_pf : plan(s0c, s1c, start);
+            uint32_t L = 0, rel = 0, w0 = pl.w0, nwords = pl.nwords;
+            uint32_t next_start = pl.end, next_round = 0;
+            if (pl.end > start) {
+                if ((uint32_t)lane >= start && (uint32_t)lane < pl.end) { L = s1c - s0c; rel = s0c - (w0 << 4); }
+            } else {                                           // pieces 64 round .. 64 round + 63 of segment `start`
+                const uint32_t a0 = __builtin_amdgcn_readlane(s0c, start), a1 = __builtin_amdgcn_readlane(s1c, start);
+                const uint32_t nk = a1 - a0 - (uint32_t)k + 1u;
+                const uint32_t k0 = 64u * PIECE_K * round;             // first k-mer of this round
+                const uint32_t kend = min(k0 + 64u * PIECE_K, nk);
+                w0 = (a0 + k0) >> 4;
+                nwords = ((a0 + kend + (uint32_t)k - 1u + 15u) >> 4) - w0;
+                const uint32_t kp = k0 + PIECE_K * (uint32_t)lane;
+                if (kp < kend) { L = min(PIECE_K, kend - kp) + (uint32_t)k - 1u; rel = a0 + kp - (w0 << 4); }
+                if (kend < nk) { next_start = start; next_round = round + 1u; } else next_start = start + 1u;
+            }
+            // ---- its packed words: out of the prefetch registers, or fetched now (a round of several tiles)
+            if (!(first_tile && prefetched)) {
 #pragma unroll
                 for (int i = 0; i < STAGE_PF; i++) {
-                    const uint32_t idx = threadIdx.x + (uint32_t)i * PART_THREADS;
-                    pf[i] = idx < nxt.nwords + 1 ? bases[nxt.w0 + idx] : 0u;
+                    const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                    pf[i] = idx < nwords + 1u ? bases[w0 + idx] : 0u;          // +1: the spare word
                 }
-                if (threadIdx.x < nxt.cnt) {
-                    const uint32_t s0 = seg_off[nxt.first + threadIdx.x], s1 = seg_off[nxt.first + threadIdx.x + 1];
-                    Ln = s1 - s0; reln = s0 - (nxt.w0 << 4);
+                prefetched = false;                            // (a later tile of the round: the registers held the next round's words)
+            }
+#pragma unroll
+            for (int i = 0; i < STAGE_PF; i++) {
+                const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                if (idx < WSTAGE) stage_l[idx] = pf[i];
+            }
+            // ---- behind the round's first tile: the first tile of the next round into the registers, the offsets of the
+            // round after it on their way
+            if (first_tile) {
+                prefetched = false;
+                if (T + 2u * n_waves < n_super) load_seg(T + 2u * n_waves, s0nn, s1nn);       // (used a whole round from now)
+                if (T + n_waves < n_super) {
+                    pl_pf = plan(s0n, s1n, 0u);
+                    if (pl_pf.end > 0u) {
+                        prefetched = true;
+#pragma unroll
+                        for (int i = 0; i < STAGE_PF; i++) {
+                            const uint32_t idx = (uint32_t)lane + 64u * (uint32_t)i;
+                            pf[i] = idx < pl_pf.nwords + 1u ? bases[pl_pf.w0 + idx] : 0u;
+                        }
+                    }
                 }
             }
-            uint32_t maxL = L;                               // over the wave
+            first_tile = false;
+            // longest and shortest segment of the wave (reads of one length: two instructions)
+            uint32_t maxL = __builtin_amdgcn_readfirstlane(L), minL = maxL;
+            if (__ballot(L != maxL)) {
+                maxL = L; minL = L;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, o));
-            maxL = __builtin_amdgcn_readfirstlane(maxL);
+                for (int o = 32; o > 0; o >>= 1) {
+                    maxL = max(maxL, (uint32_t)__shfl_xor((int)maxL, o));
+                    minL = min(minL, (uint32_t)__shfl_xor((int)minL, o));
+                }
+                maxL = __builtin_amdgcn_readfirstlane(maxL); minL = __builtin_amdgcn_readfirstlane(minL);
+            }
 
             // ---- per-lane walk; every lane of the wave runs the same (block, t) schedule ----------
             // Bases come from 64-bit windows loaded once per block (a block of WBLK <= 16 bases spans
             // at most two packed words), never from per-lane reloads inside the step loop.
             auto window32 = [&](uint32_t pos) -> uint32_t {  // the 16 bases from stream position pos
-                const uint32_t wi = min(pos >> 4, (uint32_t)(STAGE_WORDS + 14));
+                const uint32_t wi = min(pos >> 4, WSTAGE + 14u);
                 return __builtin_amdgcn_alignbit(stage[wi + 1], stage[wi], 2u * (pos & 15u));
             };
             Nt32State nt{0, 0};
@@ -292,31 +411,36 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 for (int t = 0; t < 16 && jb + t < m; t++)
                     nt32_init_step(nt, (wv >> (2 * t)) & 3u, (unsigned)(jb + t));
             }
-            uint32_t hreg[WBLK], sreg[WBLK];
+            // suffix minima of the blocks before: block b reads those of block b - NBLK from sr[b % NBLK] and leaves its own there
+            uint32_t hreg[WBLK], sr0[WBLK], sr1[NBLK == 2 ? WBLK : 1];
 #pragma unroll
-            for (int t = 0; t < WBLK; t++) { hreg[t] = 0xFFFFFFFFu; sreg[t] = 0xFFFFFFFFu; }
-            // the current run: [run_start, i) of partition run_p; NO_RUN before the first k-mer.  The k-mer
-            // index i of a step is the same in every lane, so run lengths are scalar-minus-vector.
+            for (int t = 0; t < WBLK; t++) { hreg[t] = 0xFFFFFFFFu; sr0[t] = 0xFFFFFFFFu; if constexpr (NBLK == 2) sr1[t] = 0xFFFFFFFFu; }
+            // the current run: partition run_p, started at k-mer (run_lim >> 14) - max_n; NO_RUN before the first k-mer.  The
+            // k-mer index i of a step is the same in every lane, so run lengths are scalar-minus-vector; run_lim is kept
+            // shifted to where the descriptor holds the length (k-mer indices stay below 2^15).
             constexpr uint32_t NO_RUN = 0xFFFFFFFFu;
-            uint32_t run_start = 0, run_p = NO_RUN;
-            uint32_t dcnt = 0;                               // this lane's descriptors
+            uint32_t run_lim = 0, run_p = NO_RUN;
+            SHK_LDS uint32_t *dptr = dbase;                  // this lane's next descriptor slot
+            uint32_t fpos = rel;                             // where this lane's first unflushed run starts
             // the waves of one SIMD flush at different fill levels: a flush is a chain of LDS round trips,
             // it overlaps with the VALU-bound walk of the others only if they do not all flush together
-            const uint32_t flush_at = LDESC_CAP - DESC_CHECK - (wave >> 2);
-            uint32_t minL = L;                               // over the wave
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) minL = min(minL, (uint32_t)__shfl_xor((int)minL, o));
-            minL = __builtin_amdgcn_readfirstlane(minL);
+            SHK_LDS uint32_t *const flush_at = dbase + 64u * (LDESC_CAP - DESC_CHECK - (wave >> 2));
+            auto flush = [&]() {
+                SHK_CLK(const unsigned long long f0 = __builtin_amdgcn_s_memtime();)
+                fpos = wave_flush<RW>((SHK_LDS PartSharedT<RW> *)&sh, wave, ((uint32_t)(uintptr_t)dptr - (uint32_t)(uintptr_t)dbase) >> 8, fpos, k, pp.G, pp.slice_cap, g,
+                                      (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore));
+                dptr = dbase;
+                SHK_CLK(clk_flush += __builtin_amdgcn_s_memtime() - f0;)
+            };
             const uint32_t n_mmers_max = maxL >= (uint32_t)m ? maxL - (uint32_t)m + 1u : 0u;
             const uint32_t n_blocks = (n_mmers_max + WBLK - 1) / WBLK;
-            // blocks whose WBLK m-mers exist in every lane of the wave (and are not the first): no bounds logic
+            // blocks whose WBLK m-mers exist in every lane of the wave (and are behind the first k-mer): no bounds logic
             const uint32_t n_full = minL >= (uint32_t)m ? (minL - (uint32_t)m + 1u) / WBLK : 0u;
-            auto emit = [&](uint32_t i_end) {                // close [run_start, i_end) of this lane
-                sh.desc_a[wave][dcnt][lane] = (rel + run_start) | ((i_end - run_start - 1u) << 18);
-                sh.desc_p[wave][dcnt][lane] = (uint16_t)run_p;
-                dcnt++;
+            auto emit = [&](uint32_t c_end) {                // close the run at k-mer i_end: c_end = (i_end - 1 + max_n) << 14
+                *dptr = (c_end - run_lim) | run_p;           // n - 1 = i_end - 1 - run_start
+                dptr += 64;
             };
-            auto do_block = [&](auto full_tag, uint32_t bq) {
+            auto do_block = [&](auto full_tag, uint32_t bq, uint32_t (&srs)[WBLK], const uint32_t mid) {
                 constexpr bool FULL = decltype(full_tag)::value;
                 const uint32_t q0 = bq * WBLK;                             // first m-mer of the block
                 // the state holds m-mer q; after using it, base q leaves and base q+m enters.
@@ -324,14 +448,11 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                 const uint32_t X = window32(rel + q0), Y = window32(rel + q0 + (uint32_t)m);
                 const uint32_t ze = ((X & 0x33333333u) << 2) | (Y & 0x33333333u);
                 const uint32_t zo = (X & 0xCCCCCCCCu) | ((Y >> 2) & 0x33333333u);
-                uint32_t pm = 0xFFFFFFFFu;
+                uint32_t pm = NBLK == 2 ? mid : 0xFFFFFFFFu;
 #pragma unroll
                 for (int t = 0; t < WBLK; t++) {
                     if (t % DESC_CHECK == 0) {
-                        if (__ballot(dcnt > flush_at)) {                    // wave-uniform
-                            wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore));
-                            dcnt = 0;
-                        }
+                        if (__ballot(dptr > flush_at)) flush();            // wave-uniform
                     }
                     const uint32_t q = q0 + (uint32_t)t;
                     const uint32_t j = q + (uint32_t)m - 1u;               // last base of m-mer q (wave-uniform)
@@ -348,42 +469,53 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
                     }
                     hreg[t] = h;
                     pm = min(pm, h);
-                    // k-mer i = q - w + 1 completes here; its window is suffix(prev block, t+1) + prefix(this block, t)
-                    const uint32_t kmin = (t < WBLK - 1) ? min(sreg[(t + 1) % WBLK], pm) : pm;
-                    const bool valid = FULL ? true : (have && (bq > 0 || t == WBLK - 1));
+                    // k-mer i = q - NBLK * WBLK + 1 completes here; its window is suffix(block b - NBLK, t+1) [+ block b - 1] + prefix(this block, t)
+                    uint32_t kmin = pm;
+                    if (t < WBLK - 1) kmin = min(srs[(t + 1) % WBLK], kmin);
+                    const bool valid = FULL ? true : (have && (bq > (uint32_t)(NBLK - 1) || (bq == (uint32_t)(NBLK - 1) && t == WBLK - 1)));
                     const uint32_t p = kmin & pmask;
                     // a new run starts here if the partition changes or the current run is full
-                    if (valid && (p != run_p || run_start + max_n <= i)) {
-                        if (run_p != NO_RUN) emit(i);
-                        run_start = i; run_p = p;
+                    if (valid && (p != run_p || run_lim <= (i << 14))) {
+                        if (FULL || run_p != NO_RUN) emit((i - 1u + max_n) << 14);
+                        run_lim = (i + max_n) << 14; run_p = p;
                     }
                 }
-                // suffix minima of this block for the next one
-                sreg[WBLK - 1] = hreg[WBLK - 1];
+                // suffix minima of this block for the block NBLK further on
+                srs[WBLK - 1] = hreg[WBLK - 1];
 #pragma unroll
-                for (int t = WBLK - 2; t >= 0; t--) sreg[t] = min(hreg[t], sreg[t + 1]);
+                for (int t = WBLK - 2; t >= 0; t--) srs[t] = min(hreg[t], srs[t + 1]);
             };
+            SHK_CLK({ const unsigned long long t1 = __builtin_amdgcn_s_memtime(); clk_pre += t1 - clk_t0; clk_t0 = t1; })
             for (uint32_t bq = 0; bq < n_blocks; bq++) {
-                if (bq > 0 && bq < n_full) do_block(std::true_type{}, bq);
-                else do_block(std::false_type{}, bq);
-            }
-            // close the last run of every segment (it ends with the segment's last k-mer)
-            if (__ballot(dcnt >= LDESC_CAP)) { wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore)); dcnt = 0; }
-            if (run_p != NO_RUN) emit(L - (uint32_t)k + 1u);
-            if (__ballot(dcnt != 0)) wave_flush<RW>((SHK_LDS PartShared *)&sh, (const SHK_LDS uint32_t *)stage, wave, dcnt, k, pp.G, pp.slice_cap, g, (SHK_GLOBAL uint64_t *)recs, SHK_DBG(pp.dbg_nostore));
-            // ---- the next tile replaces this one once every wave has finished reading it
-            __syncthreads();
-            if (have_nxt) {
-#pragma unroll
-                for (int i = 0; i < STAGE_PF; i++) {
-                    const uint32_t idx = threadIdx.x + (uint32_t)i * PART_THREADS;
-                    if (idx < nxt.nwords + 8) sh.stage[idx] = pf[i];
+                // The next tile's words (requested before the walk) are waited for HERE, a few blocks in and before this tile's
+                // first record leaves: loads and stores share one in-order counter, and a wait placed where the words are used —
+                // behind the tile's last flush — also sat out the completion of every record store of the tile.
+                if (bq == 3u) __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                const bool full = bq >= (uint32_t)NBLK && bq < n_full;
+                if constexpr (NBLK == 1) {
+                    if (full) do_block(std::true_type{}, bq, sr0, 0u);
+                    else do_block(std::false_type{}, bq, sr0, 0u);
+                } else {
+                    if (bq & 1u) {
+                        if (full) do_block(std::true_type{}, bq, sr1, sr0[0]);
+                        else do_block(std::false_type{}, bq, sr1, sr0[0]);
+                    } else {
+                        if (full) do_block(std::true_type{}, bq, sr0, sr1[0]);
+                        else do_block(std::false_type{}, bq, sr0, sr1[0]);
+                    }
                 }
             }
-            __syncthreads();
-            cur = nxt; have_cur = have_nxt; L = Ln; rel = reln;
+            SHK_CLK({ const unsigned long long t1 = __builtin_amdgcn_s_memtime(); clk_walk += t1 - clk_t0; clk_t0 = t1; })
+            // close the last run of every segment (it ends with the segment's last k-mer)
+            if (__ballot(dptr >= dbase + 64u * LDESC_CAP)) flush();
+            if (run_p != NO_RUN) emit((L - (uint32_t)k + max_n) << 14);
+            if (__ballot(dptr != dbase)) flush();
+            start = next_start; round = next_round;
+            SHK_CLK(clk_tail += __builtin_amdgcn_s_memtime() - clk_t0;)
         }
+        s0c = s0n; s1c = s1n; s0n = s0nn; s1n = s1nn;
     }
+    SHK_CLK(if (pp.dbg_clk && lane == 0) { atomicAdd(pp.dbg_clk + 0, clk_pre); atomicAdd(pp.dbg_clk + 1, clk_walk); atomicAdd(pp.dbg_clk + 2, clk_flush); atomicAdd(pp.dbg_clk + 3, clk_tail); atomicAdd(pp.dbg_clk + 4, 1ull); })
     __syncthreads();
     // publish this workgroup's slice fills (may exceed slice_cap: the host then retries bigger) and
     // their maximum (one global atomic per workgroup)

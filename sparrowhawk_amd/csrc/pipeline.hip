@@ -452,8 +452,22 @@ private:
     char *base_ = nullptr; size_t total_ = 0; volatile uint32_t *flags_ = nullptr; uint32_t n_slabs_ = 0; hipStream_t st_ = nullptr;
 };
 
-// minimiser length of the counting partitions and of the graph partitions
-static inline int part_m(int k) { return k - (k >= 23 ? 16 : 8) + 1; }
+// m-mers in the minimiser window of a k-mer (pass 1 of the counting step walks them in one block of 8 or 16, or in two
+// blocks of 9), and the minimiser length of the counting partitions and of the graph partitions that follows from it.
+// k = 31 takes the window of 18 (m = 14): runs of 9.7 k-mers instead of 8.3, a seventh fewer records for pass 1 to store.
+// Measured on the bench isolate (profiles/r04_final/window_sweep.txt): w = 20 (m = 12) makes pass 1 faster still, but the
+// partitions get uneven (fewer distinct minimisers per partition: std / mean 0.136 against 0.108) and the graph tables pay
+// 0.11 ms for it; two-word keys (k = 51, reads cut short by quality masking) lose with 18 — most of their records are the
+// partial runs at segment ends, and longer runs make those longer to expand.  SHK_PART_WIN = 16 / 18 / 20 forces a window
+// for k >= 31 (results never depend on it).
+static inline int part_win(int k) {
+    static const int forced = [] { const char *e = getenv("SHK_PART_WIN"); return e ? atoi(e) : 0; }();
+    if (k < 23) return 8;
+    if (k < 31) return 16;
+    if (forced == 16 || forced == 18 || forced == 20) return forced;
+    return k <= 32 ? 18 : 16;
+}
+static inline int part_m(int k) { return k - part_win(k) + 1; }
 
 template <int W> class Pipeline : public IPipeline {
 public:
@@ -543,10 +557,16 @@ public:
     }
 
     // ---- partitioned counting (count_part.h) ---------------------------------------------------
-    template <int WBLK>
-    void launch_partition(const uint32_t *d_bases, const uint32_t *d_seg_off, uint32_t n_seg) {
-        hipLaunchKernelGGL((k_partition<W, WBLK>), dim3(pp_.G), dim3(PART_THREADS), 0, stream_, d_bases, d_seg_off,
+    template <int WBLK, int NBLK>
+    void launch_partition_t(const uint32_t *d_bases, const uint32_t *d_seg_off, uint32_t n_seg) {
+        hipLaunchKernelGGL((k_partition<W, WBLK, NBLK>), dim3(pp_.G), dim3(PART_THREADS), 0, stream_, d_bases, d_seg_off,
                            n_seg, pp_, recs_.p, fill_.p, (uint32_t *)(ctl_.p + 8));
+    }
+    void launch_partition(int win, const uint32_t *d_bases, const uint32_t *d_seg_off, uint32_t n_seg) {
+        if (win == 20) launch_partition_t<10, 2>(d_bases, d_seg_off, n_seg);
+        else if (win == 18) launch_partition_t<9, 2>(d_bases, d_seg_off, n_seg);
+        else if (win == 16) launch_partition_t<16, 1>(d_bases, d_seg_off, n_seg);
+        else launch_partition_t<8, 1>(d_bases, d_seg_off, n_seg);
     }
 
     int count_batch(const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg, uint64_t n_bases,
@@ -577,15 +597,8 @@ public:
     }
     // pass 1 over the batch: one launch, or one per piece (count_batch_pieces) appending to the same slices
     void launch_partition_all(int wblk, const uint32_t *d_bases, const uint32_t *d_seg_off, uint64_t n_seg) {
-        if (piece_list_.empty()) {
-            if (wblk == 16) launch_partition<16>(d_bases, d_seg_off, (uint32_t)n_seg);
-            else launch_partition<8>(d_bases, d_seg_off, (uint32_t)n_seg);
-            return;
-        }
-        for (const DevPiece &pc : piece_list_) {
-            if (wblk == 16) launch_partition<16>(pc.d_bases, pc.d_seg_off, (uint32_t)pc.n_seg);
-            else launch_partition<8>(pc.d_bases, pc.d_seg_off, (uint32_t)pc.n_seg);
-        }
+        if (piece_list_.empty()) { launch_partition(wblk, d_bases, d_seg_off, (uint32_t)n_seg); return; }
+        for (const DevPiece &pc : piece_list_) launch_partition(wblk, pc.d_bases, pc.d_seg_off, (uint32_t)pc.n_seg);
     }
     int count_batch_impl(const uint32_t *d_bases, const uint32_t *d_seg_off, const uint32_t *h_bases, const uint32_t *h_seg_off,
                          uint64_t n_seg, uint64_t n_bases, std::string &err) {
@@ -601,14 +614,29 @@ public:
         // are packed densely into a buffer of their own; pass 2 then reads one run per batch and partition
         if (have_parts_) if (int rc = pack_current_batch(err)) return rc;
         constexpr int RW = 2 * W;
-        const int wblk = k_ >= 23 ? 16 : 8;
+        const int wblk = part_win(k_);                    // m-mers per window
         const uint64_t inst_ub = n_bases - n_seg * (uint64_t)(k_ - 1);
         const int cus = n_cus_;
         const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
         pp_.k = k_; pp_.m = k_ - wblk + 1; pp_.dbg_nostore = env_dbg("SHK_DEBUG_NOSTORE");
+        pp_.dbg_clk = nullptr;
+#if SHK_ABLATE
+        if (env_dbg("SHK_DEBUG_P1CLK")) {                   // (timing experiment: the buffer is leaked on purpose, the report goes to stderr)
+            static unsigned long long *clk = nullptr;
+            if (!clk) (void)hipMalloc((void **)&clk, 64);
+            else {
+                unsigned long long h[8] = {0};
+                (void)hipDeviceSynchronize(); (void)hipMemcpy(h, clk, 64, hipMemcpyDeviceToHost);
+                if (h[4]) fprintf(stderr, "[p1clk] per wave: pre %.0f walk(incl. flush) %.0f flush %.0f tail %.0f cycles (%llu waves)\n", (double)h[0] / h[4], (double)h[1] / h[4], (double)h[2] / h[4], (double)h[3] / h[4], h[4]);
+            }
+            (void)hipMemset(clk, 0, 64);
+            pp_.dbg_clk = clk;
+        }
+#endif
         pp_.max_n = std::min<uint32_t>(32u * RW - 3u - (uint32_t)(k_ - 1), 63u);
         if (uint64_t mn = env_u64("SHK_PART_MAXN", 0)) pp_.max_n = std::min<uint32_t>(pp_.max_n, (uint32_t)mn);
         pp_.G = (uint32_t)std::min<uint64_t>((uint64_t)std::min(cus, 256), n_super);
+        if (uint64_t fg = env_u64("SHK_PART_G", 0)) pp_.G = (uint32_t)std::min<uint64_t>(pp_.G, fg);   // (tests: few workgroups, many tiles per wave)
         uint32_t P = 64;
         // instances per partition: sized so that the distinct k-mers of a 100x isolate load the LDS k-mer table to ~40 %
         const uint64_t per_part = env_u64("SHK_PART_INST", W == 1 ? 100000 : 40000);
@@ -661,8 +689,7 @@ public:
                     HIPCHK(hipEventCreateWithFlags(&evs[c], hipEventDisableTiming));
                     HIPCHK(hipEventRecord(evs[c], copy_stream_));
                     HIPCHK(hipStreamWaitEvent(stream_, evs[c], 0));
-                    if (wblk == 16) launch_partition<16>(d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
-                    else launch_partition<8>(d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
+                    launch_partition(wblk, d_bases, d_seg_off + s0, (uint32_t)(s1 - s0));
                 }
                 HIPCHK(hipGetLastError());
                 times_.add("h2d_pieces_x1", (double)C);

@@ -153,7 +153,7 @@ def test_record_blocks_beyond_one_gibibyte_cross_intact():
     """Round 3: a grouped ncclSend / ncclRecv of a rank to ITSELF delivered only part of a 1.2 GB block on the GPU box (the
     rest of the receive buffer kept stale pool memory: half the k-mers lost, duplicate rows, a broken graph — found with
     the configs[4] share).  The block a rank keeps is a device copy now and every other block travels in pieces of
-    <= 256 MiB.  Here: 5 M reads of an isolate (76 M records = 1.22 GB, sent raw) through a one-rank communicator
+    <= 256 MiB.  Here: 5.8 M reads of an isolate (77 M records = 1.23 GB, sent raw) through a one-rank communicator
     must count exactly what the plain path counts."""
     sys.path.insert(0, ROOT)
     import torch
@@ -161,8 +161,8 @@ def test_record_blocks_beyond_one_gibibyte_cross_intact():
     from sparrowhawk_amd import AssemblyHelper
     from sparrowhawk_amd.dist import LibComm, sharded_preprocess_rccl
     dev = torch.device("cuda", 0)
-    d_bases, d_seg, n_reads, n_bases, _g = bench.make_reads_on_device(torch, dev, 5_000_000, 150, 150, 0xEC07)
-    assert n_reads == 5_000_000
+    d_bases, d_seg, n_reads, n_bases, _g = bench.make_reads_on_device(torch, dev, 5_000_000, 174, 150, 0xEC07)
+    assert n_reads == 5_800_000
     h = AssemblyHelper.new(31, False, 5, 20, 0, False, False, False, False)
     h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), n_reads, n_bases, n_reads)
     h.assemble()

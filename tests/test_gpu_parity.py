@@ -820,6 +820,42 @@ def test_long_reads_are_split_into_overlapping_segments():
         assert h.total_instances == 2 * (len(seq) - k + 1)
 
 
+@pytest.mark.parametrize("groups", [1, 3, 0])
+def test_reads_of_mixed_lengths_many_tiles_per_wave(groups, monkeypatch):
+    """Pass 1 gives every wave tiles of its own: 64 segments when they fit the wave's stage, fewer when they do not, a
+    segment of more than 2048 k-mers in pieces of 160 k-mers (a lane per piece) — and the first tile of the next round
+    travels in registers meanwhile.  Reads of 40 ... 9000 bases in random order, on one or three workgroups (SHK_PART_G)
+    so that every wave walks many rounds, through the FASTQ entry and the packed entry: the oracle's counts and contigs."""
+    import torch
+    from sparrowhawk_amd import pack_fastq
+    if groups:
+        monkeypatch.setenv("SHK_PART_G", str(groups))
+    rng = np.random.default_rng(4100 + groups)
+    g = synth.random_genome(30000, 77)
+    gs = synth.codes_to_str(g)
+    lens = [40, 75, 151, 151, 151, 250, 300, 300, 700, 1500, 2078, 2079, 2400, 5200, 9000]
+    recs = []
+    for i in range(2600):
+        L = int(lens[rng.integers(len(lens))])
+        a = int(rng.integers(0, len(gs) - L))
+        s = gs[a:a + L]
+        if rng.integers(2):
+            s = revcomp(s)
+        recs.append(f"@r{i}\n{s}\n+\n{'I' * L}\n")
+    fq = "".join(recs).encode()
+    for k in (31, 51):
+        o = run_oracle([fq], k=k, min_count=2)
+        compare_all(product(fq, k=k, min_count=2), o)
+        bases, seg, nb, nr = pack_fastq(fq, k, 20)
+        d_bases = torch.from_numpy(bases.view(np.int32)).cuda()
+        d_seg = torch.from_numpy(seg.view(np.int32)).cuda()
+        torch.cuda.synchronize()
+        h = AssemblyHelper.new(k, True, 2, 20, 0, False, False, False, False)
+        h.preprocess_packed_device(d_bases.data_ptr(), d_seg.data_ptr(), len(seg) - 1, nb, nr)
+        h.assemble()
+        compare_all(h, o)
+
+
 @pytest.mark.parametrize("P,genome", [(64, 3000), (1, 20000)])
 def test_counts_saturate_at_u32_max(P, genome):
     """SPEC S4: counts are u32 and saturate at 0xFFFFFFFF.  Forced through the shard layer's run tables: the
