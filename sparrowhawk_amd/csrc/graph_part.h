@@ -175,7 +175,7 @@ __device__ __forceinline__ uint32_t gp_table_size(uint32_t rows) {
     const uint32_t want = 2u * rows;
     return want <= 8u ? 8u : 1u << (32 - __clz((int)(want - 1u)));
 }
-__global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ gp_cnt, uint32_t GP,
+__global__ __launch_bounds__(1024) void k_gp_scan(uint32_t *__restrict__ gp_cnt /* read, then zeroed: k_gp_rows uses it as its cursors */, uint32_t GP,
                                                   unsigned long long *__restrict__ off, uint32_t *__restrict__ msk,
                                                   uint32_t *__restrict__ roff, unsigned long long *__restrict__ total) {
     // One workgroup on the critical path: what counts is the number of DEPENDENT memory round trips.  Chunks of
@@ -195,6 +195,11 @@ __global__ __launch_bounds__(1024) void k_gp_scan(const uint32_t *__restrict__ g
         for (uint32_t j = 0; j < PER; j++) {
             const uint32_t e = j * 1024u + threadIdx.x, p = c0 + e;
             lc[e + (e >> 4)] = p < GP ? gp_cnt[p] : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < PER; j++) {
+            const uint32_t p = c0 + j * 1024u + threadIdx.x;
+            if (p < GP) gp_cnt[p] = 0u;
         }
         __syncthreads();
         unsigned long long my = 0; uint32_t myr = 0;
@@ -406,6 +411,19 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
     }
     __syncthreads();
     if (in_lds && !KEYS_IN_LDS) for (uint32_t t = threadIdx.x; t <= pmask; t += blockDim.x) gtab[t] = tab[t];
+    // which slots are taken, a bit each (tables are 8 slots at least and start at multiples of 8: whole bytes, no atomics)
+    {
+        uint8_t *occ = gt.occ + (gt.off[P] >> 3);
+        for (uint32_t t8 = threadIdx.x; t8 <= (pmask >> 3); t8 += blockDim.x) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < 8; b++) {
+                const uint64_t e = in_lds ? tab[8u * t8 + b] : __hip_atomic_load(&gtab[8u * t8 + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bits |= (e != EMPTY64 ? 1u : 0u) << b;
+            }
+            occ[t8] = (uint8_t)bits;
+        }
+    }
     if (SHK_DBG(gt.dbg) == 1) { if (threadIdx.x == 0) qcnt[P] = 0; return; }     // timing experiment: table build only
     // ---- neighbours
     unsigned long long *myq = queries + 8ull * r0;
@@ -482,6 +500,10 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
 }
 
 // answers the cross-partition queries of partition blockIdx.x
+// Every query is a chain of four dependent memory round trips (the query, its node's key and the destination table's place,
+// the table entry, the key the entry names); a thread takes up to four queries at a time and moves them through the chain
+// together, so that a round trip is waited for once per four queries (round 4; one at a time: 177 us for the 4 M queries
+// of the bench isolate).
 template <int W>
 __global__ __launch_bounds__(256) void k_graph_remote(KeyArr<W> keys, int k, GraphTable gt,
                                                       const uint32_t *__restrict__ roff,
@@ -491,19 +513,68 @@ __global__ __launch_bounds__(256) void k_graph_remote(KeyArr<W> keys, int k, Gra
     const uint32_t P = blockIdx.x;
     const unsigned long long *myq = queries + 8ull * roff[P];
     const uint32_t nq = qcnt[P];
-    for (uint32_t t = threadIdx.x; t < nq; t += blockDim.x) {
-        const unsigned long long q = myq[t];
-        if (q >> 63) continue;                                  // a cross-rank query: answered by its owner (shard_graph.h)
-        const uint32_t i = (uint32_t)q, j = (uint32_t)(q >> 32) & 7u, p = (uint32_t)(q >> 35) & 0x1FFFFu;
-        const Kmer<W> x = keys.load(i);
-        const Kmer<W> rx = km_revcomp<W>(x, k);
-        bool o; const Kmer<W> c = adj_candidate<W>(x, rx, k, j, o);
-        const uint32_t idx = gt_lookup_in<W>(gt, keys, c, p);
-        if (idx == NIL) continue;
-        atomicOr((uint32_t *)adj + (i >> 2), (1u << j) << (8 * (i & 3u)));
-        const uint32_t u = j < 4 ? idx * 2u + (o ? 1u : 0u) : idx * 2u + (o ? 0u : 1u);
-        uint32_t *slot = nb + 2ull * i + (j < 4 ? 0 : 1);
-        if (atomicCAS(slot, NIL, u) != NIL) atomicExch(slot, NB_MULTI);     // second neighbour of this side
+    constexpr int U = W <= 2 ? 4 : (W <= 4 ? 2 : 1);       // (wide keys: the registers cost more than the round trips)
+    for (uint32_t t0 = threadIdx.x; t0 < nq; t0 += blockDim.x * U) {
+        unsigned long long q[U]; bool live[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t t = t0 + (uint32_t)u * blockDim.x;
+            q[u] = t < nq ? myq[t] : ~0ull;
+            live[u] = !(q[u] >> 63);                            // (bit 63: a cross-rank query, answered by its owner — shard_graph.h — or no query)
+        }
+        Kmer<W> x[U]; unsigned long long tbase[U]; uint32_t tmask[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t i = (uint32_t)q[u], p = (uint32_t)(q[u] >> 35) & 0x1FFFFu;
+            x[u] = live[u] ? keys.load(i) : km_zero<W>();
+            tbase[u] = live[u] ? gt.off[p] : 0ull;
+            tmask[u] = live[u] ? gt.msk[p] : 0u;
+        }
+        Kmer<W> c[U]; bool o[U]; uint32_t fp[U], slot[U]; uint64_t e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t j = (uint32_t)(q[u] >> 32) & 7u;
+            const Kmer<W> rx = km_revcomp<W>(x[u], k);
+            c[u] = adj_candidate<W>(x[u], rx, k, j, o[u]);
+            const uint64_t h = gt_hash<W>(c[u]);
+            fp[u] = (uint32_t)(h >> 32); slot[u] = (uint32_t)h & tmask[u];
+        }
+        bool taken[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const unsigned long long s = tbase[u] + slot[u];
+            taken[u] = live[u] && ((gt.occ[s >> 3] >> (s & 7u)) & 1u);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) e[u] = taken[u] ? gt.e[tbase[u] + slot[u]] : EMPTY64;
+        // first candidate entry of every query (the common end: an empty slot, or the one entry with the fingerprint)
+        Kmer<W> cand[U]; bool want[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            want[u] = e[u] != EMPTY64 && (uint32_t)(e[u] >> 32) == fp[u];
+            cand[u] = want[u] ? keys.load((uint32_t)e[u]) : km_zero<W>();
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!live[u]) continue;
+            uint32_t idx = NIL;
+            if (want[u] && km_eq<W>(cand[u], c[u])) idx = (uint32_t)e[u];
+            else if (e[u] != EMPTY64) {                         // (rare: walk on from the next slot)
+                uint32_t s = (slot[u] + 1u) & tmask[u];
+                for (uint32_t t = 1; t <= tmask[u]; t++) {
+                    const uint64_t ee = gt.e[tbase[u] + s];
+                    if (ee == EMPTY64) break;
+                    if ((uint32_t)(ee >> 32) == fp[u] && km_eq<W>(keys.load((uint32_t)ee), c[u])) { idx = (uint32_t)ee; break; }
+                    s = (s + 1u) & tmask[u];
+                }
+            }
+            if (idx == NIL) continue;
+            const uint32_t i = (uint32_t)q[u], j = (uint32_t)(q[u] >> 32) & 7u;
+            atomicOr((uint32_t *)adj + (i >> 2), (1u << j) << (8 * (i & 3u)));
+            const uint32_t v = j < 4 ? idx * 2u + (o[u] ? 1u : 0u) : idx * 2u + (o[u] ? 0u : 1u);
+            uint32_t *dst = nb + 2ull * i + (j < 4 ? 0 : 1);
+            if (atomicCAS(dst, NIL, v) != NIL) atomicExch(dst, NB_MULTI);     // second neighbour of this side
+        }
     }
 }
 

@@ -92,6 +92,8 @@ template <int W> struct CountTable {           // open addressing, linear probin
 // node into one 134 MB table (the flat version: 3.2 GB fetched for 5 M nodes, profiles/r01_s2_start).
 struct GraphTable {                            // entry = fingerprint<<32 | node index
     uint64_t *e;
+    uint8_t *occ;                              // one bit per slot of e[]: occupied (1.5 MB for 5 M nodes: it stays in every XCD's L2, and three of
+                                               // four cross-partition questions are about k-mers that do not exist — half of those end at an empty first slot)
     const unsigned long long *off;             // [GP] first slot of the partition's table
     const uint32_t *msk;                       // [GP] its size - 1 (power of two)
     uint32_t gp_mask;                          // GP - 1
@@ -371,6 +373,22 @@ static inline uint32_t env_dbg(const char *name) {
 #else
     (void)name; return 0u;
 #endif
+}
+
+// Two fills in one launch (a step of the pipeline made sixteen hipMemsetAsync calls, 5-6 us of the GPU each and most of them a
+// few dozen bytes): regions of whole 32-bit words.
+__global__ __launch_bounds__(256) void k_fill2(uint32_t *a, unsigned long long na, uint32_t va, uint32_t *b, unsigned long long nb, uint32_t vb) {
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < na + nb; i += stride) {
+        if (i < na) a[i] = va; else b[i - na] = vb;
+    }
+}
+static inline hipError_t fill2_async(void *a, size_t bytes_a, uint32_t va, void *b, size_t bytes_b, uint32_t vb, hipStream_t st) {
+    const unsigned long long na = bytes_a / 4, nb = bytes_b / 4;
+    const unsigned long long blocks = std::min<unsigned long long>((na + nb + 255) / 256, 2048ull);
+    if (!blocks) return hipSuccess;
+    hipLaunchKernelGGL(k_fill2, dim3((uint32_t)blocks), dim3(256), 0, st, (uint32_t *)a, na, va, (uint32_t *)b, nb, vb);
+    return hipGetLastError();
 }
 
 // ---- the contig text goes to the host by a KERNEL that writes pinned host memory slab by slab and raises a flag per slab
@@ -661,8 +679,7 @@ public:
             const uint64_t n_slices = (uint64_t)P * pp_.G;
             if (int rc = recs_.alloc(n_slices * cap * RW, err)) return rc;
             if (int rc = fill_.alloc(n_slices, err)) return rc;
-            HIPCHK(hipMemsetAsync(fill_.p, 0, n_slices * 4, stream_));
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
+            HIPCHK(fill2_async(fill_.p, n_slices * 4, 0u, ctl_.p, CTL_WORDS * sizeof(unsigned long long), 0u, stream_));
             EvTimer t(stream_);
             if (h_bases && attempt == 0) {
                 // ---- upload and pass 1, piece by piece
@@ -888,8 +905,7 @@ public:
             bloom_new = 0; bloom_kmer_bytes = 0; bloom_kmer_bytes_exact = 0;
             for (int j = 0; j < W; j++) if (int rc = keys[j].alloc(cap, err)) return rc;
             if (int rc = cnt.alloc(cap, err)) return rc;
-            HIPCHK(hipMemsetAsync(dh.p, 0, 500 * 8, stream_));
-            HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
+            HIPCHK(fill2_async(dh.p, 500 * 8, 0u, ctl_.p, CTL_WORDS * sizeof(unsigned long long), 0u, stream_));
             KeyArr<W> ok; for (int j = 0; j < W; j++) ok.w[j] = keys[j].p;
             const uint32_t probe_parts = (uint32_t)env_u64("SHK_PROBE_PARTS", 512);     // 0 = off
             const uint32_t n_probe = (repartition && probe_parts && n_parts / 4 >= probe_parts) ? probe_parts : 0u;
@@ -1404,7 +1420,7 @@ public:
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
         g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
-        g.gt.e = gt_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
+        g.gt.e = gt_.p; g.gt.occ = gt_occ_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
         g.n = (uint32_t)n_solid_;
         if (sh_active_) {                                   // sharded assembly: which rank owns a neighbour candidate
             g.gt.cp_mask = sh_P_ - 1u; g.gt.world = sh_world_; g.gt.rank = sh_rank_;
@@ -1432,6 +1448,7 @@ public:
         while (gp_ < 131072u && (uint64_t)gp_ * gp_rows_target < n_for_gp) gp_ <<= 1;
         gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
+        if (int rc = gt_occ_.alloc(gt_slots_ / 8 + 8, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
         if (int rc = gt_msk_.alloc(gp_, err)) return rc;
         DevBuf<uint32_t> gp_of, gp_cnt, gp_roff, gp_rows;
@@ -1446,10 +1463,9 @@ public:
         if (int rc = nb_.alloc(2 * n + 2, err)) return rc;
         if (int rc = alive_.alloc(n, err)) return rc;
         if (int rc = row_starts_.alloc(((n + 63) / 64) * 2 + 2, err)) return rc;
-        HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));   // (the mini tables are initialised by their builders)
-        // (no fills for adj_ and alive_: k_graph_local writes the adjacency byte of every row before k_graph_remote ORs
-        // into it, k_row_starts sets the alive flags)
-        HIPCHK(hipMemsetAsync(ctl_.p, 0, CTL_WORDS * sizeof(unsigned long long), stream_));
+        // (the mini tables are initialised by their builders; no fills for adj_ and alive_: k_graph_local writes the adjacency
+        // byte of every row before k_graph_remote ORs into it, k_row_starts sets the alive flags)
+        HIPCHK(fill2_async(gp_cnt.p, (size_t)gp_ * 4, 0u, ctl_.p, CTL_WORDS * sizeof(unsigned long long), 0u, stream_));
         // (sharded assembly: a rank that holds NO solid k-mer still owns partitions and is asked about neighbour candidates by
         // the others — its (empty) mini tables must exist: found by the 250-case campaign on 4 ranks, where such a rank answered
         // from tables nobody had built and took a memory fault)
@@ -1460,7 +1476,7 @@ public:
                                gp_of.p, gp_cnt.p);
             hipLaunchKernelGGL(k_gp_scan, dim3(1), dim3(1024), 0, stream_, gp_cnt.p, gp_, gt_off_.p, gt_msk_.p, gp_roff.p,
                                ctl_.p + 2);
-            HIPCHK(hipMemsetAsync(gp_cnt.p, 0, (size_t)gp_ * 4, stream_));          // reused as the row-list cursors
+            // (gp_cnt is reused as the row-list cursors: k_gp_scan left it zeroed)
             hipLaunchKernelGGL(k_gp_rows, dim3(grid_for(n)), dim3(256), 0, stream_, gp_of.p, (uint32_t)n, gp_roff.p, gp_cnt.p,
                                gp_rows.p);
             HIPCHK(hipGetLastError());
@@ -1713,8 +1729,8 @@ public:
             if (int rc = cs.d_heads.alloc(seg_cap, err)) return rc;
             if (int rc = cs.ringmin.alloc(seg_cap, err)) return rc;
             const unsigned long long *skip = corr_pending_ ? ctl_.p + 16 : (const unsigned long long *)nullptr;
-            HIPCHK(hipMemsetAsync(ctl_.p + 5, 0, 6 * 8, stream_));          // 5 splitters, 6 chains, 7 ring splitters, 8 flags, 9 alive oriented nodes, 10 nodes walked
-            HIPCHK(hipMemsetAsync(cs.slot_of.p, 0xFF, (size_t)seg_cap * 4, stream_));
+            // 5 splitters, 6 chains, 7 ring splitters, 8 flags, 9 alive oriented nodes, 10 nodes walked
+            HIPCHK(fill2_async(ctl_.p + 5, 6 * 8, 0u, cs.slot_of.p, (size_t)seg_cap * 4, 0xFFFFFFFFu, stream_));
             unsigned int *d_nspl = (unsigned int *)(ctl_.p + 5);
             uint32_t *d_flags = (uint32_t *)(ctl_.p + 8);
             hipLaunchKernelGGL(k_succ_split<W>, dim3((total + 256 * SS_ITEMS - 1) / (256 * SS_ITEMS)), dim3(256), 0, stream_, g,
@@ -2605,7 +2621,7 @@ private:
     bool rows_scattered_ = false;                    // most rows came out of the k-mer-level repartition (run_count_partitions)
     // solid set / graph
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
-    DevBuf<uint64_t> gt_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
+    DevBuf<uint64_t> gt_; DevBuf<uint8_t> gt_occ_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
     DevBuf<unsigned long long> gt_off_; DevBuf<uint32_t> gt_msk_;
     DevBuf<uint8_t> adj_, adj0_, alive_;
     DevBuf<uint32_t> row_starts_;                    // one bit per solid row: a group of rows of one minimiser partition starts here (k_row_starts)
