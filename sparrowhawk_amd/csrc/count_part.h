@@ -235,6 +235,11 @@ __device__ __forceinline__ uint32_t wave_flush(SHK_LDS PartSharedT<RW> *sh_l, ui
                     for (int o = 0; o < RW; o++) r[o] = ((uint64_t)off << 20) | n1;
                 } else part_build_record<RW>(sh->stage + wave * WSTAGE, dbg == 6 ? sh->rmask : sh->rmask + n1 * (2 * RW), off, n1, k, r);
                 const uint32_t slice = p * G + g;                            // (P * G <= 2^22)
+                if (dbg == 7) {                                              // (timing experiment: every record twice, side by side — twice the requests, the same lines)
+                    const uint32_t i2 = min(2u * idx, slice_cap - 2u);
+                    part_store_record<RW>(r, recs + ((uint64_t)slice * slice_cap + i2) * RW);
+                    part_store_record<RW>(r, recs + ((uint64_t)slice * slice_cap + i2 + 1u) * RW);
+                } else
                 if (dbg != 5) part_store_record<RW>(r, recs + ((uint64_t)slice * slice_cap + (dbg == 1 ? 0u : idx)) * RW);
                 else if (r[0] == 0x1234567ull) recs[0] = r[1];               // (keeps the record alive)
             }

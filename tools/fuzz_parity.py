@@ -29,8 +29,8 @@ for case in range(n_cases):
     if rng.random() < 0.2:                                   # inverted repeat / hairpin material
         L = min(int(rng.integers(k, 3 * k)), glen - 1); src = int(rng.integers(0, glen - L)); dst = int(rng.integers(0, glen - L))
         g[dst:dst + L] = (3 - g[src:src + L])[::-1]
-    rl = int(rng.choice([max(k + 3, 60), 100, 150, 250, k + 120]))
-    rl = max(rl, k + 1)
+    rl = int(rng.choice([max(k + 3, 60), 100, 150, 250, k + 120, 300, 700, 2300, 5500]))   # (round 4, >= 300: several tiles per round of pass 1, segments walked in pieces)
+    rl = max(min(rl, glen - 1), k + 1)
     cov = float(rng.choice([3, 8, 20, 40]))
     err = float(rng.choice([0.0, 0.002, 0.01, 0.03]))
     circular = bool(rng.random() < 0.3)
@@ -84,6 +84,8 @@ for case in range(n_cases):
     if rng.random() < 0.25: env["SHK_SEG_CAP"] = str(int(rng.choice([1, 8, 64])))   # round 4: the splitter list outgrows its room -> the ranking is called off and repeated
     if rng.random() < 0.3: env["SHK_DEVICE_PLAN"] = "1"            # round 4: emission planned on the device for <= 512 chain records (default: on the host)
     if rng.random() < 0.25: env["SHK_ARRIVAL_MIN"] = "1"           # round 4: the writer starts on contig text that is still arriving (slab-copy kernel + host flags)
+    if rng.random() < 0.4: env["SHK_PART_G"] = str(int(rng.choice([1, 2, 5])))   # round 4: few workgroups -> every wave of pass 1 walks many tiles (prefetch of the next round)
+    if rng.random() < 0.3: env["SHK_PART_WIN"] = str(int(rng.choice([16, 18, 20])))   # round 4: minimiser window of pass 1 for k >= 31 (one block of 16, two of 9, two of 10)
     if rng.random() < 0.3: env["SHK_GUNZIP_DEVICE_MIN"] = "2048"   # round 4: gzip members go to the device inflater first (it declines most of these tiny ones)
     old = {e: os.environ.get(e) for e in env}
     os.environ.update(env)
