@@ -46,6 +46,7 @@ struct PartParams {
     int k, m;
     uint32_t max_n;
     uint32_t dbg_nostore;        // timing experiments only (SHK_DEBUG_NOSTORE): 1 = every record to slot 0 of its slice, 2 = no flush
+    uint32_t dbg_flush_at;       // timing experiments only (SHK_DEBUG_P1FLUSH, ABLATE builds): descriptors a lane may hold before its wave flushes
     unsigned long long *dbg_clk; // timing experiments only (SHK_DEBUG_P1CLK, ABLATE builds): wave-cycles per phase of k_partition, summed over the waves
 };
 
@@ -429,7 +430,8 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             uint32_t fpos = rel;                             // where this lane's first unflushed run starts
             // the waves of one SIMD flush at different fill levels: a flush is a chain of LDS round trips,
             // it overlaps with the VALU-bound walk of the others only if they do not all flush together
-            SHK_LDS uint32_t *const flush_at = dbase + 64u * (LDESC_CAP - DESC_CHECK - (wave >> 2));
+            SHK_LDS uint32_t *const flush_at = dbase + 64u * (SHK_DBG(pp.dbg_flush_at) ? min(SHK_DBG(pp.dbg_flush_at), LDESC_CAP - DESC_CHECK) - min(wave >> 2, SHK_DBG(pp.dbg_flush_at) - 1u)
+                                                                                          : LDESC_CAP - DESC_CHECK - (wave >> 2));
             auto flush = [&]() {
                 SHK_CLK(const unsigned long long f0 = __builtin_amdgcn_s_memtime();)
                 fpos = wave_flush<RW>((SHK_LDS PartSharedT<RW> *)&sh, wave, ((uint32_t)(uintptr_t)dptr - (uint32_t)(uintptr_t)dbase) >> 8, fpos, k, pp.G, pp.slice_cap, g,

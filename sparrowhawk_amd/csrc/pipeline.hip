@@ -637,7 +637,7 @@ public:
         const int cus = n_cus_;
         const uint64_t n_super = (n_seg + PART_THREADS - 1) / PART_THREADS;
         pp_.k = k_; pp_.m = k_ - wblk + 1; pp_.dbg_nostore = env_dbg("SHK_DEBUG_NOSTORE");
-        pp_.dbg_clk = nullptr;
+        pp_.dbg_clk = nullptr; pp_.dbg_flush_at = env_dbg("SHK_DEBUG_P1FLUSH");
 #if SHK_ABLATE
         if (env_dbg("SHK_DEBUG_P1CLK")) {                   // (timing experiment: the buffer is leaked on purpose, the report goes to stderr)
             static unsigned long long *clk = nullptr;
