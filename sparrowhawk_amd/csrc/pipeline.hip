@@ -929,7 +929,10 @@ public:
                 const uint32_t per_cu = 2u;
                 // (groups of `merge` partitions share a table; a group is only worth it when the chip still gets >= 2 groups per workgroup)
                 // (1, 2 or 4, and the groups' stride a multiple of 256: the members of a group share the low bits of their number)
-                uint32_t merge = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_COUNT_MERGE", 2), 1), 4);
+                // Default ONE partition per table since the window of pass 1 grew (round 4): measured alternating on the bench isolate,
+                // pass 2 0.642 against 0.662 ms with two per table, and the assembly behind it 1.46 against 1.55 ms — rows that come
+                // out in pure partition groups suit the graph tables and the collapse's tiles (k = 51 masked: 1.03 against 1.05 ms).
+                uint32_t merge = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(env_u64("SHK_COUNT_MERGE", 1), 1), 4);
                 if (merge == 3) merge = 2;
                 while (merge > 1 && (n_parts % merge != 0 || (n_parts / merge) % 256u != 0 || n_parts / merge < 2u * per_cu * (uint32_t)n_cus_)) merge >>= 1;
                 const uint32_t n_groups = (n_parts + merge - 1) / merge;
