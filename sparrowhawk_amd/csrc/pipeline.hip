@@ -1319,7 +1319,9 @@ public:
         HIPCHK(hipMemcpyAsync(dd_base_.p, base.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
         HIPCHK(hipMemsetAsync(ctl_.p + 12, 0, 8, stream_));
         EvTimer t(stream_, stage_timers_);
-        hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
+        // (two workgroups per CU where the kernel's registers allow it, as on one GPU: with one, 588 us against 418 for the
+        // bench isolate — found in the timeline of the one-rank leg, profiles/r04_final/sharded_one_rank_timeline.txt)
+        hipLaunchKernelGGL(k_dedupe_partitions<W>, dim3(std::min<uint32_t>(pp_.P, (W <= 2 ? 2u : 1u) * (uint32_t)n_cus_)), dim3(COUNT_THREADS), 0, stream_,
                            run_view_, 0u, pp_.P, dd_base_.p, dd_recs_.p, dd_w_.p, dd_n_.p, (uint32_t *)(ctl_.p + 12),
                            (OvfRec *)nullptr, (uint32_t *)nullptr, 0u, 0u, (uint32_t *)nullptr);
         HIPCHK(hipGetLastError());
@@ -1382,8 +1384,13 @@ public:
         n_emitted_ = 0; emit_threshold_ = emit_threshold; n_distinct_ = 0;
         double ms = 0; uint64_t inst = 0;
         have_parts_ = n_runs != 0;
+        // Room for the rows: raw records are at least as many as the k-mers they bring, DEDUPLICATED ones are not — the bench
+        // isolate's 4.88 M distinct records hold 5.0 M distinct k-mers, so a hint of one row per record made every sharded
+        // step count twice (0.46 ms each: the second attempt knows the exact number).  Weights travel only when the records
+        // repeat a lot (at most half of the raw ones are distinct), i.e. at coverages where rows per record stay near one.
+        const uint64_t rows_hint = d_recv_w ? 2 * total_recs + (1u << 16) : std::max<uint64_t>(1u << 16, total_recs);
         if (int rc = run_count_partitions(run_view_, n_owned, emit_threshold, ekeys_, ecnt_, n_emitted_, histo, inst,
-                                          std::max<uint64_t>(1u << 16, total_recs), ms, err)) return rc;
+                                          rows_hint, ms, err)) return rc;
         times_.add("count_kernel", ms);
         total_instances_ = inst;
         for (int i = 0; i < 500; i++) { histo_[i] = histo[i]; n_distinct_ += histo[i]; }
