@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void k_rank_init(const SegRec *__restrict__ se
 // one launch follows HOPS pointers (the reach grows HOPS-fold per launch instead of doubling: a launch
 // over ~300 k splitters is all latency, so ceil(log4 n) launches of four dependent reads beat
 // ceil(log2 n) launches of two); heads point to themselves with A = K = 0, so overshooting adds nothing
-static constexpr int RANK_HOPS = 4;
+static constexpr int RANK_HOPS = 8;                   // hops per launch (round 4: 4 -> 8, ten launches of 9 us became seven of 10 for the bench isolate)
 __global__ __launch_bounds__(256) void k_rank_jump(const unsigned int *__restrict__ n_spl_p,
                                                    const RankRec *__restrict__ Ri, RankRec *__restrict__ Ro, uint32_t round = 0) {
     const uint32_t n_spl = *n_spl_p;

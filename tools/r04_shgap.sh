@@ -3,7 +3,7 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?}"
 OUT=$PWD/gpurun_out/${1:-r04shgap}; mkdir -p "$OUT"; export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python bench.py --force-sharded --steps 6 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/trace.log" 2>&1 || tail -5 "$OUT/trace.log"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace" -o t -- python bench.py ${BENCH_ARGS:---force-sharded} --steps 6 --warmup 2 --no-cpu-baseline --no-host-leg --no-legs --no-inflight-leg > "$OUT/trace.log" 2>&1 || tail -5 "$OUT/trace.log"
 F=$(find "$OUT/trace" -name "*kernel_trace.csv" | head -1)
 python3 - "$F" <<'PY'
 import csv, sys
