@@ -375,10 +375,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             }
             // ---- behind the round's first tile: the first tile of the next round into the registers, the offsets of the
             // round after it on their way
+            // (one-word keys only: with wider records the flush needs the twelve registers — kept across the walk they were
+            // spilled, and the spill traffic shared the memory pipeline with the record stores: k = 51 with its errors left in
+            // took 1.54 ms where the shared-tile kernel had taken 1.18)
             if (first_tile) {
                 prefetched = false;
                 if (T + 2u * n_waves < n_super) load_seg(T + 2u * n_waves, s0nn, s1nn);       // (used a whole round from now)
-                if (T + n_waves < n_super) {
+                if (W == 1 && T + n_waves < n_super) {
                     pl_pf = plan(s0n, s1n, 0u);
                     if (pl_pf.end > 0u) {
                         prefetched = true;
