@@ -970,6 +970,9 @@ public:
                 items.reserve(n_ovf);
                 std::vector<uint32_t> bad;
                 uint32_t n_untried = 0;
+                // (read once: inside the loop these were 2 x 16384 walks through the environment — with k_ovf_scatter's launch
+                // 0.55 ms behind the read-back on configs[2] with its errors left in, profiles/r04_final/errors_left_in_timeline.txt)
+                const unsigned long long fill_pct = env_u64("SHK_OVF_FILL_PCT", 110), cap_pct = env_u64("SHK_OVF_CAP_PCT", bloom ? 100 : 150);
                 for (uint32_t i = 0; i < n_ovf; i++) {
                     // A partition of >= 2^32 instances may hold a k-mer whose count saturates (SPEC S4).  The bucket path
                     // counts without the saturating add and keeps 32-bit bucket cursors: such a giant is re-run by residue
@@ -982,12 +985,12 @@ public:
                     // too many distinct k-mers only costs itself a second pass over its own k-mer list
                     // (about half of an error-rich bucket's k-mers are distinct: a table at ~45 % keeps the linear
                     // probe chains far below the 48-probe limit; at 60 % one bucket in a few hit it and re-ran by residue classes)
-                    const unsigned long long per = (unsigned long long)S * env_u64("SHK_OVF_FILL_PCT", 110) / 100;
+                    const unsigned long long per = (unsigned long long)S * fill_pct / 100;
                     const uint32_t F = (uint32_t)std::min<unsigned long long>(std::max<unsigned long long>((ov[i].instances + per - 1) / per, 2ull), OVF_MAX_F);
                     if (ov[i].est_distinct == 0) n_untried++;
                     // (Bloom mode: at least one sighting per distinct k-mer never reaches the buckets — error-rich
                     // partitions are mostly singletons — so the regions start at the instance count, not 1.5 x it)
-                    const unsigned long long capb = ov[i].instances * env_u64("SHK_OVF_CAP_PCT", bloom ? 100 : 150) / (100ull * F) + 256;   // 50 % slack
+                    const unsigned long long capb = ov[i].instances * cap_pct / (100ull * F) + 256;   // 50 % slack
                     item.p = ov[i].p; item.F = F; item.cap = (uint32_t)std::min<unsigned long long>(capb, 0xFFFFFFF0ull);
                     item.pad = 0; item.base = 0;
                 }
