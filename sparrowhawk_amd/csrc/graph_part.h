@@ -155,7 +155,15 @@ __global__ __launch_bounds__(256) void k_gp_count(KeyArr<W> keys, uint32_t n, in
     const uint32_t n_round = (n + stride - 1) / stride * stride;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += stride) {
         uint32_t p = 0xFFFFFFFFu;
-        if (i < n) { p = km_min_scan_lut<W>(keys.load(i), k, gt.gm, lut, all_a).min_all() & gt.gp_mask; gp_of[i] = p; }
+        if (i < n) {
+            const MinScan ms = km_min_scan_lut<W>(keys.load(i), k, gt.gm, lut, all_a);
+            p = ms.min_all() & gt.gp_mask; gp_of[i] = p;
+            if (gt.scan) {                                      // kept for k_graph_local
+                gt.scan[i] = make_uint2(ms.first.fh, ms.first.rh);
+                gt.scan[(size_t)gt.scan_n + i] = make_uint2(ms.last.fh, ms.last.rh);
+                gt.scan[2 * (size_t)gt.scan_n + i] = make_uint2(ms.min_wo_first, ms.min_wo_last);
+            }
+        }
         unsigned long long todo = __ballot(p != 0xFFFFFFFFu);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
@@ -439,6 +447,11 @@ __global__ __launch_bounds__(256) void k_graph_local(KeyArr<W> keys, int k, Grap
         if (act) {
             x = keep ? kept_key(q) : keys.load(i);
             rx = km_revcomp<W>(x, k);                              // rc(x+b) = (3-b) + rc(x)[..k-1): one revcomp per node
+            if (gt.scan) {                                         // the scan k_gp_count made (three 8-byte loads)
+                const uint2 a = gt.scan[i], b = gt.scan[(size_t)gt.scan_n + i], c = gt.scan[2 * (size_t)gt.scan_n + i];
+                ms.first.fh = a.x; ms.first.rh = a.y; ms.last.fh = b.x; ms.last.rh = b.y; ms.min_wo_first = c.x; ms.min_wo_last = c.y;
+                ms.h_first = min(a.x, a.y); ms.h_last = min(b.x, b.y);
+            } else
             if (SHK_DBG(gt.dbg) != 2) ms = km_min_scan_lut<W>(x, k, gt.gm, lut, all_a);      // (2: timing experiment without the scan)
             out_b = km_base<W>(x, k, k - (int)gm);                 // first base of the last gm-mer
             last_b = km_base<W>(x, k, (int)gm - 1);                // last base of the first gm-mer

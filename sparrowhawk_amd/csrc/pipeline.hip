@@ -92,6 +92,8 @@ template <int W> struct CountTable {           // open addressing, linear probin
 // node into one 134 MB table (the flat version: 3.2 GB fetched for 5 M nodes, profiles/r01_s2_start).
 struct GraphTable {                            // entry = fingerprint<<32 | node index
     uint64_t *e;
+    uint2 *scan = nullptr;                     // [3][scan_n]: every node's minimiser scan as k_gp_count made it (hash states of its first and last gm-mer,
+    uint32_t scan_n = 0;                       // the minima without the first / without the last) — k_graph_local reads 24 bytes instead of repeating k + 1 hash steps
     uint8_t *occ;                              // one bit per slot of e[]: occupied (1.5 MB for 5 M nodes: it stays in every XCD's L2, and three of
                                                // four cross-partition questions are about k-mers that do not exist — half of those end at an empty first slot)
     const unsigned long long *off;             // [GP] first slot of the partition's table
@@ -1433,7 +1435,7 @@ public:
         Graph<W> g;
         for (int j = 0; j < W; j++) g.keys.w[j] = skeys_[j].p;
         g.cnt = scnt_.p; g.adj = adj_.p; g.nb = nb_.p; g.k = k_;
-        g.gt.e = gt_.p; g.gt.occ = gt_occ_.p; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
+        g.gt.e = gt_.p; g.gt.occ = gt_occ_.p; g.gt.scan = gt_scan_.p; g.gt.scan_n = gt_scan_.p ? (uint32_t)n_solid_ : 0u; g.gt.off = gt_off_.p; g.gt.msk = gt_msk_.p; g.gt.gp_mask = gp_ - 1u; g.gt.gm = part_m(k_); g.gt.dbg = env_dbg("SHK_DEBUG_G");
         g.n = (uint32_t)n_solid_;
         if (sh_active_) {                                   // sharded assembly: which rank owns a neighbour candidate
             g.gt.cp_mask = sh_P_ - 1u; g.gt.world = sh_world_; g.gt.rank = sh_rank_;
@@ -1462,6 +1464,10 @@ public:
         gt_slots_ = 4 * n + 8ull * gp_;               // >= sum of max(8, pow2 >= 2 x rows)
         if (int rc = gt_.alloc(gt_slots_, err)) return rc;
         if (int rc = gt_occ_.alloc(gt_slots_ / 8 + 8, err)) return rc;
+        // the nodes' minimiser scans, kept from k_gp_count for k_graph_local (24 B per node; not for graphs beyond 64 M nodes,
+        // and dropped when the rows are regrouped in between: k_graph_local then repeats the scan as before)
+        gt_scan_.release();
+        if (n && n <= (64ull << 20) && env_u64("SHK_KEEP_SCAN", 1)) if (int rc = gt_scan_.alloc(3 * n, err)) return rc;
         if (int rc = gt_off_.alloc(gp_, err)) return rc;
         if (int rc = gt_msk_.alloc(gp_, err)) return rc;
         DevBuf<uint32_t> gp_of, gp_cnt, gp_roff, gp_rows;
@@ -1509,6 +1515,7 @@ public:
                 WAIT_STREAM();                          // (the old arrays go back to the pool below)
                 for (int j = 0; j < W; j++) skeys_[j].swap(nk[j]);
                 scnt_.swap(nc); gp_of.swap(ngp);
+                gt_scan_.release();                     // (indexed by the old row numbers)
                 g = graph_view();
                 times_.add("graph_rows_regrouped_x1", 1.0);
             }
@@ -2634,7 +2641,7 @@ private:
     bool rows_scattered_ = false;                    // most rows came out of the k-mer-level repartition (run_count_partitions)
     // solid set / graph
     DevBuf<uint64_t> skeys_[W]; DevBuf<uint32_t> scnt_;
-    DevBuf<uint64_t> gt_; DevBuf<uint8_t> gt_occ_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
+    DevBuf<uint64_t> gt_; DevBuf<uint8_t> gt_occ_; DevBuf<uint2> gt_scan_; uint64_t gt_slots_ = 0; uint32_t gp_ = 64;
     DevBuf<unsigned long long> gt_off_; DevBuf<uint32_t> gt_msk_;
     DevBuf<uint8_t> adj_, adj0_, alive_;
     DevBuf<uint32_t> row_starts_;                    // one bit per solid row: a group of rows of one minimiser partition starts here (k_row_starts)
