@@ -385,6 +385,12 @@ __global__ __launch_bounds__(256) void k_fill2(uint32_t *a, unsigned long long n
         if (i < na) a[i] = va; else b[i - na] = vb;
     }
 }
+// out[i] = i * stride (the places of the partitions' deduplicated records when one batch sits in its slices: a launch instead of
+// a copy from pageable host memory, which the runtime only starts once the stream has drained — the host then fell behind
+// pass 1 and the launches after it reached the GPU one by one, 36 us of idle time behind k_partition)
+__global__ __launch_bounds__(256) void k_stride_fill(unsigned long long *out, uint32_t n, unsigned long long stride) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (unsigned long long)i * stride;
+}
 static inline hipError_t fill2_async(void *a, size_t bytes_a, uint32_t va, void *b, size_t bytes_b, uint32_t vb, hipStream_t st) {
     const unsigned long long na = bytes_a / 4, nb = bytes_b / 4;
     const unsigned long long blocks = std::min<unsigned long long>((na + nb + 255) / 256, 2048ull);
@@ -918,7 +924,10 @@ public:
                 if (int rc = dd_n_.alloc(n_parts, err)) return rc;
                 if (int rc = dd_recs_.alloc(split_total_ * 2 * W + 2, err)) return rc;
                 if (int rc = dd_w_.alloc(split_total_ + 2, err)) return rc;
-                HIPCHK(hipMemcpyAsync(dd_base_.p, split_base_.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_));
+                if (split_stride_) {
+                    hipLaunchKernelGGL(k_stride_fill, dim3((n_parts + 255) / 256), dim3(256), 0, stream_, dd_base_.p, n_parts, split_stride_);
+                    HIPCHK(hipGetLastError());
+                } else HIPCHK(hipMemcpyAsync(dd_base_.p, split_base_.data(), (size_t)n_parts * 8, hipMemcpyHostToDevice, stream_));
                 // (no sample launch in front: the partitions the dedupe tries are the sample, and its verdict is where the counting
                 // kernel's own tally starts — count_part.h)
                 const uint32_t defer_after = n_probe / 8;
@@ -1115,8 +1124,9 @@ public:
                 double ms = 0; uint64_t inst = 0;
                 // where k_dedupe_partitions may put the distinct records of partition p (two-kernel pass 2): at the place
                 // of p's own raw records — the slice region of p, or the sum of the batches' shares
-                split_base_.assign(n_count_parts_, 0); split_total_ = 0;
+                split_base_.assign(n_count_parts_, 0); split_total_ = 0; split_stride_ = 0;
                 if (batches_.empty()) {
+                    split_stride_ = (unsigned long long)pp_.G * pp_.slice_cap;
                     for (uint32_t p = 0; p < n_count_parts_; p++) split_base_[p] = (unsigned long long)p * pp_.G * pp_.slice_cap;
                     split_total_ = (unsigned long long)n_count_parts_ * pp_.G * pp_.slice_cap;
                 } else {
@@ -2628,7 +2638,7 @@ private:
     bool have_parts_ = false;
     bool have_dedup_ = false;                        // shard_dedupe ran: dd_* hold the distinct records of every partition
     bool split_ready_ = false;                       // histogram() prepared split_base_ / split_total_ for the two-kernel pass 2
-    std::vector<unsigned long long> split_base_; unsigned long long split_total_ = 0;
+    std::vector<unsigned long long> split_base_; unsigned long long split_total_ = 0, split_stride_ = 0;      // (split_stride_ != 0: split_base_[p] = p * split_stride_)
     DevBuf<uint64_t> dd_recs_; DevBuf<uint32_t> dd_w_, dd_n_; DevBuf<unsigned long long> dd_base_;
     PartParams pp_{};
     DevBuf<uint64_t> recs_; DevBuf<uint32_t> fill_;
