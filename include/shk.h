@@ -76,7 +76,9 @@ int shk_finish_reads(shk_handle *h);
  *   d_bases   : uint32 words, base i of the stream in bits [2*(i%16), 2*(i%16)+1] of word i/16;
  *               at least ceil(n_bases/16)+1 words allocated
  *   d_seg_off : uint32[n_seg+1], base offset of each segment in the stream (ascending,
- *               d_seg_off[n_seg] == n_bases); every segment is >= k bases
+ *               d_seg_off[n_seg] == n_bases); every segment is >= k bases and of any length (a segment of more
+ *               than 2048 k-mers is walked in pieces by the counting pass; before round 4 segments beyond 163840
+ *               bases were refused)
  * Both are HIP device pointers on the handle's device; they are read, not retained.
  * n_reads is only used for progress/statistics. */
 int shk_preprocess_packed_device(shk_handle *h, const void *d_bases, const void *d_seg_off,
