@@ -11,7 +11,7 @@
 //           k_ovf_scatter / k_count_buckets   partitions whose distinct k-mers exceed the LDS table
 //                               (error-rich reads): split once more by k-mer hash, counted per bucket
 //
-// Minimiser = the m-mer (m = k - WBLK + 1) of a k-mer with the smallest canonical ntHash
+// Minimiser = the m-mer (m = k - w + 1, w = 8, 16 or 18 m-mers per k-mer) of a k-mer with the smallest canonical ntHash
 // (SPEC S3); partition = low bits of that hash.  Both strands of a k-mer share it, so every
 // instance of a canonical k-mer lands in one partition.  A record is a run of consecutive
 // k-mers of one read segment with the same partition: (n + k - 1) bases, 2-bit, little-endian,
@@ -38,8 +38,6 @@ namespace shk {
 static constexpr int PART_THREADS = 1024;            // pass 1: 4 waves per SIMD
 static constexpr int COUNT_THREADS = 1024;           // pass 2: 4 waves per SIMD hide the LDS latency
 static constexpr int PART_MAX_P = 16384;             // LDS cursors: 64 KB
-static constexpr int STAGE_WORDS = 10240;            // 163840 bases of a read tile in LDS
-static constexpr uint32_t MAX_SEG_BASES = 32768;     // host splits longer segments (overlap k-1)
 
 struct PartParams {
     uint32_t P, G, slice_cap;
@@ -60,8 +58,9 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 }
 
 // ---- pass 1 -------------------------------------------------------------------------------
-// One 1024-thread workgroup per CU, one lane per read segment.  A tile of segments is staged in LDS
-// by coalesced dword loads; every lane then walks its segment base by base: rolling canonical
+// One 1024-thread workgroup per CU, one lane per read segment.  Every WAVE stages a tile of 64 segments
+// of its own in LDS (coalesced dword loads; round 4 — the tile loop in k_partition says why); every lane
+// then walks its segment base by base: rolling canonical
 // ntHash (32-bit state, kmer.h) of the m-mers, sliding-window minimum in registers, run detection.
 // Finished runs go to a LANE-PRIVATE descriptor list in LDS (slot i of lane l at [i][l]: conflict
 // free, no ballot, no atomics); a wave turns its descriptors into records by itself whenever a lane's
@@ -77,8 +76,8 @@ __device__ __forceinline__ uint64_t sel4(uint32_t b, uint64_t t0, uint64_t t1, u
 // The window of a k-mer is NBLK blocks of WBLK m-mers (m = k - NBLK*WBLK + 1).  With one block the
 // minimum of the window is min(suffix of the block before, prefix of this block); with two it is
 // min3(suffix of the block before the last, the whole last block, prefix of this block) — the same
-// instruction count per base, a window of 20 m-mers instead of 16, runs of 10.5 k-mers on average
-// instead of 8.5: a fifth fewer records to build, store and fetch again.
+// instruction count per base; k = 31 uses two blocks of 9 (18 m-mers instead of 16: runs of 9.7 k-mers
+// on average instead of 8.3, a seventh fewer records to build, store and fetch again).
 static constexpr int PART_WAVES = PART_THREADS / 64;
 static constexpr uint32_t LDESC_CAP = 12;            // descriptors per lane
 static constexpr int STAGE_PF = 12;                  // prefetch registers per lane: ceil(WSTAGE / 64)
