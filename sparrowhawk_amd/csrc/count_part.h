@@ -319,13 +319,13 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
     struct Plan { uint32_t end, w0, nwords; };
     auto plan = [&](uint32_t s0, uint32_t s1, uint32_t start) -> Plan {
         const uint32_t Ls = s1 - s0;
-        const uint32_t w0 = __builtin_amdgcn_readlane(s0, start) >> 4;
+        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)s0, start) >> 4;     // (the builtin is typed int: beyond 2^31 bases an arithmetic shift put w0 out of range, nothing "fitted" and every segment was walked alone, in pieces — correct and 20 x slower: configs[4]'s share)
         const bool is_long = Ls >= (uint32_t)k + LONG_NK;
         const bool fits = ((s1 + 15u) >> 4) - w0 <= WSTAGE - 1u;
         const unsigned long long stop = __ballot((uint32_t)lane >= start && (is_long || !fits));
         const uint32_t end = stop ? (uint32_t)__builtin_ctzll(stop) : 64u;
         Plan pl; pl.end = end; pl.w0 = w0;
-        pl.nwords = end > start ? ((__builtin_amdgcn_readlane(s1, end - 1u) + 15u) >> 4) - w0 : 0u;
+        pl.nwords = end > start ? (((uint32_t)__builtin_amdgcn_readlane((int)s1, end - 1u) + 15u) >> 4) - w0 : 0u;
         return pl;
     };
     uint32_t T = g * PART_WAVES + wave;                        // this wave's round
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(PART_THREADS) void k_partition(const uint32_t *__re
             if (pl.end > start) {
                 if ((uint32_t)lane >= start && (uint32_t)lane < pl.end) { L = s1c - s0c; rel = s0c - (w0 << 4); }
             } else {                                           // pieces 64 round .. 64 round + 63 of segment `start`
-                const uint32_t a0 = __builtin_amdgcn_readlane(s0c, start), a1 = __builtin_amdgcn_readlane(s1c, start);
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_readlane((int)s0c, start), a1 = (uint32_t)__builtin_amdgcn_readlane((int)s1c, start);
                 const uint32_t nk = a1 - a0 - (uint32_t)k + 1u;
                 const uint32_t k0 = 64u * PIECE_K * round;             // first k-mer of this round
                 const uint32_t kend = min(k0 + 64u * PIECE_K, nk);

@@ -277,6 +277,9 @@ def test_config4_metagenome_share_of_one_gpu(torch_dev):
     check_sampled_counts(torch, d, h, k, pos)
     asm = h.get_assembly()
     print("config4 share timings:", {kk: round(v, 2) for kk, v in h.timings().items()})
+    # base offsets beyond 2^31 (3.75 G bases here): pass 1 once took 82 ms instead of 7 — an int-typed readlane made every tile
+    # "not fit" and every read was walked alone, correct and twenty times slower; nothing but a clock shows that
+    assert h.timings()["partition_kernel"] < 25.0, h.timings()["partition_kernel"]
     cs = contigs_of_json(asm)
     n_nodes = sum(len(c) - k + 1 for c in cs)
     assert 0 < n_nodes <= h.n_solid                                            # correction only ever removes nodes
