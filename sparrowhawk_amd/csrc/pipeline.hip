@@ -1637,7 +1637,7 @@ public:
         const dim3 G(1024), B(256);
         const bool tips = corr_tips_, bubbles = corr_bubbles_;
         const int s_tip = round == 0 ? 16 : 5, s_bub = round == 0 ? 17 : 6;
-        HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 4 * 8, stream_));
+        HIPCHK(fill2_async(ctl_.p + 3, 4 * 8, 0u, nullptr, 0, 0u, stream_));      // (one launch: a small hipMemsetAsync at an odd offset came out as three fill kernels)
         if (tips) {
             hipLaunchKernelGGL(k_tip_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
                                corr_.cand.p, (unsigned int *)(ctl_.p + 3), round == 0 ? (uint2 *)corr_.tip_head.p : (uint2 *)nullptr,
@@ -1654,7 +1654,7 @@ public:
             if (int rc = apply_marks(g, corr_.mark, corr_.removed, s_tip, err)) return rc;
         }
         if (bubbles) {
-            HIPCHK(hipMemsetAsync(ctl_.p + 3, 0, 8, stream_));
+            HIPCHK(fill2_async(ctl_.p + 3, 8, 0u, nullptr, 0, 0u, stream_));
             hipLaunchKernelGGL(k_fork_candidates<W>, dim3(grid_for(n)), B, 0, stream_, g, alive_.p,
                                corr_.cand.p, (unsigned int *)(ctl_.p + 3));
             hipLaunchKernelGGL(k_bubble<W>, G, B, 0, stream_, g, corr_.cand.p, (const unsigned int *)(ctl_.p + 3), corr_.mark.p);
@@ -1803,7 +1803,7 @@ public:
                                    cs.winfo.p, cs.ol.p, d_ncyc, d_flags);
             }
             if (plan) {
-                HIPCHK(hipMemsetAsync(ctl_.p + 18, 0, 3 * 8, stream_));
+                HIPCHK(fill2_async(ctl_.p + 18, 3 * 8, 0u, nullptr, 0, 0u, stream_));
                 hipLaunchKernelGGL(k_plan_emit, dim3(1), dim3(1024), 0, stream_, cs.d_heads.p, (const unsigned int *)(ctl_.p + 6), (uint32_t)k_, plan->max_heads,
                                    plan->out_cap, (const uint32_t *)d_flags, plan->d_off, ctl_.p + 18);
                 hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, plan->d_off, plan->d_out, (const unsigned long long *)(ctl_.p + 18));
