@@ -1028,7 +1028,7 @@ public:
                     unsigned long long n_buckets_ub = 0;
                     for (auto &it : items) n_buckets_ub += it.F;
                     if (int rc = d_blist.alloc(n_buckets_ub, err)) return rc;
-                    HIPCHK(hipMemsetAsync(ctl_.p + 4, 0, sizeof(unsigned long long), stream_));
+                    HIPCHK(fill2_async(ctl_.p + 4, sizeof(unsigned long long), 0u, nullptr, 0, 0u, stream_));
                     if (int rc = d_sumfill.alloc(ni, err)) return rc;
                     hipLaunchKernelGGL(k_ovf_check, dim3(grid_for(ni)), dim3(256), 0, stream_, d_items.p, d_fill.p, ni, d_maxfill.p,
                                        d_blist.p, (uint32_t *)(ctl_.p + 4), d_sumfill.p);
@@ -1332,7 +1332,7 @@ public:
         if (int rc = dd_recs_.alloc(n_raw * 2 * W + 2, err)) return rc;
         if (int rc = dd_w_.alloc(n_raw + 2, err)) return rc;
         HIPCHK(hipMemcpyAsync(dd_base_.p, base.data(), (size_t)pp_.P * 8, hipMemcpyHostToDevice, stream_));
-        HIPCHK(hipMemsetAsync(ctl_.p + 12, 0, 8, stream_));
+        HIPCHK(fill2_async(ctl_.p + 12, 8, 0u, nullptr, 0, 0u, stream_));
         EvTimer t(stream_, stage_timers_);
         // (two workgroups per CU where the kernel's registers allow it, as on one GPU: with one, 588 us against 418 for the
         // bench isolate — found in the timeline of the one-rank leg, profiles/r04_final/sharded_one_rank_timeline.txt)
@@ -1542,7 +1542,7 @@ public:
             t2.stop_later("adjacency_kernel", pending_timers_);
             if (sh_active_ && sh_world_ > 1) {
                 // the candidates that live on other ranks: staged compactly before `queries` goes (shard_cross_adjacency)
-                HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+                HIPCHK(fill2_async(ctl_.p + 13, 8, 0u, nullptr, 0, 0u, stream_));
                 hipLaunchKernelGGL(k_xq_total, dim3(gp_), dim3(256), 0, stream_, gp_roff.p, queries.p, gp_cnt.p, (unsigned int *)(ctl_.p + 13));
                 unsigned int n_x = 0;
                 if (int rc = read_ctl(n_x, 13, err)) return rc;
@@ -1551,7 +1551,7 @@ public:
                 if (int rc = xq_pay_.alloc((size_t)n_x * (W + 1), err)) return rc;
                 if (int rc = xq_meta_.alloc(n_x, err)) return rc;
                 if (n_x) {
-                    HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+                    HIPCHK(fill2_async(ctl_.p + 13, 8, 0u, nullptr, 0, 0u, stream_));
                     hipLaunchKernelGGL(k_xq_stage<W>, dim3(gp_), dim3(256), 0, stream_, g.keys, k_, gp_roff.p, queries.p, gp_cnt.p,
                                        (unsigned int *)(ctl_.p + 13), n_x, xq_dest_.p, xq_pay_.p, xq_meta_.p);
                     HIPCHK(hipGetLastError());
@@ -1917,7 +1917,7 @@ public:
             if (int rc = d_off2.alloc(nh, err)) return rc;
             if (int rc = d_c.alloc(n_emit + 1, err)) return rc;
             if (int rc = d_out2.alloc(out_bytes2 + 16, err)) return rc;
-            HIPCHK(hipMemsetAsync(ctl_.p + 14, 0, 8, stream_));
+            HIPCHK(fill2_async(ctl_.p + 14, 8, 0u, nullptr, 0, 0u, stream_));
             hipLaunchKernelGGL(k_w_plan_fill, dim3(grid_for(nh)), dim3(256), 0, stream_, cs.d_heads.p, nh, (uint32_t)k_, off.p, idx.p, d_off2.p, d_c.p, (uint32_t *)(ctl_.p + 14));
             EvTimer t3(stream_, stage_timers_);
             hipLaunchKernelGGL(k_emit<W>, dim3(grid_for(n)), dim3(256), 0, stream_, g, alive_.p, cs.ol.p, d_off2.p, d_out2.p);
@@ -2297,7 +2297,7 @@ public:
         DevBuf<uint32_t> xpred;                          // per local oriented node: record of hl.recv that names its simple predecessor on another rank
         if (int rc = xpred.alloc(2ull * n + 2, err)) return rc;
         HIPCHK(hipMemsetAsync(xpred.p, 0xFF, (2ull * n + 2) * 4, stream_));
-        HIPCHK(hipMemsetAsync(ctl_.p + 13, 0, 8, stream_));
+        HIPCHK(fill2_async(ctl_.p + 13, 8, 0u, nullptr, 0, 0u, stream_));
         if (world > 1) {
             if (int rc = hdest.alloc(2ull * n + 1, err)) return rc;
             if (int rc = hpay.alloc(4ull * n + 2, err)) return rc;
